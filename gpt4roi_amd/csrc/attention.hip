@@ -1,0 +1,223 @@
+// attention.hip -- fused softmax(Q K^T * scale [+ causal mask]) V for gfx950, bf16 MFMA, fp32
+// online softmax.  Serves both transformers of the path:
+//   CLIP ViT-L/14 self-attention  (16 heads x 64, S = P^2+1, bidirectional)  -- SURVEY 8a row a4
+//   LLaMA-7B self-attention       (32 heads x 128, causal, KV cache)         -- row a16; the region
+//   tokens are ordinary query rows attending to the cached K/V (north_star: "region-token x KV").
+// The reference delegates this arithmetic to HF transformers (spi_llava.py:66-67, 198-205) or to
+// flash-attn (llava/train/llama_flash_attn_monkey_patch.py:15-91).
+//
+// Mapping: workgroup = 4 waves = 128 query rows of one (batch, head); wave = 32 query rows.
+//   S^T = K Q^T  with v_mfma_f32_32x32x16_bf16 (K tile from LDS as the A operand, Q fragments in
+//   registers as B) so that every lane owns ONE query column: its 32 score registers, its running
+//   max / sum and all of its O^T accumulator registers belong to the same query -> softmax needs
+//   one cross-lane exchange (lane ^ 32) and the O rescale is a per-lane scalar.
+//   O^T += V^T P^T : V is staged TRANSPOSED in LDS (keys contiguous) so the A operand is two
+//   8-byte reads; the key order inside each 16-key MFMA step is permuted to match the registers the
+//   lane already holds for P (no P shuffle, no LDS round trip for P).
+#include "g4r_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int KVB = 64;       // keys per tile
+constexpr int VT_LD = 68;     // Vt row stride in elements (136 B: conflict-free ds_read_b64)
+
+struct AttnArgs {
+  const bf16_t* Q;
+  const bf16_t* K;
+  const bf16_t* V;
+  bf16_t* O;
+  long q_row, k_row, v_row, o_row;      // row strides (elements)
+  long q_batch, k_batch, v_batch, o_batch;
+  int Tq, Tk, H;
+  float scale;
+  int causal;                            // query i sees keys <= i + (Tk - Tq)
+};
+
+template <int D>
+__device__ __forceinline__ int k_swz(int row) {
+  return D == 128 ? (row & 15) : ((row >> 1) & 7);
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs p) {
+  constexpr int SLOTS = D / 8;            // 16-B slots per key row
+  constexpr int KSTEPS = D / 16;          // MFMA k-steps over the head dim
+  constexpr int DB = D / 32;              // 32-row blocks of O^T
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[KVB * D];
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[D * VT_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, ql = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qblock = blockIdx.x * 128;
+  const int qi = qblock + wave * 32 + ql;
+  const int off = p.Tk - p.Tq;
+  const bf16_t* Qb = p.Q + (size_t)b * p.q_batch + (size_t)h * D;
+  const bf16_t* Kb = p.K + (size_t)b * p.k_batch + (size_t)h * D;
+  const bf16_t* Vb = p.V + (size_t)b * p.v_batch + (size_t)h * D;
+
+  // Q fragments (B operand: lane holds Q[q = lane&31][d = kk*16 + hi*8 .. +7])
+  bf16x8 qf[KSTEPS];
+  {
+    const int qr = qi < p.Tq ? qi : p.Tq - 1;
+    const bf16_t* qrow = Qb + (size_t)qr * p.q_row + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
+  }
+
+  float16v oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  int kend = p.Tk;
+  if (p.causal) {
+    const int last = qblock + 127 + off + 1;  // one past the last key any row of this block sees
+    if (last < kend) kend = last;
+  }
+
+  for (int j0 = 0; j0 < kend; j0 += KVB) {
+    // ---- stage K (row-major, swizzled) and V (transposed) ----
+#pragma unroll
+    for (int it = 0; it < KVB * SLOTS / 256; ++it) {
+      const int pk = it * 256 + tid;
+      const int row = pk / SLOTS, s = pk % SLOTS;
+      int key = j0 + row;
+      if (key > p.Tk - 1) key = p.Tk - 1;
+      const uint4v kv = *reinterpret_cast<const uint4v*>(Kb + (size_t)key * p.k_row + s * 8);
+      *reinterpret_cast<uint4v*>(reinterpret_cast<char*>(Ks) + row * (D * 2) + ((s ^ k_swz<D>(row)) << 4)) = kv;
+      // V: lanes run along keys so the transposing 2-byte stores hit distinct banks
+      const int vrow = pk % KVB, vs = pk / KVB;
+      int vkey = j0 + vrow;
+      if (vkey > p.Tk - 1) vkey = p.Tk - 1;
+      const uint4v vv = *reinterpret_cast<const uint4v*>(Vb + (size_t)vkey * p.v_row + vs * 8);
+      const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Vt[(vs * 8 + 2 * e) * VT_LD + vrow] = (bf16_t)(w[e] & 0xffffu);
+        Vt[(vs * 8 + 2 * e + 1) * VT_LD + vrow] = (bf16_t)(w[e] >> 16);
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T for two 32-key blocks ----
+    float16v sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+      const int row = kb * 32 + ql;
+      const char* krow = reinterpret_cast<const char*>(Ks) + row * (D * 2);
+      const int sw = k_swz<D>(row);
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((kk * 2 + hi) ^ sw) << 4));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sacc[kb], 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax for this lane's query (keys: j0 + kb*32 + (r&3) + 8*(r>>2) + 4*hi) ----
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float s = sacc[kb][r] * p.scale;
+        if (key >= p.Tk || (p.causal && key > qi + off)) s = -INFINITY;
+        sacc[kb][r] = s;
+        mt = fmaxf(mt, s);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float m_new = fmaxf(m_run, mt);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;  // fully masked so far: exp(-inf - 0) = 0
+    const float alpha = __expf(m_run - m_use);             // m_run = -inf -> 0
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(sacc[kb][r] - m_use);
+        sacc[kb][r] = e;
+        rs += e;
+      }
+    rs += __shfl_xor(rs, 32);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        uint4v pw;
+        pw.x = pack_bf16x2(sacc[kb][hf * 8 + 0], sacc[kb][hf * 8 + 1]);
+        pw.y = pack_bf16x2(sacc[kb][hf * 8 + 2], sacc[kb][hf * 8 + 3]);
+        pw.z = pack_bf16x2(sacc[kb][hf * 8 + 4], sacc[kb][hf * 8 + 5]);
+        pw.w = pack_bf16x2(sacc[kb][hf * 8 + 6], sacc[kb][hf * 8 + 7]);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+        const int kbase = kb * 32 + hf * 16 + 4 * hi;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const bf16_t* vrow = Vt + (d * 32 + ql) * VT_LD + kbase;
+          const uint2v lo = *reinterpret_cast<const uint2v*>(vrow);
+          const uint2v hi2 = *reinterpret_cast<const uint2v*>(vrow + 8);
+          const uint4v vw = {lo.x, lo.y, hi2.x, hi2.y};
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, oacc[d], 0, 0, 0);
+        }
+      }
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane owns query qi, d = db*32 + 8*g + 4*hi + (0..3) ----
+  if (qi < p.Tq) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    bf16_t* orow = p.O + (size_t)b * p.o_batch + (size_t)qi * p.o_row + (size_t)h * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint2v w = {pack_bf16x2(oacc[d][g * 4] * inv, oacc[d][g * 4 + 1] * inv),
+                          pack_bf16x2(oacc[d][g * 4 + 2] * inv, oacc[d][g * 4 + 3] * inv)};
+        *reinterpret_cast<uint2v*>(orow + d * 32 + g * 8 + 4 * hi) = w;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Q [B][Tq][H*D-strided rows], K/V [B][Tk][...], O [B][Tq][...]; all bf16; row/batch strides in
+// elements (multiples of 8).  head_dim 64 or 128.  causal: query i attends keys <= i + (Tk - Tq).
+int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
+                            int head_dim, long q_row, long k_row, long v_row, long o_row, long q_batch,
+                            long k_batch, long v_batch, long o_batch, float scale, int causal, void* stream) {
+  G4R_REQUIRE(B > 0 && H > 0 && Tq >= 0 && Tk > 0, "flash_attn: bad shape");
+  G4R_REQUIRE(head_dim == 64 || head_dim == 128, "flash_attn: head_dim must be 64 or 128");
+  if (Tq == 0) return G4R_OK;
+  G4R_REQUIRE(Q && K && V && O, "flash_attn: null pointer");
+  G4R_REQUIRE(q_row % 8 == 0 && k_row % 8 == 0 && v_row % 8 == 0 && o_row % 4 == 0 && q_batch % 8 == 0 &&
+                  k_batch % 8 == 0 && v_batch % 8 == 0 && o_batch % 4 == 0,
+              "flash_attn: strides must keep 16-byte alignment");
+  G4R_REQUIRE(!causal || Tk >= Tq, "flash_attn: causal needs Tk >= Tq");
+  AttnArgs a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_row, k_row, v_row, o_row,
+                q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal};
+  dim3 grid(g4r_ceil_div(Tq, 128), H, B);
+  if (head_dim == 64)
+    hipLaunchKernelGGL(flash_attn_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(flash_attn_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  G4R_CHECK_LAUNCH("flash_attn_fwd");
+  return G4R_OK;
+}
+
+}  // extern "C"

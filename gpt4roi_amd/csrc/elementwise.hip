@@ -1,0 +1,569 @@
+// elementwise.hip -- HBM-bound glue kernels of the region-feature path (NHWC, bf16 storage,
+// fp32 arithmetic, 16-byte accesses, one pass each).  Each kernel names the reference lines
+// whose arithmetic it restates for MI355X.
+#include "g4r_common.h"
+
+namespace {
+
+struct F8 {
+  float v[8];
+};
+__device__ __forceinline__ F8 ld8(const bf16_t* p) {
+  const uint4v r = *reinterpret_cast<const uint4v*>(p);
+  F8 o;
+  o.v[0] = bf16lo(r.x); o.v[1] = bf16hi(r.x); o.v[2] = bf16lo(r.y); o.v[3] = bf16hi(r.y);
+  o.v[4] = bf16lo(r.z); o.v[5] = bf16hi(r.z); o.v[6] = bf16lo(r.w); o.v[7] = bf16hi(r.w);
+  return o;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const F8& a) {
+  uint4v w;
+  w.x = pack_bf16x2(a.v[0], a.v[1]); w.y = pack_bf16x2(a.v[2], a.v[3]);
+  w.z = pack_bf16x2(a.v[4], a.v[5]); w.w = pack_bf16x2(a.v[6], a.v[7]);
+  *reinterpret_cast<uint4v*>(p) = w;
+}
+__device__ __forceinline__ F8 ld8f(const float* p) {
+  const float4v a = *reinterpret_cast<const float4v*>(p);
+  const float4v b = *reinterpret_cast<const float4v*>(p + 4);
+  F8 o = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+  return o;
+}
+
+// torch.linspace(-1, 1, n)[i] in fp32 (symmetric evaluation, as ATen's linspace kernel does)
+__device__ __forceinline__ float linspace_pm1(int i, int n) {
+  if (n == 1) return -1.f;
+  const float step = 2.f / (float)(n - 1);
+  return i < n / 2 ? -1.f + step * (float)i : 1.f - step * (float)(n - 1 - i);
+}
+
+// align_corners=True source coordinate (F.interpolate, bilinear): src = dst * (in-1)/(out-1)
+struct Lerp {
+  int i0, i1;
+  float w1;  // weight of i1; weight of i0 = 1 - w1
+};
+__device__ __forceinline__ Lerp lerp_ac(int dst, int in_size, int out_size) {
+  Lerp l;
+  if (out_size <= 1) {
+    l.i0 = l.i1 = 0;
+    l.w1 = 0.f;
+    return l;
+  }
+  const float scale = (float)(in_size - 1) / (float)(out_size - 1);
+  const float src = scale * (float)dst;
+  int i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  l.i0 = i0;
+  l.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l.w1 = src - (float)i0;
+  return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a6 + first half of a7: bilinear (align_corners=True) upsample of one ViT level to H x W,
+// concatenated with the two coordinate channels and zero padding up to Cpad channels.
+//   MLVLROIQueryModule.forward  gpt4roi/models/layers.py:225-232
+//   MLVLFuseModule.generate_coordinate / forward  layers.py:117-127, 183-189
+// in : [B, Hin*Win (+ row offset), ldin] bf16 token-major (= NHWC);  out: [B, H, W, Cpad] bf16.
+// The interpolation result is rounded to bf16 before the coordinate concat, as F.interpolate on
+// a bf16 tensor does.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample_coord_kernel(const bf16_t* __restrict__ in,
+                                                             bf16_t* __restrict__ out, int B, int Hin,
+                                                             int Win, long in_batch_stride, int ldin,
+                                                             int H, int W, int C, int Cpad) {
+  const int nvec = Cpad >> 3;
+  const long total = (long)B * H * W * nvec;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    const long pix = i / nvec;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long)W * H));
+    F8 o;
+    if (v * 8 < C) {
+      const Lerp ly = lerp_ac(y, Hin, H), lx = lerp_ac(x, Win, W);
+      const bf16_t* base = in + (size_t)b * in_batch_stride + v * 8;
+      const F8 p00 = ld8(base + ((size_t)ly.i0 * Win + lx.i0) * ldin);
+      const F8 p01 = ld8(base + ((size_t)ly.i0 * Win + lx.i1) * ldin);
+      const F8 p10 = ld8(base + ((size_t)ly.i1 * Win + lx.i0) * ldin);
+      const F8 p11 = ld8(base + ((size_t)ly.i1 * Win + lx.i1) * ldin);
+      const float wy1 = ly.w1, wy0 = 1.f - wy1, wx1 = lx.w1, wx0 = 1.f - wx1;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        o.v[k] = wy0 * (wx0 * p00.v[k] + wx1 * p01.v[k]) + wy1 * (wx0 * p10.v[k] + wx1 * p11.v[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = v * 8 + k;
+        o.v[k] = c == C ? linspace_pm1(x, W) : (c == C + 1 ? linspace_pm1(y, H) : 0.f);
+      }
+    }
+    st8(out + (size_t)pix * Cpad + v * 8, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a7: one "_single_shuffle" input assembly for ONE target level (layers.py:152-180):
+//   out[:, 0:R)        = own      [:, 0:R)
+//   out[:, R:R+S)      = interp(top [:, R+S : R+2S))      (coarser neighbour, fp32 bilinear,
+//   out[:, R+S:R+2S)   = interp(down[:, R   : R+S))        finer neighbour,   align_corners=True)
+// with R = C/2, S = C/4.  Each source may carry a deferred GroupNorm+ReLU (ConvModule order conv
+// -> GN -> ReLU, mmcv/cnn/bricks/conv_module.py:196-206): y = relu(a*x + s), a/s per (batch,
+// channel) from g4r_groupnorm_affine_nhwc_bf16; null = source already final (round 0 feeds the
+// biased 1x1-conv output directly, layers.py:191).
+// All maps NHWC bf16; result rounded to bf16 once (the conv input cast under autocast).
+// ---------------------------------------------------------------------------------------------
+struct ShuffleSrc {
+  const bf16_t* x;
+  const float* affine;  // [B, 2, C] or null
+  int H, W;
+};
+
+__device__ __forceinline__ F8 gn_relu(const F8& x, const float* aff, int b, int C, int c0) {
+  if (!aff) return x;
+  const F8 a = ld8f(aff + (size_t)b * 2 * C + c0);
+  const F8 s = ld8f(aff + (size_t)b * 2 * C + C + c0);
+  F8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o.v[k] = fmaxf(a.v[k] * x.v[k] + s.v[k], 0.f);
+  return o;
+}
+
+__device__ __forceinline__ F8 sample_src(const ShuffleSrc& s, int b, int y, int x, int H, int W, int C,
+                                         int c0) {
+  const bf16_t* base = s.x + (size_t)b * s.H * s.W * C + c0;
+  if (s.H == H && s.W == W)  // identity resize (level is its own neighbour at the ends)
+    return gn_relu(ld8(base + ((size_t)y * W + x) * C), s.affine, b, C, c0);
+  const Lerp ly = lerp_ac(y, s.H, H), lx = lerp_ac(x, s.W, W);
+  const F8 p00 = gn_relu(ld8(base + ((size_t)ly.i0 * s.W + lx.i0) * C), s.affine, b, C, c0);
+  const F8 p01 = gn_relu(ld8(base + ((size_t)ly.i0 * s.W + lx.i1) * C), s.affine, b, C, c0);
+  const F8 p10 = gn_relu(ld8(base + ((size_t)ly.i1 * s.W + lx.i0) * C), s.affine, b, C, c0);
+  const F8 p11 = gn_relu(ld8(base + ((size_t)ly.i1 * s.W + lx.i1) * C), s.affine, b, C, c0);
+  const float wy1 = ly.w1, wy0 = 1.f - wy1, wx1 = lx.w1, wx0 = 1.f - wx1;
+  F8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    o.v[k] = wy0 * (wx0 * p00.v[k] + wx1 * p01.v[k]) + wy1 * (wx0 * p10.v[k] + wx1 * p11.v[k]);
+  return o;
+}
+
+__global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShuffleSrc own, ShuffleSrc top, ShuffleSrc down,
+                                                           bf16_t* __restrict__ out, int B, int C) {
+  const int H = own.H, W = own.W;
+  const int nvec = C >> 3;
+  const int R = C >> 1, S = C >> 2;
+  const long total = (long)B * H * W * nvec;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    const long pix = i / nvec;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long)W * H));
+    const int c = v * 8;
+    F8 o;
+    if (c < R)
+      o = sample_src(own, b, y, x, H, W, C, c);
+    else if (c < R + S)
+      o = sample_src(top, b, y, x, H, W, C, c + S);   // top[:, R+S + (c-R)]
+    else
+      o = sample_src(down, b, y, x, H, W, C, c - S);  // down[:, R + (c-R-S)]
+    st8(out + (size_t)pix * C + c, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CLIP ViT front end (HF CLIPVisionEmbeddings: conv14/14 no bias -> cat(cls) -> + pos-emb).
+// ---------------------------------------------------------------------------------------------
+// img [B,3,S,S] float32 NCHW -> patches [B*P*P, Kpad] bf16, k = c*196 + ky*14 + kx (conv weight
+// flatten order), zero padded to Kpad.
+__global__ __launch_bounds__(256) void im2col_patch14_kernel(const float* __restrict__ img,
+                                                             bf16_t* __restrict__ out, int B, int S,
+                                                             int P, int Kpad) {
+  const long total = (long)B * P * P * Kpad;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % Kpad);
+    const long t = i / Kpad;
+    float v = 0.f;
+    if (k < 588) {
+      const int c = k / 196, r = k % 196, ky = r / 14, kx = r % 14;
+      const int px = (int)(t % P), py = (int)((t / P) % P), b = (int)(t / ((long)P * P));
+      v = img[(((size_t)b * 3 + c) * S + py * 14 + ky) * S + px * 14 + kx];
+    }
+    out[i] = f32_to_bf16(v);
+  }
+}
+
+// tokens[b, 0] = cls + pos[0]; tokens[b, 1+i] = patch[b*n+i] + pos[1+i]      (bf16, C % 8 == 0)
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const bf16_t* __restrict__ patch,
+                                                           const bf16_t* __restrict__ cls,
+                                                           const bf16_t* __restrict__ pos,
+                                                           bf16_t* __restrict__ tok, int B, int n, int C) {
+  const int nvec = C >> 3;
+  const long total = (long)B * (n + 1) * nvec;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    const long row = i / nvec;
+    const int s = (int)(row % (n + 1)), b = (int)(row / (n + 1));
+    const F8 a = s == 0 ? ld8(cls + v * 8) : ld8(patch + ((size_t)b * n + s - 1) * C + v * 8);
+    const F8 p = ld8(pos + (size_t)s * C + v * 8);
+    F8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = bf16_to_f32(f32_to_bf16(a.v[k])) + p.v[k];
+    st8(tok + row * C + v * 8, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LLaMA glue (the arithmetic spi_llava.py:198-205 delegates to HF LlamaModel).
+// ---------------------------------------------------------------------------------------------
+// qkv [T, 3*Hh*D] bf16 (q | k | v) -> RoPE(q) in place layout qout [T, Hh*D]; RoPE(k) and v appended
+// to the caches at rows pos0.. : kcache/vcache [maxT, Hh*D].  cos/sin [maxT, D/2] fp32.
+// rotate_half convention: x' = x*cos + rot(x)*sin, rot(x) = cat(-x[D/2:], x[:D/2]).
+__global__ __launch_bounds__(256) void rope_qkv_kernel(const bf16_t* __restrict__ qkv,
+                                                       const float* __restrict__ cs,
+                                                       const float* __restrict__ sn,
+                                                       bf16_t* __restrict__ qout,
+                                                       bf16_t* __restrict__ kcache,
+                                                       bf16_t* __restrict__ vcache, int T, int Hh, int D,
+                                                       int pos0) {
+  const int half = D >> 1;
+  const int hv = half >> 3;  // 8-wide vectors per half head
+  const long total = (long)T * Hh * hv;
+  const int HD = Hh * D;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % hv);
+    const int h = (int)((i / hv) % Hh);
+    const int t = (int)(i / ((long)hv * Hh));
+    const int pos = pos0 + t;
+    const F8 c = ld8f(cs + (size_t)pos * half + v * 8);
+    const F8 s = ld8f(sn + (size_t)pos * half + v * 8);
+    const size_t off = (size_t)h * D + v * 8;
+    const bf16_t* row = qkv + (size_t)t * 3 * HD;
+    {
+      const F8 a = ld8(row + off), b = ld8(row + off + half);
+      F8 o1, o2;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        o1.v[k] = a.v[k] * c.v[k] - b.v[k] * s.v[k];
+        o2.v[k] = b.v[k] * c.v[k] + a.v[k] * s.v[k];
+      }
+      st8(qout + (size_t)t * HD + off, o1);
+      st8(qout + (size_t)t * HD + off + half, o2);
+    }
+    {
+      const F8 a = ld8(row + HD + off), b = ld8(row + HD + off + half);
+      F8 o1, o2;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        o1.v[k] = a.v[k] * c.v[k] - b.v[k] * s.v[k];
+        o2.v[k] = b.v[k] * c.v[k] + a.v[k] * s.v[k];
+      }
+      st8(kcache + (size_t)pos * HD + off, o1);
+      st8(kcache + (size_t)pos * HD + off + half, o2);
+    }
+    *reinterpret_cast<uint4v*>(vcache + (size_t)pos * HD + off) =
+        *reinterpret_cast<const uint4v*>(row + 2 * HD + off);
+    *reinterpret_cast<uint4v*>(vcache + (size_t)pos * HD + off + half) =
+        *reinterpret_cast<const uint4v*>(row + 2 * HD + off + half);
+  }
+}
+
+// gu [T, 2*F] bf16 (gate | up) -> out [T, F] = silu(gate) * up
+__global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out,
+                                                     int T, int F) {
+  const int nvec = F >> 3;
+  const long total = (long)T * nvec;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    const long t = i / nvec;
+    const F8 g = ld8(gu + t * 2 * F + v * 8), u = ld8(gu + t * 2 * F + F + v * 8);
+    F8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float sg = bf16_to_f32(f32_to_bf16(g.v[k] / (1.f + __expf(-g.v[k]))));  // silu rounds to bf16
+      o.v[k] = sg * u.v[k];
+    }
+    st8(out + t * F + v * 8, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a15: embedding lookup + image-patch splice + <bbox> region-token injection in one gather
+// (replaces the per-sample host loop of gpt4roi/models/spi_llava.py:99-196).
+//   ids [B, T] int64.  For sample b: tokens equal to patch_id take consecutive rows of
+//   img[b] ([B, n_patch, C]); tokens equal to bbox_id take consecutive rows of spi (rows
+//   spi_offset[b] ..); everything else takes embed[id].  The reference requires the patch run to
+//   sit right after <im_start> and be followed by <im_end> (:125-128) and #<bbox> == n_i (:149-157);
+//   violations set status[b] != 0 instead of raising on the device.
+// One workgroup per sample; ranks by a block-wide prefix scan.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splice_embed_kernel(const long* __restrict__ ids,
+                                                           const bf16_t* __restrict__ embed,
+                                                           const bf16_t* __restrict__ img,
+                                                           const bf16_t* __restrict__ spi,
+                                                           const int* __restrict__ spi_offset,
+                                                           bf16_t* __restrict__ out, int* __restrict__ status,
+                                                           int T, int C, int n_patch, long patch_id,
+                                                           long bbox_id, long im_start_id, long im_end_id,
+                                                           int vocab) {
+  extern __shared__ int sh[];  // [T] patch rank, [T] bbox rank, [8] scratch
+  int* prank = sh;
+  int* brank = sh + T;
+  __shared__ int carry[2];
+  __shared__ int wsum[2][4];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long* row = ids + (size_t)b * T;
+  if (tid == 0) carry[0] = carry[1] = 0;
+  __syncthreads();
+  for (int base = 0; base < T; base += 256) {
+    const int t = base + tid;
+    const long id = t < T ? row[t] : -1;
+    const int fp = id == patch_id, fb = id == bbox_id;
+    const unsigned long long mp = __ballot(fp), mb = __ballot(fb);
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int pp = __popcll(mp & below), pb = __popcll(mb & below);
+    if (lane == 0) {
+      wsum[0][wave] = __popcll(mp);
+      wsum[1][wave] = __popcll(mb);
+    }
+    __syncthreads();
+    int op = carry[0], ob = carry[1];
+    for (int w = 0; w < wave; ++w) {
+      op += wsum[0][w];
+      ob += wsum[1][w];
+    }
+    if (t < T) {
+      prank[t] = fp ? op + pp : -1;
+      brank[t] = fb ? ob + pb : -1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      carry[0] += wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+      carry[1] += wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+    }
+    __syncthreads();
+  }
+  // structural checks (one thread; T is ~1-2k)
+  if (tid == 0) {
+    int st = 0;
+    const int np = carry[0], nb = carry[1];
+    if (np != 0 && np != n_patch) st |= 1;                       // wrong number of patch tokens
+    const int want = spi_offset ? spi_offset[b + 1] - spi_offset[b] : 0;
+    if (nb != want) st |= 2;                                       // #<bbox> != #regions
+    if (np > 0) {
+      int first = -1;
+      for (int t = 0; t < T; ++t)
+        if (prank[t] == 0) { first = t; break; }
+      if (first < 1 || row[first - 1] != im_start_id) st |= 4;    // <im_start> must precede
+      if (first + n_patch >= T || row[first + n_patch] != im_end_id) st |= 8;  // <im_end> must follow
+      for (int t = first; t < first + n_patch && t < T; ++t)
+        if (prank[t] != t - first) { st |= 16; break; }           // run must be contiguous
+    }
+    status[b] = st;
+  }
+  const int nvec = C >> 3;
+  const int so = spi_offset ? spi_offset[b] : 0;
+  for (int i = tid; i < T * nvec; i += 256) {
+    const int t = i / nvec, v = i % nvec;
+    const bf16_t* src;
+    if (prank[t] >= 0 && prank[t] < n_patch)
+      src = img + ((size_t)b * n_patch + prank[t]) * C;
+    else if (brank[t] >= 0 && spi)
+      src = spi + ((size_t)so + brank[t]) * C;
+    else {
+      long id = row[t];
+      if (id < 0) id = 0;
+      if (id >= vocab) id = vocab - 1;
+      src = embed + (size_t)id * C;
+    }
+    *reinterpret_cast<uint4v*>(out + ((size_t)b * T + t) * C + v * 8) =
+        *reinterpret_cast<const uint4v*>(src + v * 8);
+  }
+}
+
+// greedy decode: argmax over a logits row (first maximum wins, like torch.argmax on ties at the
+// lowest index).  One workgroup per row.
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, long ld, int N,
+                                                          long* __restrict__ out) {
+  __shared__ float bv[256];
+  __shared__ int bi[256];
+  const float* row = logits + (size_t)blockIdx.x * ld;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float v = row[i];
+    if (v > best || (v == best && i < idx)) {
+      best = v;
+      idx = i;
+    }
+  }
+  bv[threadIdx.x] = best;
+  bi[threadIdx.x] = idx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float v = bv[threadIdx.x + s];
+      const int i = bi[threadIdx.x + s];
+      if (v > bv[threadIdx.x] || (v == bv[threadIdx.x] && i < bi[threadIdx.x])) {
+        bv[threadIdx.x] = v;
+        bi[threadIdx.x] = i;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = bi[0];
+}
+
+// y[i] = a[i] + b[row(i) % brows]  (bf16; used for "+ pos_embedd" style adds), C % 8 == 0
+__global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ a,
+                                                       const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
+                                                       long rows, int C, long brows) {
+  const int nvec = C >> 3;
+  const long total = rows * nvec;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    const long r = i / nvec;
+    const F8 x = ld8(a + r * C + v * 8), z = ld8(b + (r % brows) * C + v * 8);
+    F8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = x.v[k] + z.v[k];
+    st8(y + r * C + v * 8, o);
+  }
+}
+
+// float32 -> bf16 and bf16 -> float32 casts (weights / feature hand-over)
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
+                                                            long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    y[i] = f32_to_bf16(x[i]);
+}
+
+inline int grid_for(long work_items) {
+  long b = (work_items + 255) / 256;
+  if (b > 256L * 16) b = 256L * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int g4r_upsample_coord_nhwc_bf16(const void* in, void* out, int B, int Hin, int Win, long in_batch_stride,
+                                 int ldin, int H, int W, int C, int Cpad, void* stream) {
+  G4R_REQUIRE(B > 0 && Hin > 0 && Win > 0 && H > 0 && W > 0, "upsample_coord: bad shape");
+  G4R_REQUIRE(C % 8 == 0 && Cpad % 8 == 0 && Cpad >= C + 2 && ldin % 8 == 0, "upsample_coord: channels");
+  G4R_REQUIRE(in && out, "upsample_coord: null pointer");
+  const long total = (long)B * H * W * (Cpad / 8);
+  hipLaunchKernelGGL(upsample_coord_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in, (bf16_t*)out, B, Hin, Win, in_batch_stride, ldin, H, W, C, Cpad);
+  G4R_CHECK_LAUNCH("upsample_coord");
+  return G4R_OK;
+}
+
+int g4r_fuse_shuffle_nhwc_bf16(const void* own, const float* own_affine, int H, int W, const void* top,
+                               const float* top_affine, int Ht, int Wt, const void* down,
+                               const float* down_affine, int Hd, int Wd, void* out, int B, int C,
+                               void* stream) {
+  G4R_REQUIRE(B > 0 && H > 0 && W > 0 && Ht > 0 && Wt > 0 && Hd > 0 && Wd > 0, "fuse_shuffle: bad shape");
+  G4R_REQUIRE(C % 32 == 0, "fuse_shuffle: C must be a multiple of 32");
+  G4R_REQUIRE(own && top && down && out, "fuse_shuffle: null pointer");
+  ShuffleSrc so = {(const bf16_t*)own, own_affine, H, W};
+  ShuffleSrc st = {(const bf16_t*)top, top_affine, Ht, Wt};
+  ShuffleSrc sd = {(const bf16_t*)down, down_affine, Hd, Wd};
+  const long total = (long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(fuse_shuffle_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, so, st,
+                     sd, (bf16_t*)out, B, C);
+  G4R_CHECK_LAUNCH("fuse_shuffle");
+  return G4R_OK;
+}
+
+int g4r_im2col_patch14_f32(const float* img, void* out, int B, int S, int Kpad, void* stream) {
+  G4R_REQUIRE(B > 0 && S > 0 && S % 14 == 0 && Kpad >= 588, "im2col_patch14: bad shape");
+  G4R_REQUIRE(img && out, "im2col_patch14: null pointer");
+  const int P = S / 14;
+  const long total = (long)B * P * P * Kpad;
+  hipLaunchKernelGGL(im2col_patch14_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img,
+                     (bf16_t*)out, B, S, P, Kpad);
+  G4R_CHECK_LAUNCH("im2col_patch14");
+  return G4R_OK;
+}
+
+int g4r_vit_assemble_bf16(const void* patch, const void* cls, const void* pos, void* tok, int B, int n, int C,
+                          void* stream) {
+  G4R_REQUIRE(B > 0 && n > 0 && C % 8 == 0, "vit_assemble: bad shape");
+  G4R_REQUIRE(patch && cls && pos && tok, "vit_assemble: null pointer");
+  const long total = (long)B * (n + 1) * (C / 8);
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)patch, (const bf16_t*)cls, (const bf16_t*)pos, (bf16_t*)tok, B, n, C);
+  G4R_CHECK_LAUNCH("vit_assemble");
+  return G4R_OK;
+}
+
+int g4r_rope_qkv_bf16(const void* qkv, const float* cos_tab, const float* sin_tab, void* q_out, void* k_cache,
+                      void* v_cache, int T, int heads, int head_dim, int pos0, void* stream) {
+  G4R_REQUIRE(T >= 0 && heads > 0 && head_dim % 16 == 0 && pos0 >= 0, "rope_qkv: bad shape");
+  if (T == 0) return G4R_OK;
+  G4R_REQUIRE(qkv && cos_tab && sin_tab && q_out && k_cache && v_cache, "rope_qkv: null pointer");
+  const long total = (long)T * heads * (head_dim / 16);
+  hipLaunchKernelGGL(rope_qkv_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)qkv, cos_tab, sin_tab, (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache, T,
+                     heads, head_dim, pos0);
+  G4R_CHECK_LAUNCH("rope_qkv");
+  return G4R_OK;
+}
+
+int g4r_swiglu_bf16(const void* gate_up, void* out, int T, int F, void* stream) {
+  G4R_REQUIRE(T >= 0 && F > 0 && F % 8 == 0, "swiglu: bad shape");
+  if (T == 0) return G4R_OK;
+  G4R_REQUIRE(gate_up && out, "swiglu: null pointer");
+  hipLaunchKernelGGL(swiglu_kernel, dim3(grid_for((long)T * (F / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)gate_up, (bf16_t*)out, T, F);
+  G4R_CHECK_LAUNCH("swiglu");
+  return G4R_OK;
+}
+
+int g4r_splice_embed_bf16(const long* ids, const void* embed, const void* img, const void* spi,
+                          const int* spi_offset, void* out, int* status, int B, int T, int C, int n_patch,
+                          long patch_id, long bbox_id, long im_start_id, long im_end_id, int vocab,
+                          void* stream) {
+  G4R_REQUIRE(B > 0 && T > 0 && C % 8 == 0 && vocab > 0 && n_patch >= 0, "splice_embed: bad shape");
+  G4R_REQUIRE(T <= 16384, "splice_embed: T <= 16384");
+  G4R_REQUIRE(ids && embed && out && status, "splice_embed: null pointer");
+  G4R_REQUIRE(n_patch == 0 || img, "splice_embed: image features missing");
+  hipLaunchKernelGGL(splice_embed_kernel, dim3(B), dim3(256), 2 * T * sizeof(int), (hipStream_t)stream, ids,
+                     (const bf16_t*)embed, (const bf16_t*)img, (const bf16_t*)spi, spi_offset, (bf16_t*)out,
+                     status, T, C, n_patch, patch_id, bbox_id, im_start_id, im_end_id, vocab);
+  G4R_CHECK_LAUNCH("splice_embed");
+  return G4R_OK;
+}
+
+int g4r_argmax_rows_f32(const float* logits, long ld, int rows, int N, long* out, void* stream) {
+  G4R_REQUIRE(rows >= 0 && N > 0, "argmax_rows: bad shape");
+  if (rows == 0) return G4R_OK;
+  G4R_REQUIRE(logits && out, "argmax_rows: null pointer");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ld, N, out);
+  G4R_CHECK_LAUNCH("argmax_rows");
+  return G4R_OK;
+}
+
+int g4r_add_rows_bf16(const void* a, const void* b, void* y, long rows, int C, long brows, void* stream) {
+  G4R_REQUIRE(rows >= 0 && C % 8 == 0 && brows > 0, "add_rows: bad shape");
+  if (rows == 0) return G4R_OK;
+  G4R_REQUIRE(a && b && y, "add_rows: null pointer");
+  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, rows, C, brows);
+  G4R_CHECK_LAUNCH("add_rows");
+  return G4R_OK;
+}
+
+int g4r_cast_f32_to_bf16(const float* x, void* y, long n, void* stream) {
+  if (n <= 0) return G4R_OK;
+  G4R_REQUIRE(x && y, "cast: null pointer");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x,
+                     (bf16_t*)y, n);
+  G4R_CHECK_LAUNCH("cast_f32_bf16");
+  return G4R_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,469 @@
+// gemm_bf16.hip -- bf16 MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (CDNA4).
+//
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T )          (nn.Linear layout: W is [out, in])
+//
+// One kernel template serves every dense contraction of the region-feature path
+// (SURVEY.md section 8a rows a4, a7, a8, a14, a16 -- the arithmetic the reference delegates to
+// cuBLAS/cuDNN through torch.nn.Linear / nn.Conv2d, e.g. gpt4roi/models/layers.py:129-144,
+// 257-270 and llava/model/llava.py:52):
+//   AMODE 0  dense A [M, lda]
+//   AMODE 1  implicit GEMM of a 3x3 / pad 1 / stride 1 convolution over NHWC activations:
+//            row m = pixel (b, y, x), K index = ((group * 9 + tap) * Cin + c); out-of-image taps
+//            read a zero line.  `groups` > 1 sums several convolutions in one accumulator
+//            (the "sum_l pconv_l(roi_feats[l])" of layers.py:321-324).
+//
+// Machine mapping (MI355X_MICROARCH.md / cdna_hip_programming.md section 5):
+//   * v_mfma_f32_32x32x16_bf16, operands swapped (W as the "A" operand) so that a lane's 4
+//     consecutive accumulator registers are 4 consecutive N columns -> 8/16-byte stores;
+//   * BK = 64; tiles staged global->LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR round
+//     trip), double buffered, one barrier per K tile;
+//   * the LDS image is lane-linear for the DMA, so the bank-conflict swizzle
+//     (16-B slot ^= (row>>1)&7) is applied on the per-lane SOURCE address and again on the
+//     ds_read_b128 address (rule "both sides or neither");
+//   * XCD-aware, bijective workgroup -> tile map so neighbouring tiles share panels in one L2.
+#include "g4r_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* W;
+  void* C;               // bf16 or f32 [M, ldc]
+  float* ws;             // split-K partials [splits][M][N] (fp32), or null
+  const float* bias;     // [N] fp32 or null
+  const bf16_t* residual;  // [M, ldr] bf16 or null
+  const bf16_t* zeros;   // >= 128 B of zeros (AMODE 1 padding source)
+  long a_group_stride;   // AMODE 1: elements between groups
+  int M, N, K;
+  int lda, ldw, ldc, ldr;
+  int act;               // 0 none, 1 relu, 2 quick_gelu (x*sigmoid(1.702x)), 3 silu
+  int out_f32;
+  int splits, tiles_per_split;  // K tiles (of 64) per z slice
+  int H, Wd, Cin, groups;      // AMODE 1 geometry
+  int tiles_m, tiles_n;
+};
+
+constexpr int BK = 64;
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return v > 0.f ? v : 0.f;
+  if (act == 2) return v / (1.f + __expf(-1.702f * v));
+  if (act == 3) return v / (1.f + __expf(-v));
+  return v;
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 3 : 4)) void gemm_bf16_nt_kernel(GemmArgs p) {
+  constexpr int NW = WM * WN;
+  constexpr int NT = NW * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 accumulators per wave
+  constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;  // 16-B slots staged per thread
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE_BYTES
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- XCD-aware bijective remap of the 1-D grid (cdna_hip_programming.md 5.5 T1) ----
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  // tile order: M fastest inside a column panel group so consecutive workgroups of one XCD
+  // reuse the same W panel (weights are the big operand for M << N shapes).
+  const int tile_m = wg % p.tiles_m, tile_n = wg / p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int split = blockIdx.y;
+  const int t_begin = split * p.tiles_per_split;
+  int t_end = t_begin + p.tiles_per_split;
+  const int nt_total = p.K / BK;
+  if (t_end > nt_total) t_end = nt_total;
+
+  // ---- per-thread staging descriptors ----
+  const bf16_t* a_src[NA];
+  int a_y[NA], a_x[NA];
+  const bf16_t* b_src[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int pslot = (j * NW + wave) * 64 + lane;
+    const int row = pslot >> 3, ps = pslot & 7;
+    const int kslot = ps ^ ((row >> 1) & 7);
+    int gm = m0 + row;
+    if (gm > p.M - 1) gm = p.M - 1;
+    if (AMODE == 0) {
+      a_src[j] = p.A + (size_t)gm * p.lda + kslot * 8;
+      a_y[j] = a_x[j] = 0;
+    } else {
+      const int hw = p.H * p.Wd;
+      const int b = gm / hw, rem = gm - b * hw;
+      a_y[j] = rem / p.Wd;
+      a_x[j] = rem - a_y[j] * p.Wd;
+      a_src[j] = p.A + (size_t)gm * p.lda + kslot * 8;  // centre tap of this pixel
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int pslot = (j * NW + wave) * 64 + lane;
+    const int row = pslot >> 3, ps = pslot & 7;
+    const int kslot = ps ^ ((row >> 1) & 7);
+    int gn = n0 + row;
+    if (gn > p.N - 1) gn = p.N - 1;
+    b_src[j] = p.W + (size_t)gn * p.ldw + kslot * 8;
+  }
+
+  auto stage = [&](int t, int buf) {
+    char* sa = smem + buf * STAGE_BYTES;
+    char* sb = sa + A_BYTES;
+    const int k0 = t * BK;
+    // A operand
+    long a_off;
+    int dy = 0, dx = 0;
+    if (AMODE == 0) {
+      a_off = k0;
+    } else {
+      const int per_tap = p.Cin / BK;           // K tiles per tap
+      const int tap_lin = t / per_tap;          // group * 9 + tap
+      const int c0 = (t - tap_lin * per_tap) * BK;
+      const int grp = tap_lin / 9, tap = tap_lin - grp * 9;
+      dy = tap / 3 - 1;
+      dx = tap - (tap / 3) * 3 - 1;
+      a_off = (long)grp * p.a_group_stride + ((long)dy * p.Wd + dx) * p.lda + c0;
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const bf16_t* src = a_src[j] + a_off;
+      if (AMODE == 1) {
+        const int yy = a_y[j] + dy, xx = a_x[j] + dx;
+        if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.Wd) src = p.zeros + (lane & 7) * 8;
+      }
+      char* dst_wave = sa + (j * NW + wave) * 1024;
+      if (GLDS) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst_wave, 16, 0, 0);
+      } else {
+        *reinterpret_cast<uint4v*>(dst_wave + lane * 16) = *reinterpret_cast<const uint4v*>(src);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bf16_t* src = b_src[j] + k0;
+      char* dst_wave = sb + (j * NW + wave) * 1024;
+      if (GLDS) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst_wave, 16, 0, 0);
+      } else {
+        *reinterpret_cast<uint4v*>(dst_wave + lane * 16) = *reinterpret_cast<const uint4v*>(src);
+      }
+    }
+  };
+
+  float16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets: row = base + (lane & 31), 16-B slot = (kk*2 + (lane>>5)) ^ ((row>>1)&7)
+  const int frow = lane & 31;
+  const int fsw = (frow >> 1) & 7;
+  const int fhi = lane >> 5;
+  const int a_row_off = (wm * WTM + frow) * 128;
+  const int b_row_off = (wn * WTN + frow) * 128;
+
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * STAGE_BYTES;
+    const char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int slot = ((kk * 2 + fhi) ^ fsw) << 4;
+      bf16x8 af[TM], wf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * 128 + slot);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * 128 + slot);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (t_begin < t_end) {
+    stage(t_begin, 0);
+    __syncthreads();  // drains the LDS-DMA queue (vmcnt(0)) and publishes the tile
+    int cur = 0;
+    for (int t = t_begin; t < t_end - 1; ++t) {
+      stage(t + 1, cur ^ 1);
+      compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
+    compute(cur);
+  }
+
+  // ---- epilogue.  D[i = n][j = m]: m = lane & 31, n = 8*(r>>2) + 4*(lane>>5) + (r&3) ----
+  const int em = lane & 31, en = 4 * (lane >> 5);
+  const bool vec_ok = (p.N & 3) == 0;  // then every in-range quad is a full, aligned quad
+  const int mw = m0 + wm * WTM + em, nw = n0 + wn * WTN + en;
+  if (p.splits > 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = mw + i * 32, n = nw + j * 32 + q * 8;
+          if (m < p.M && n < p.N) {
+            float* dst = p.ws + ((size_t)split * p.M + m) * p.N + n;
+            if (vec_ok) {
+              *reinterpret_cast<float4v*>(dst) = float4v{acc[i][j][q * 4], acc[i][j][q * 4 + 1],
+                                                         acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) dst[r] = acc[i][j][q * 4 + r];
+            }
+          }
+        }
+    return;
+  }
+  // One 32x32 accumulator at a time (keeps the live range of epilogue temporaries short):
+  // bias (16-B loads) -> activation (wave-uniform branch) -> residual add -> packed store.
+  const bool res_vec = vec_ok && (p.ldr & 3) == 0;
+  const bool out_vec = vec_ok && (p.ldc & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float16v c = acc[i][j];
+      const int m = mw + i * 32;
+      if (p.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nw + j * 32 + q * 8;
+          float4v b = {0.f, 0.f, 0.f, 0.f};
+          if (n < p.N) {
+            if (vec_ok) {
+              b = *reinterpret_cast<const float4v*>(p.bias + n);
+            } else {
+              b.x = p.bias[n];
+              if (n + 1 < p.N) b.y = p.bias[n + 1];
+              if (n + 2 < p.N) b.z = p.bias[n + 2];
+              if (n + 3 < p.N) b.w = p.bias[n + 3];
+            }
+          }
+          c[q * 4 + 0] += b.x;
+          c[q * 4 + 1] += b.y;
+          c[q * 4 + 2] += b.z;
+          c[q * 4 + 3] += b.w;
+        }
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = fmaxf(c[r], 0.f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = c[r] / (1.f + __expf(-1.702f * c[r]));
+      } else if (p.act == 3) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = c[r] / (1.f + __expf(-c[r]));
+      }
+      if (m < p.M) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nw + j * 32 + q * 8;
+          if (n >= p.N) continue;
+          float v0 = c[q * 4], v1 = c[q * 4 + 1], v2 = c[q * 4 + 2], v3 = c[q * 4 + 3];
+          if (p.residual) {
+            const bf16_t* rp = p.residual + (size_t)m * p.ldr + n;
+            if (res_vec) {
+              const uint2v rr = *reinterpret_cast<const uint2v*>(rp);
+              v0 += bf16lo(rr.x); v1 += bf16hi(rr.x); v2 += bf16lo(rr.y); v3 += bf16hi(rr.y);
+            } else {
+              v0 += bf16_to_f32(rp[0]);
+              if (n + 1 < p.N) v1 += bf16_to_f32(rp[1]);
+              if (n + 2 < p.N) v2 += bf16_to_f32(rp[2]);
+              if (n + 3 < p.N) v3 += bf16_to_f32(rp[3]);
+            }
+          }
+          if (p.out_f32) {
+            float* dst = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+            if (out_vec) {
+              *reinterpret_cast<float4v*>(dst) = float4v{v0, v1, v2, v3};
+            } else {
+              dst[0] = v0;
+              if (n + 1 < p.N) dst[1] = v1;
+              if (n + 2 < p.N) dst[2] = v2;
+              if (n + 3 < p.N) dst[3] = v3;
+            }
+          } else {
+            bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+            if (out_vec) {
+              *reinterpret_cast<uint2v*>(dst) = uint2v{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+            } else {
+              dst[0] = f32_to_bf16(v0);
+              if (n + 1 < p.N) dst[1] = f32_to_bf16(v1);
+              if (n + 2 < p.N) dst[2] = f32_to_bf16(v2);
+              if (n + 3 < p.N) dst[3] = f32_to_bf16(v3);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// split-K combine + epilogue: C = act(sum_s ws[s] + bias) + residual
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
+  const long total = (long)p.M * p.N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i % p.N);
+    const long m = i / p.N;
+    float x = 0.f;
+    for (int s = 0; s < p.splits; ++s) x += p.ws[(size_t)s * total + i];
+    if (p.bias) x += p.bias[n];
+    x = apply_act(x, p.act);
+    if (p.residual) x += bf16_to_f32(p.residual[(size_t)m * p.ldr + n]);
+    if (p.out_f32)
+      reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = x;
+    else
+      reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(x);
+  }
+}
+
+// Tiny/irregular contractions (K not a multiple of 64, e.g. the Linear(4,256) of pos_embedd,
+// gpt4roi/models/layers.py:260-267): one thread per output, fp32 accumulate.  Not a hot path.
+__global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restrict__ A,
+                                                           const bf16_t* __restrict__ W,
+                                                           const float* __restrict__ bias,
+                                                           void* __restrict__ C, int M, int N, int K,
+                                                           int lda, int ldw, int ldc, int act,
+                                                           int out_f32) {
+  const long total = (long)M * N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i % N);
+    const long m = i / N;
+    float x = 0.f;
+    for (int k = 0; k < K; ++k) x += bf16_to_f32(A[m * lda + k]) * bf16_to_f32(W[(size_t)n * ldw + k]);
+    if (bias) x += bias[n];
+    x = apply_act(x, act);
+    if (out_f32)
+      reinterpret_cast<float*>(C)[m * ldc + n] = x;
+    else
+      reinterpret_cast<bf16_t*>(C)[m * ldc + n] = f32_to_bf16(x);
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS>
+int launch_tile(GemmArgs& p, hipStream_t stream) {
+  p.tiles_m = g4r_ceil_div(p.M, BM);
+  p.tiles_n = g4r_ceil_div(p.N, BN);
+  const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, AMODE, GLDS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return g4r_note_hip_error(e, "gemm: hipFuncSetAttribute");
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, p.splits);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
+  G4R_CHECK_LAUNCH("gemm_bf16_nt");
+  if (p.splits > 1) {
+    long total = (long)p.M * p.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    G4R_CHECK_LAUNCH("splitk_reduce");
+  }
+  return G4R_OK;
+}
+
+template <int AMODE>
+int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
+  switch (tile_cfg) {
+    case 0: return launch_tile<128, 128, 2, 2, AMODE, true>(p, stream);
+    case 1: return launch_tile<256, 128, 4, 2, AMODE, true>(p, stream);
+    case 2: return launch_tile<128, 128, 2, 2, AMODE, false>(p, stream);  // register-staged A/B probe
+    case 4: return launch_tile<64, 128, 1, 4, AMODE, true>(p, stream);
+    default: return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// See include/g4r_kernels.h for the contract.
+int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, const void* residual,
+                     float* workspace, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
+                     int act, int out_f32, int splits, int tile_cfg, void* stream) {
+  G4R_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative shape");
+  if (M == 0 || N == 0) return G4R_OK;
+  G4R_REQUIRE(A && W && C, "gemm: null pointer");
+  G4R_REQUIRE(act >= 0 && act <= 3, "gemm: act must be 0..3");
+  if (K % BK != 0 || K == 0) {
+    G4R_REQUIRE(residual == nullptr, "gemm: residual unsupported on the small-K path");
+    long total = (long)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(small_linear_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)A, (const bf16_t*)W, bias, C, M, N, K, lda, ldw, ldc, act, out_f32);
+    G4R_CHECK_LAUNCH("small_linear");
+    return G4R_OK;
+  }
+  G4R_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0, "gemm: lda/ldw must be multiples of 8 (16-byte rows)");
+  G4R_REQUIRE(splits >= 1, "gemm: splits >= 1");
+  G4R_REQUIRE(splits == 1 || workspace, "gemm: split-K needs a workspace of splits*M*N floats");
+  GemmArgs p = {};
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.ws = workspace; p.bias = bias;
+  p.residual = (const bf16_t*)residual;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
+  p.act = act; p.out_f32 = out_f32;
+  const int nt = K / BK;
+  if (splits > nt) splits = nt;
+  p.tiles_per_split = g4r_ceil_div(nt, splits);
+  p.splits = g4r_ceil_div(nt, p.tiles_per_split);
+  return launch_gemm<0>(p, tile_cfg, (hipStream_t)stream);
+}
+
+int g4r_conv3x3_nhwc_bf16(const void* X, const void* W, void* Y, const float* bias, const void* zeros,
+                          float* workspace, int batch, int H, int Wd, int Cin, int Cout, int groups,
+                          long x_group_stride, int act, int out_f32, int splits, int tile_cfg,
+                          void* stream) {
+  G4R_REQUIRE(batch >= 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && groups >= 1, "conv3x3: bad shape");
+  if (batch == 0) return G4R_OK;
+  G4R_REQUIRE(X && W && Y && zeros, "conv3x3: null pointer");
+  G4R_REQUIRE((Cin % BK) == 0, "conv3x3: Cin must be a multiple of 64");
+  G4R_REQUIRE(act >= 0 && act <= 3, "conv3x3: act must be 0..3");
+  G4R_REQUIRE(splits >= 1 && (splits == 1 || workspace), "conv3x3: split-K needs a workspace");
+  GemmArgs p = {};
+  p.A = (const bf16_t*)X; p.W = (const bf16_t*)W; p.C = Y; p.ws = workspace; p.bias = bias;
+  p.zeros = (const bf16_t*)zeros;
+  p.M = batch * H * Wd; p.N = Cout; p.K = groups * 9 * Cin;
+  p.lda = Cin; p.ldw = p.K; p.ldc = Cout; p.ldr = 0;
+  p.act = act; p.out_f32 = out_f32;
+  p.H = H; p.Wd = Wd; p.Cin = Cin; p.groups = groups; p.a_group_stride = x_group_stride;
+  const int nt = p.K / BK;
+  if (splits > nt) splits = nt;
+  p.tiles_per_split = g4r_ceil_div(nt, splits);
+  p.splits = g4r_ceil_div(nt, p.tiles_per_split);
+  return launch_gemm<1>(p, tile_cfg, (hipStream_t)stream);
+}
+
+}  // extern "C"

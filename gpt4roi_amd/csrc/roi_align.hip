@@ -1,0 +1,527 @@
+// roi_align.hip -- RoIAlign for MI355X (gfx950), written from scratch for CDNA4.
+//
+// Replaces, behind the C ABI of include/g4r_roi_align.h, the reference's
+//   roi_align_forward_cuda_kernel / roi_align_backward_cuda_kernel
+//   (/root/reference/mmcv-1.4.7/mmcv/ops/csrc/common/cuda/roi_align_cuda_kernel.cuh:17-210,
+//    bilinear helpers common/cuda/common_cuda_helper.hpp:28-119).
+// Same sampling rules, different machine mapping:
+//   * the bilinear taps of a RoI are separable (row taps x column taps) and shared by all
+//     channels, so a workgroup first builds the two 1-D tap tables of its RoI in LDS and then
+//     only gathers -- the CUDA kernel recomputes all of it per output element;
+//   * NCHW drop-in kernel: one workgroup = (RoI, slab of channels); consecutive lanes own
+//     consecutive bins of one channel plane => output stores are fully coalesced and the 16
+//     gathers of a bin stay inside the RoI's window of one plane (L1/L2 resident);
+//   * NHWC multi-level kernel (the fused region path): one wave = one bin, lanes over channels,
+//     every corner is one contiguous 16 B/lane (1 KiB/wave) load, 4 levels in one launch, the
+//     workgroup -> (level, RoI) map is XCD-aware so a RoI's window stays in one XCD's L2.
+// Arithmetic follows the reference's expression order (no FMA contraction in this file), so
+// fp32 results agree with the reference CPU implementation to the last bit on most inputs.
+#include <float.h>
+#include <hip/hip_fp16.h>
+
+#include "g4r_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+template <typename CT>
+struct Tap1D {
+  CT coord;  // the un-clamped sample coordinate (what max-pool records as argmax)
+  CT frac;   // l = v - low   (h = 1 - l)
+  int lo, hi;
+  int valid;
+};
+
+// roi_align_cuda_kernel.cuh / common_cuda_helper.hpp:33-56, one axis at a time.
+template <typename CT>
+__device__ __forceinline__ Tap1D<CT> make_tap1d(CT v, int size) {
+  Tap1D<CT> t;
+  t.coord = v;
+  if (v < (CT)-1.0 || v > (CT)size) {
+    t.frac = (CT)0;
+    t.lo = t.hi = 0;
+    t.valid = 0;
+    return t;
+  }
+  if (v <= (CT)0) v = (CT)0;
+  int lo = (int)v, hi;
+  if (lo >= size - 1) {
+    hi = lo = size - 1;
+    v = (CT)lo;
+  } else {
+    hi = lo + 1;
+  }
+  t.frac = v - (CT)lo;
+  t.lo = lo;
+  t.hi = hi;
+  t.valid = 1;
+  return t;
+}
+
+template <typename CT>
+struct RoiGeom {
+  CT start_h, start_w, bin_h, bin_w;
+  int grid_h, grid_w;
+  int batch;
+};
+
+// roi_align_cuda_kernel.cuh:31-62
+template <typename CT, typename RT>
+__device__ __forceinline__ RoiGeom<CT> roi_geometry(const RT* roi, CT scale, int aligned, int PH,
+                                                    int PW, int sr) {
+  RoiGeom<CT> g;
+  g.batch = (int)(CT)roi[0];
+  const CT offset = aligned ? (CT)0.5 : (CT)0.0;
+  const CT sw = (CT)roi[1] * scale - offset;
+  const CT sh = (CT)roi[2] * scale - offset;
+  const CT ew = (CT)roi[3] * scale - offset;
+  const CT eh = (CT)roi[4] * scale - offset;
+  CT rw = ew - sw, rh = eh - sh;
+  if (!aligned) {
+    rw = rw > (CT)1. ? rw : (CT)1.;
+    rh = rh > (CT)1. ? rh : (CT)1.;
+  }
+  g.start_h = sh;
+  g.start_w = sw;
+  g.bin_h = rh / (CT)PH;
+  g.bin_w = rw / (CT)PW;
+  g.grid_h = sr > 0 ? sr : (int)ceilf((float)(rh / (CT)PH));
+  g.grid_w = sr > 0 ? sr : (int)ceilf((float)(rw / (CT)PW));
+  return g;
+}
+
+template <typename CT>
+__device__ __forceinline__ CT sample_coord(CT start, CT bin, int p, int i, int grid) {
+  // "roi_start + p * bin + (i + .5f) * bin / grid", the reference's order (cuh:66-72)
+  return start + (CT)p * bin + (CT)((float)i + .5f) * bin / (CT)grid;
+}
+
+template <typename T> __device__ __forceinline__ float ld(const float* p) { return *p; }
+__device__ __forceinline__ float load_as(const float* p, float) { return *p; }
+__device__ __forceinline__ double load_as(const double* p, double) { return *p; }
+__device__ __forceinline__ float load_as(const __half* p, float) { return __half2float(*p); }
+__device__ __forceinline__ void store_as(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store_as(double* p, double v) { *p = v; }
+__device__ __forceinline__ void store_as(__half* p, float v) { *p = __float2half(v); }
+
+// ---------------------------------------------------------------------------------------------
+// NCHW forward (the mmcv drop-in).  grid = (n_rois, ceil(C / cpb)), block = 256.
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename CT, int MAXTAB>
+__global__ __launch_bounds__(256) void roi_align_fwd_nchw_kernel(
+    const T* __restrict__ in, const T* __restrict__ rois, T* __restrict__ out,
+    T* __restrict__ amy, T* __restrict__ amx, int B, int C, int H, int W, int PH, int PW, CT scale,
+    int sr, int pool_mode, int aligned, int cpb) {
+  __shared__ Tap1D<CT> ytab[MAXTAB];
+  __shared__ Tap1D<CT> xtab[MAXTAB];
+  const int n = blockIdx.x;
+  const int c0 = blockIdx.y * cpb;
+  const int c1 = min(C, c0 + cpb);
+  const int tid = threadIdx.x;
+  const RoiGeom<CT> g = roi_geometry<CT>(rois + (size_t)5 * n, scale, aligned, PH, PW, sr);
+  const int gh = g.grid_h, gw = g.grid_w;
+  const int ny = PH * gh, nx = PW * gw;
+  const bool use_tab = ny <= MAXTAB && nx <= MAXTAB;  // workgroup-uniform
+  if (use_tab) {
+    for (int i = tid; i < ny; i += 256)
+      ytab[i] = make_tap1d<CT>(sample_coord<CT>(g.start_h, g.bin_h, i / gh, i % gh, gh), H);
+    for (int i = tid; i < nx; i += 256)
+      xtab[i] = make_tap1d<CT>(sample_coord<CT>(g.start_w, g.bin_w, i / gw, i % gw, gw), W);
+    __syncthreads();
+  }
+  const int bins = PH * PW;
+  const int total = (c1 - c0) * bins;
+  const bool batch_ok = g.batch >= 0 && g.batch < B;
+  const int per_bin = gh * gw;
+  const CT count = (CT)(per_bin > 1 ? per_bin : 1);
+  for (int idx = tid; idx < total; idx += 256) {
+    const int c = c0 + idx / bins;
+    const int bin = idx % bins;
+    const int ph = bin / PW, pw = bin % PW;
+    const size_t oi = ((size_t)n * C + c) * bins + bin;
+    if (!batch_ok) {
+      store_as(out + oi, (CT)0);
+      if (pool_mode == 0) {
+        store_as(amy + oi, (CT)-1.f);
+        store_as(amx + oi, (CT)-1.f);
+      }
+      continue;
+    }
+    const T* plane = in + ((size_t)g.batch * C + c) * H * W;
+    CT acc = (CT)0;
+    CT best = (CT)-FLT_MAX, by = (CT)-1.f, bx = (CT)-1.f;
+    for (int iy = 0; iy < gh; ++iy) {
+      const Tap1D<CT> ty = use_tab ? ytab[ph * gh + iy]
+                                   : make_tap1d<CT>(sample_coord<CT>(g.start_h, g.bin_h, ph, iy, gh), H);
+      for (int ix = 0; ix < gw; ++ix) {
+        const Tap1D<CT> tx = use_tab ? xtab[pw * gw + ix]
+                                     : make_tap1d<CT>(sample_coord<CT>(g.start_w, g.bin_w, pw, ix, gw), W);
+        CT val = (CT)0;
+        if (ty.valid && tx.valid) {
+          const CT ly = ty.frac, lx = tx.frac;
+          const CT hy = (CT)1. - ly, hx = (CT)1. - lx;
+          const CT v1 = load_as(plane + ty.lo * W + tx.lo, CT());
+          const CT v2 = load_as(plane + ty.lo * W + tx.hi, CT());
+          const CT v3 = load_as(plane + ty.hi * W + tx.lo, CT());
+          const CT v4 = load_as(plane + ty.hi * W + tx.hi, CT());
+          const CT w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+          val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+        }
+        if (val > best) {
+          best = val;
+          by = ty.coord;
+          bx = tx.coord;
+        }
+        acc += val;
+      }
+    }
+    if (pool_mode == 0) {
+      store_as(out + oi, best);
+      store_as(amy + oi, by);
+      store_as(amx + oi, bx);
+    } else {
+      store_as(out + oi, acc / count);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCHW backward: scatter with hardware float atomics (as the reference does, cuh:111-210).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_accum(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_accum(double* p, double v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_accum(__half* p, float v) {
+  // 16-bit add through a CAS on the enclosing aligned dword
+  unsigned int* word = (unsigned int*)((uintptr_t)p & ~(uintptr_t)3);
+  const bool upper = ((uintptr_t)p & 2) != 0;
+  unsigned int old = *word, assumed;
+  do {
+    assumed = old;
+    unsigned short h = upper ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xffffu);
+    __half hv = __ushort_as_half(h);
+    unsigned short nh = __half_as_ushort(__float2half(__half2float(hv) + v));
+    unsigned int repl = upper ? ((assumed & 0x0000ffffu) | ((unsigned int)nh << 16))
+                              : ((assumed & 0xffff0000u) | nh);
+    old = atomicCAS(word, assumed, repl);
+  } while (old != assumed);
+}
+
+template <typename T, typename CT>
+__global__ __launch_bounds__(256) void roi_align_bwd_nchw_kernel(
+    const T* __restrict__ gout, const T* __restrict__ rois, const T* __restrict__ amy,
+    const T* __restrict__ amx, T* __restrict__ gin, long nthreads, int B, int C, int H, int W,
+    int PH, int PW, CT scale, int sr, int pool_mode, int aligned) {
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads;
+       index += (long)blockDim.x * gridDim.x) {
+    const int pw = (int)(index % PW);
+    const int ph = (int)((index / PW) % PH);
+    const int c = (int)((index / PW / PH) % C);
+    const int n = (int)(index / PW / PH / C);
+    const CT go = load_as(gout + index, CT());
+    const RoiGeom<CT> g = roi_geometry<CT>(rois + (size_t)5 * n, scale, aligned, PH, PW, sr);
+    if (g.batch < 0 || g.batch >= B) continue;
+    T* gplane = gin + ((size_t)g.batch * C + c) * H * W;
+    if (pool_mode == 0) {
+      const CT y = load_as(amy + index, CT()), x = load_as(amx + index, CT());
+      if (y != (CT)-1.f) {
+        const Tap1D<CT> ty = make_tap1d<CT>(y, H), tx = make_tap1d<CT>(x, W);
+        if (ty.valid && tx.valid) {
+          const CT ly = ty.frac, lx = tx.frac, hy = (CT)1. - ly, hx = (CT)1. - lx;
+          atomic_accum(gplane + ty.lo * W + tx.lo, go * (hy * hx));
+          atomic_accum(gplane + ty.lo * W + tx.hi, go * (hy * lx));
+          atomic_accum(gplane + ty.hi * W + tx.lo, go * (ly * hx));
+          atomic_accum(gplane + ty.hi * W + tx.hi, go * (ly * lx));
+        }
+      }
+    } else {
+      const int gh = g.grid_h, gw = g.grid_w;
+      const CT count = (CT)(gh * gw);
+      for (int iy = 0; iy < gh; ++iy) {
+        const Tap1D<CT> ty = make_tap1d<CT>(sample_coord<CT>(g.start_h, g.bin_h, ph, iy, gh), H);
+        for (int ix = 0; ix < gw; ++ix) {
+          const Tap1D<CT> tx = make_tap1d<CT>(sample_coord<CT>(g.start_w, g.bin_w, pw, ix, gw), W);
+          if (ty.valid && tx.valid) {
+            const CT ly = ty.frac, lx = tx.frac, hy = (CT)1. - ly, hx = (CT)1. - lx;
+            atomic_accum(gplane + ty.lo * W + tx.lo, go * (hy * hx) / count);
+            atomic_accum(gplane + ty.lo * W + tx.hi, go * (hy * lx) / count);
+            atomic_accum(gplane + ty.hi * W + tx.lo, go * (ly * hx) / count);
+            atomic_accum(gplane + ty.hi * W + tx.hi, go * (ly * lx) / count);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NHWC multi-level forward (fused region path).  One launch = all levels of
+// MlvlRoIExtractor.forward (gpt4roi/models/layers.py:307-313).
+// workgroup = (level, roi, bin-row ph); wave = bin; lane = 8 consecutive channels.
+// ---------------------------------------------------------------------------------------------
+#define G4R_MAX_LEVELS 8
+struct MlvlArgs {
+  const void* feat[G4R_MAX_LEVELS];
+  const float* affine[G4R_MAX_LEVELS];  // deferred GroupNorm+ReLU: [B, 2, C] (a then s) or null
+  int H[G4R_MAX_LEVELS];
+  int W[G4R_MAX_LEVELS];
+  float scale[G4R_MAX_LEVELS];
+};
+
+struct Vec8 {
+  float v[8];
+};
+__device__ __forceinline__ Vec8 load8(const bf16_t* p) {
+  const uint4v r = *reinterpret_cast<const uint4v*>(p);
+  Vec8 o;
+  o.v[0] = bf16lo(r.x); o.v[1] = bf16hi(r.x); o.v[2] = bf16lo(r.y); o.v[3] = bf16hi(r.y);
+  o.v[4] = bf16lo(r.z); o.v[5] = bf16hi(r.z); o.v[6] = bf16lo(r.w); o.v[7] = bf16hi(r.w);
+  return o;
+}
+__device__ __forceinline__ Vec8 load8(const float* p) {
+  const float4v a = *reinterpret_cast<const float4v*>(p);
+  const float4v b = *reinterpret_cast<const float4v*>(p + 4);
+  Vec8 o;
+  o.v[0] = a.x; o.v[1] = a.y; o.v[2] = a.z; o.v[3] = a.w;
+  o.v[4] = b.x; o.v[5] = b.y; o.v[6] = b.z; o.v[7] = b.w;
+  return o;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const Vec8& a) {
+  uint4v r;
+  r.x = pack_bf16x2(a.v[0], a.v[1]); r.y = pack_bf16x2(a.v[2], a.v[3]);
+  r.z = pack_bf16x2(a.v[4], a.v[5]); r.w = pack_bf16x2(a.v[6], a.v[7]);
+  *reinterpret_cast<uint4v*>(p) = r;
+}
+__device__ __forceinline__ void store8(float* p, const Vec8& a) {
+  float4v x = {a.v[0], a.v[1], a.v[2], a.v[3]}, y = {a.v[4], a.v[5], a.v[6], a.v[7]};
+  *reinterpret_cast<float4v*>(p) = x;
+  *reinterpret_cast<float4v*>(p + 4) = y;
+}
+
+#define MLVL_MAX_XTAB 256
+#define MLVL_MAX_YTAB 16
+
+template <typename TI>
+__global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_kernel(MlvlArgs a,
+                                                                  const float* __restrict__ rois,
+                                                                  TI* __restrict__ out, int L, int B,
+                                                                  int C, int N, int PH, int PW, int sr,
+                                                                  int aligned) {
+  __shared__ Tap1D<float> xtab[MLVL_MAX_XTAB];
+  __shared__ Tap1D<float> ytab[MLVL_MAX_YTAB];
+  // XCD-aware decode: workgroup b runs on XCD b % 8 (observed dispatch); give all PH rows of
+  // one (level, roi) group to the same XCD so its window of the map is fetched into one L2.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int q = bid >> 3;
+  const int ph = q % PH;
+  const int grp = (q / PH) * 8 + xcd;
+  if (grp >= L * N) return;
+  const int l = grp / N, n = grp % N;
+  const int H = a.H[l], W = a.W[l];
+  const TI* feat = reinterpret_cast<const TI*>(a.feat[l]);
+  const RoiGeom<float> g = roi_geometry<float>(rois + (size_t)5 * n, a.scale[l], aligned, PH, PW, sr);
+  const int tid = threadIdx.x;
+  if (tid < sr) ytab[tid] = make_tap1d<float>(sample_coord<float>(g.start_h, g.bin_h, ph, tid, sr), H);
+  for (int i = tid; i < PW * sr; i += 256)
+    xtab[i] = make_tap1d<float>(sample_coord<float>(g.start_w, g.bin_w, i / sr, i % sr, sr), W);
+  __syncthreads();
+  const bool batch_ok = g.batch >= 0 && g.batch < B;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int nvec = C >> 3;
+  const float count = (float)(sr * sr);
+  const int bi = batch_ok ? g.batch : 0;
+  const TI* img = feat + (size_t)bi * H * W * C;
+  const float* aff = a.affine[l] ? a.affine[l] + (size_t)bi * 2 * C : nullptr;
+  for (int pw = wave; pw < PW; pw += 4) {
+    TI* orow = out + ((((size_t)l * N + n) * PH + ph) * PW + pw) * C;
+    for (int v = lane; v < nvec; v += 64) {
+      Vec8 acc;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc.v[k] = 0.f;
+      Vec8 ga, gs;
+      if (aff) {
+        ga = load8(aff + v * 8);
+        gs = load8(aff + C + v * 8);
+      }
+      if (batch_ok) {
+        for (int iy = 0; iy < sr; ++iy) {
+          const Tap1D<float> ty = ytab[iy];
+          for (int ix = 0; ix < sr; ++ix) {
+            const Tap1D<float> tx = xtab[pw * sr + ix];
+            if (ty.valid && tx.valid) {
+              const float ly = ty.frac, lx = tx.frac, hy = 1.f - ly, hx = 1.f - lx;
+              const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+              Vec8 v1 = load8(img + ((size_t)ty.lo * W + tx.lo) * C + v * 8);
+              Vec8 v2 = load8(img + ((size_t)ty.lo * W + tx.hi) * C + v * 8);
+              Vec8 v3 = load8(img + ((size_t)ty.hi * W + tx.lo) * C + v * 8);
+              Vec8 v4 = load8(img + ((size_t)ty.hi * W + tx.hi) * C + v * 8);
+              if (aff) {  // ConvModule's GN + ReLU applied to the raw conv output, per texel
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                  v1.v[k] = fmaxf(ga.v[k] * v1.v[k] + gs.v[k], 0.f);
+                  v2.v[k] = fmaxf(ga.v[k] * v2.v[k] + gs.v[k], 0.f);
+                  v3.v[k] = fmaxf(ga.v[k] * v3.v[k] + gs.v[k], 0.f);
+                  v4.v[k] = fmaxf(ga.v[k] * v4.v[k] + gs.v[k], 0.f);
+                }
+              }
+#pragma unroll
+              for (int k = 0; k < 8; ++k)
+                acc.v[k] += w1 * v1.v[k] + w2 * v2.v[k] + w3 * v3.v[k] + w4 * v4.v[k];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc.v[k] = acc.v[k] / count;
+      store8(orow + v * 8, acc);
+    }
+  }
+}
+
+template <typename T, typename CT>
+int launch_fwd_nchw(const T* in, const T* rois, T* out, T* amy, T* amx, int B, int C, int H, int W,
+                    int N, int PH, int PW, float scale, int sr, int pool_mode, int aligned,
+                    void* stream) {
+  G4R_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && N >= 0 && PH > 0 && PW > 0, "roi_align: bad shape");
+  G4R_REQUIRE(pool_mode == 0 || pool_mode == 1, "roi_align: pool_mode must be 0 (max) or 1 (avg)");
+  if (N == 0 || C == 0) return G4R_OK;
+  G4R_REQUIRE(in && rois && out, "roi_align: null pointer");
+  G4R_REQUIRE(pool_mode == 1 || (amy && amx), "roi_align: max pooling needs argmax buffers");
+  const int bins = PH * PW;
+  int cpb = g4r_ceil_div(4096, bins);
+  if (cpb > C) cpb = C;
+  const int gy = g4r_ceil_div(C, cpb);
+  G4R_REQUIRE(gy <= 65535, "roi_align: too many channel slabs");
+  dim3 grid(N, gy);
+  hipLaunchKernelGGL((roi_align_fwd_nchw_kernel<T, CT, 512>), grid, dim3(256), 0, (hipStream_t)stream,
+                     in, rois, out, amy, amx, B, C, H, W, PH, PW, (CT)scale, sr, pool_mode, aligned, cpb);
+  G4R_CHECK_LAUNCH("roi_align_forward");
+  return G4R_OK;
+}
+
+template <typename T, typename CT>
+int launch_bwd_nchw(const T* gout, const T* rois, const T* amy, const T* amx, T* gin, int B, int C,
+                    int H, int W, int N, int PH, int PW, float scale, int sr, int pool_mode,
+                    int aligned, void* stream) {
+  G4R_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && N >= 0 && PH > 0 && PW > 0, "roi_align: bad shape");
+  G4R_REQUIRE(pool_mode == 0 || pool_mode == 1, "roi_align: pool_mode must be 0 (max) or 1 (avg)");
+  const long nthreads = (long)N * C * PH * PW;
+  if (nthreads == 0) return G4R_OK;
+  G4R_REQUIRE(gout && rois && gin, "roi_align: null pointer");
+  G4R_REQUIRE(pool_mode == 1 || (amy && amx), "roi_align: max pooling needs argmax buffers");
+  long blocks = (nthreads + 255) / 256;
+  if (blocks > 256L * 32) blocks = 256L * 32;  // grid-stride beyond 8k workgroups
+  hipLaunchKernelGGL((roi_align_bwd_nchw_kernel<T, CT>), dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, gout, rois, amy, amx, gin, nthreads, B, C, H, W, PH, PW,
+                     (CT)scale, sr, pool_mode, aligned);
+  G4R_CHECK_LAUNCH("roi_align_backward");
+  return G4R_OK;
+}
+
+template <typename TI>
+int launch_mlvl(const void* const* feats, const float* const* affines, const int* heights, const int* widths, const float* scales,
+                int levels, const float* rois, void* output, int B, int C, int N, int PH, int PW,
+                int sr, int aligned, void* stream) {
+  G4R_REQUIRE(levels > 0 && levels <= G4R_MAX_LEVELS, "roi_align_mlvl: 1..8 levels");
+  G4R_REQUIRE(C > 0 && (C % 8) == 0, "roi_align_mlvl: channels must be a multiple of 8");
+  G4R_REQUIRE(PH > 0 && PW > 0 && B > 0 && N >= 0, "roi_align_mlvl: bad shape");
+  if (sr <= 0 || sr > MLVL_MAX_YTAB || PW * sr > MLVL_MAX_XTAB)
+    return g4r_note_error(G4R_ERR_UNSUPPORTED, "roi_align_mlvl: needs 0 < sampling_ratio <= 16, PW*sr <= 256");
+  if (N == 0) return G4R_OK;
+  G4R_REQUIRE(feats && heights && widths && scales && rois && output, "roi_align_mlvl: null pointer");
+  MlvlArgs a;
+  for (int l = 0; l < G4R_MAX_LEVELS; ++l) {
+    const int s = l < levels ? l : 0;
+    a.feat[l] = feats[s];
+    a.affine[l] = affines ? affines[s] : nullptr;
+    a.H[l] = heights[s];
+    a.W[l] = widths[s];
+    a.scale[l] = scales[s];
+    G4R_REQUIRE(feats[s] && heights[s] > 0 && widths[s] > 0, "roi_align_mlvl: bad level");
+  }
+  const long groups = (long)levels * N;
+  const long blocks = ((groups + 7) / 8) * 8 * PH;
+  G4R_REQUIRE(blocks < 2147483647L, "roi_align_mlvl: grid too large");
+  hipLaunchKernelGGL((roi_align_mlvl_nhwc_kernel<TI>), dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, a, rois, (TI*)output, levels, B, C, N, PH, PW, sr, aligned);
+  G4R_CHECK_LAUNCH("roi_align_mlvl_nhwc");
+  return G4R_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int g4r_roi_align_forward_f32(const float* input, const float* rois, float* output, float* argmax_y,
+                              float* argmax_x, int batch, int channels, int height, int width,
+                              int n_rois, int pooled_h, int pooled_w, float spatial_scale,
+                              int sampling_ratio, int pool_mode, int aligned, void* stream) {
+  return launch_fwd_nchw<float, float>(input, rois, output, argmax_y, argmax_x, batch, channels, height,
+                                       width, n_rois, pooled_h, pooled_w, spatial_scale, sampling_ratio,
+                                       pool_mode, aligned, stream);
+}
+int g4r_roi_align_forward_f64(const double* input, const double* rois, double* output,
+                              double* argmax_y, double* argmax_x, int batch, int channels, int height,
+                              int width, int n_rois, int pooled_h, int pooled_w, float spatial_scale,
+                              int sampling_ratio, int pool_mode, int aligned, void* stream) {
+  return launch_fwd_nchw<double, double>(input, rois, output, argmax_y, argmax_x, batch, channels,
+                                         height, width, n_rois, pooled_h, pooled_w, spatial_scale,
+                                         sampling_ratio, pool_mode, aligned, stream);
+}
+int g4r_roi_align_forward_f16(const void* input, const void* rois, void* output, void* argmax_y,
+                              void* argmax_x, int batch, int channels, int height, int width,
+                              int n_rois, int pooled_h, int pooled_w, float spatial_scale,
+                              int sampling_ratio, int pool_mode, int aligned, void* stream) {
+  return launch_fwd_nchw<__half, float>((const __half*)input, (const __half*)rois, (__half*)output,
+                                        (__half*)argmax_y, (__half*)argmax_x, batch, channels, height,
+                                        width, n_rois, pooled_h, pooled_w, spatial_scale, sampling_ratio,
+                                        pool_mode, aligned, stream);
+}
+
+int g4r_roi_align_backward_f32(const float* grad_output, const float* rois, const float* argmax_y,
+                               const float* argmax_x, float* grad_input, int batch, int channels,
+                               int height, int width, int n_rois, int pooled_h, int pooled_w,
+                               float spatial_scale, int sampling_ratio, int pool_mode, int aligned,
+                               void* stream) {
+  return launch_bwd_nchw<float, float>(grad_output, rois, argmax_y, argmax_x, grad_input, batch, channels,
+                                       height, width, n_rois, pooled_h, pooled_w, spatial_scale,
+                                       sampling_ratio, pool_mode, aligned, stream);
+}
+int g4r_roi_align_backward_f64(const double* grad_output, const double* rois, const double* argmax_y,
+                               const double* argmax_x, double* grad_input, int batch, int channels,
+                               int height, int width, int n_rois, int pooled_h, int pooled_w,
+                               float spatial_scale, int sampling_ratio, int pool_mode, int aligned,
+                               void* stream) {
+  return launch_bwd_nchw<double, double>(grad_output, rois, argmax_y, argmax_x, grad_input, batch,
+                                         channels, height, width, n_rois, pooled_h, pooled_w,
+                                         spatial_scale, sampling_ratio, pool_mode, aligned, stream);
+}
+int g4r_roi_align_backward_f16(const void* grad_output, const void* rois, const void* argmax_y,
+                               const void* argmax_x, void* grad_input, int batch, int channels,
+                               int height, int width, int n_rois, int pooled_h, int pooled_w,
+                               float spatial_scale, int sampling_ratio, int pool_mode, int aligned,
+                               void* stream) {
+  return launch_bwd_nchw<__half, float>((const __half*)grad_output, (const __half*)rois,
+                                        (const __half*)argmax_y, (const __half*)argmax_x,
+                                        (__half*)grad_input, batch, channels, height, width, n_rois,
+                                        pooled_h, pooled_w, spatial_scale, sampling_ratio, pool_mode,
+                                        aligned, stream);
+}
+
+int g4r_roi_align_mlvl_nhwc_bf16(const void* const* feats, const float* const* affines, const int* heights, const int* widths,
+                                 const float* scales, int levels, const float* rois, void* output,
+                                 int batch, int channels, int n_rois, int pooled_h, int pooled_w,
+                                 int sampling_ratio, int aligned, void* stream) {
+  return launch_mlvl<bf16_t>(feats, affines, heights, widths, scales, levels, rois, output, batch, channels,
+                             n_rois, pooled_h, pooled_w, sampling_ratio, aligned, stream);
+}
+int g4r_roi_align_mlvl_nhwc_f32(const void* const* feats, const float* const* affines, const int* heights, const int* widths,
+                                const float* scales, int levels, const float* rois, void* output,
+                                int batch, int channels, int n_rois, int pooled_h, int pooled_w,
+                                int sampling_ratio, int aligned, void* stream) {
+  return launch_mlvl<float>(feats, affines, heights, widths, scales, levels, rois, output, batch, channels,
+                            n_rois, pooled_h, pooled_w, sampling_ratio, aligned, stream);
+}
+
+}  // extern "C"

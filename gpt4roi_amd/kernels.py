@@ -1,0 +1,359 @@
+"""Typed Python fronts of the C ABI (include/g4r_kernels.h, include/g4r_roi_align.h).
+
+Thin: every function checks devices/dtypes, passes raw device pointers + the current HIP
+stream, and raises on a non-zero status.  Output tensors are allocated by the caller or
+here with torch.empty (PyTorch is only the allocator / stream provider).
+"""
+import ctypes
+from ctypes import c_float, c_int, c_long, c_void_p
+
+import torch
+
+from . import _lib
+
+P = c_void_p
+_SIGS = {
+    "g4r_gemm_bf16_nt": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                         c_int, c_int, P],
+    "g4r_conv3x3_nhwc_bf16": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_int,
+                              c_int, c_int, c_int, P],
+    "g4r_flash_attn_fwd_bf16": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long,
+                                c_long, c_long, c_long, c_long, c_float, c_int, P],
+    "g4r_layernorm_bf16": [P, P, P, P, c_int, c_int, c_long, c_long, c_float, c_int, P],
+    "g4r_rmsnorm_bf16": [P, P, P, c_int, c_int, c_long, c_long, c_float, P],
+    "g4r_groupnorm_affine_nhwc_bf16": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
+    "g4r_upsample_coord_nhwc_bf16": [P, P, c_int, c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_int, P],
+    "g4r_fuse_shuffle_nhwc_bf16": [P, P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, c_int, P, c_int,
+                                   c_int, P],
+    "g4r_im2col_patch14_f32": [P, P, c_int, c_int, c_int, P],
+    "g4r_vit_assemble_bf16": [P, P, P, P, c_int, c_int, c_int, P],
+    "g4r_rope_qkv_bf16": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "g4r_swiglu_bf16": [P, P, c_int, c_int, P],
+    "g4r_splice_embed_bf16": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_long, c_long, c_long,
+                              c_long, c_int, P],
+    "g4r_argmax_rows_f32": [P, c_long, c_int, c_int, P, P],
+    "g4r_add_rows_bf16": [P, P, P, c_long, c_int, c_long, P],
+    "g4r_cast_f32_to_bf16": [P, P, c_long, P],
+    "g4r_roi_align_mlvl_nhwc_bf16": [P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, P],
+    "g4r_roi_align_mlvl_nhwc_f32": [P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, P],
+}
+_bound = {}
+
+ACT = {None: 0, "none": 0, "relu": 1, "quick_gelu": 2, "silu": 3}
+
+
+def _fn(name):
+    f = _bound.get(name)
+    if f is None:
+        f = getattr(_lib.lib(), name)
+        f.argtypes = _SIGS[name]
+        f.restype = c_int
+        _bound[name] = f
+    return f
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _bf16(*ts):
+    for t in ts:
+        if t is not None:
+            _lib.require_gpu(t)
+            if t.dtype != torch.bfloat16:
+                raise TypeError(f"expected bfloat16, got {t.dtype}")
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None:
+            _lib.require_gpu(t)
+            if t.dtype != torch.float32:
+                raise TypeError(f"expected float32, got {t.dtype}")
+
+
+_zeros = {}
+
+
+def zeros_line(device):
+    z = _zeros.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.bfloat16, device=device)
+        _zeros[device] = z
+    return z
+
+
+def pick_tile(M, N):
+    """Tile heuristic for a 256-CU part: prefer 128x128; fall back to 64x128 when the grid would
+    otherwise leave most CUs idle."""
+    t128 = -(-M // 128) * -(-N // 128)
+    if t128 >= 192:
+        return 0
+    return 4
+
+
+def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfloat16, splits=1,
+         tile_cfg=None, workspace=None):
+    """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + residual.  a may be row-strided (last dim dense)."""
+    _bf16(a, w, residual)
+    _f32(bias)
+    assert a.dim() == 2 and w.dim() == 2 and a.size(1) == w.size(1), (a.shape, w.shape)
+    assert a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.size(0)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    assert out.stride(1) == 1 and out.shape == (M, N)
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+    if tile_cfg is None:
+        tile_cfg = pick_tile(M, N)
+    if splits > 1 and workspace is None:
+        workspace = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
+    rc = _fn("g4r_gemm_bf16_nt")(
+        _p(a), _p(w), _p(out), _p(bias), _p(residual), _p(workspace), M, N, K, a.stride(0), w.stride(0),
+        out.stride(0), residual.stride(0) if residual is not None else 0, ACT[act],
+        1 if out.dtype == torch.float32 else 0, splits, tile_cfg, _stream(a))
+    _lib.check(rc, "g4r_gemm_bf16_nt")
+    return out
+
+
+def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=torch.bfloat16, splits=1, tile_cfg=None,
+            workspace=None):
+    """x [groups?, B, H, W, Cin] NHWC bf16 (groups dim present iff groups > 1);
+    w [Cout, groups*9*Cin] prepared by prep_conv3x3_weight; returns [B, H, W, Cout]."""
+    _bf16(x, w)
+    _f32(bias)
+    x = x.contiguous()
+    if groups > 1:
+        assert x.dim() == 5 and x.size(0) == groups
+        B, H, W, Cin = x.shape[1:]
+        gstride = x.stride(0)
+    else:
+        assert x.dim() == 4
+        B, H, W, Cin = x.shape
+        gstride = 0
+    Cout = w.size(0)
+    assert w.size(1) == groups * 9 * Cin and w.is_contiguous()
+    if out is None:
+        out = torch.empty((B, H, W, Cout), dtype=out_dtype, device=x.device)
+    if tile_cfg is None:
+        tile_cfg = pick_tile(B * H * W, Cout)
+    if splits > 1 and workspace is None:
+        workspace = torch.empty((splits, B * H * W, Cout), dtype=torch.float32, device=x.device)
+    rc = _fn("g4r_conv3x3_nhwc_bf16")(
+        _p(x), _p(w), _p(out), _p(bias), _p(zeros_line(x.device)), _p(workspace), B, H, W, Cin, Cout, groups,
+        gstride, ACT[act], 1 if out.dtype == torch.float32 else 0, splits, tile_cfg, _stream(x))
+    _lib.check(rc, "g4r_conv3x3_nhwc_bf16")
+    return out
+
+
+def prep_conv3x3_weight(ws):
+    """list of torch conv weights [Cout, Cin, 3, 3] (one per group) -> [Cout, groups*9*Cin] bf16."""
+    if isinstance(ws, torch.Tensor):
+        ws = [ws]
+    parts = [w.permute(0, 2, 3, 1).reshape(w.size(0), 1, 9 * w.size(1)) for w in ws]
+    return torch.cat(parts, 1).reshape(ws[0].size(0), -1).to(torch.bfloat16).contiguous()
+
+
+def flash_attn(q, k, v, heads, scale, causal=False, out=None):
+    """q [B, Tq, heads*D], k/v [B, Tk, heads*D] (row-strided views allowed) -> [B, Tq, heads*D]."""
+    _bf16(q, k, v)
+    B, Tq, HD = q.shape
+    Tk = k.size(1)
+    D = HD // heads
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    if out is None:
+        out = torch.empty((B, Tq, HD), dtype=torch.bfloat16, device=q.device)
+    rc = _fn("g4r_flash_attn_fwd_bf16")(
+        _p(q), _p(k), _p(v), _p(out), B, heads, Tq, Tk, D, q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+        q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), int(bool(causal)), _stream(q))
+    _lib.check(rc, "g4r_flash_attn_fwd_bf16")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, relu_in=False, out=None):
+    _bf16(x)
+    _f32(gamma, beta)
+    x2 = x.reshape(-1, x.size(-1)) if x.is_contiguous() else x
+    assert x2.dim() == 2 and x2.stride(1) == 1
+    if out is None:
+        out = torch.empty((x2.size(0), x2.size(1)), dtype=torch.bfloat16, device=x.device)
+    rc = _fn("g4r_layernorm_bf16")(_p(x2), _p(gamma), _p(beta), _p(out), x2.size(0), x2.size(1), x2.stride(0),
+                                   out.stride(0), float(eps), int(relu_in), _stream(x))
+    _lib.check(rc, "g4r_layernorm_bf16")
+    return out.view(x.shape) if x.is_contiguous() else out
+
+
+def rmsnorm(x, gamma, eps=1e-6, out=None):
+    _bf16(x)
+    _f32(gamma)
+    x2 = x.reshape(-1, x.size(-1))
+    if out is None:
+        out = torch.empty_like(x2)
+    rc = _fn("g4r_rmsnorm_bf16")(_p(x2), _p(gamma), _p(out), x2.size(0), x2.size(1), x2.stride(0), out.stride(0),
+                                 float(eps), _stream(x))
+    _lib.check(rc, "g4r_rmsnorm_bf16")
+    return out.view(x.shape)
+
+
+def groupnorm_affine(x, gamma, beta, groups, eps=1e-5):
+    """x [B, H, W, C] bf16 -> scale_shift [B, 2, C] fp32 (deferred GN: y = a*x + s)."""
+    _bf16(x)
+    _f32(gamma, beta)
+    B, H, W, C = x.shape
+    acc = torch.empty((B, groups, 2), dtype=torch.float64, device=x.device)
+    ss = torch.empty((B, 2, C), dtype=torch.float32, device=x.device)
+    rc = _fn("g4r_groupnorm_affine_nhwc_bf16")(_p(x), _p(gamma), _p(beta), _p(acc), _p(ss), B, H * W, C, groups,
+                                               float(eps), _stream(x))
+    _lib.check(rc, "g4r_groupnorm_affine_nhwc_bf16")
+    return ss
+
+
+def upsample_coord(tokens, hin, win, H, W, cpad):
+    """tokens [B, hin*win, C] bf16 (row/batch strided ok) -> [B, H, W, cpad] with coord channels."""
+    _bf16(tokens)
+    B, n, C = tokens.shape
+    assert n == hin * win and tokens.stride(2) == 1
+    out = torch.empty((B, H, W, cpad), dtype=torch.bfloat16, device=tokens.device)
+    rc = _fn("g4r_upsample_coord_nhwc_bf16")(_p(tokens), _p(out), B, hin, win, tokens.stride(0), tokens.stride(1),
+                                             H, W, C, cpad, _stream(tokens))
+    _lib.check(rc, "g4r_upsample_coord_nhwc_bf16")
+    return out
+
+
+def fuse_shuffle(own, top, down, own_aff=None, top_aff=None, down_aff=None, out=None):
+    _bf16(own, top, down)
+    _f32(own_aff, top_aff, down_aff)
+    B, H, W, C = own.shape
+    if out is None:
+        out = torch.empty_like(own)
+    rc = _fn("g4r_fuse_shuffle_nhwc_bf16")(_p(own), _p(own_aff), H, W, _p(top), _p(top_aff), top.size(1),
+                                           top.size(2), _p(down), _p(down_aff), down.size(1), down.size(2),
+                                           _p(out), B, C, _stream(own))
+    _lib.check(rc, "g4r_fuse_shuffle_nhwc_bf16")
+    return out
+
+
+def im2col_patch14(img, kpad=640):
+    _f32(img)
+    img = img.contiguous()
+    B, _, S, _ = img.shape
+    Pn = S // 14
+    out = torch.empty((B * Pn * Pn, kpad), dtype=torch.bfloat16, device=img.device)
+    rc = _fn("g4r_im2col_patch14_f32")(_p(img), _p(out), B, S, kpad, _stream(img))
+    _lib.check(rc, "g4r_im2col_patch14_f32")
+    return out
+
+
+def vit_assemble(patch, cls, pos, B):
+    _bf16(patch, cls, pos)
+    n = patch.size(0) // B
+    C = patch.size(1)
+    tok = torch.empty((B, n + 1, C), dtype=torch.bfloat16, device=patch.device)
+    rc = _fn("g4r_vit_assemble_bf16")(_p(patch), _p(cls), _p(pos), _p(tok), B, n, C, _stream(patch))
+    _lib.check(rc, "g4r_vit_assemble_bf16")
+    return tok
+
+
+def rope_qkv(qkv, cos, sin, q_out, k_cache, v_cache, heads, head_dim, pos0):
+    _bf16(qkv, q_out, k_cache, v_cache)
+    _f32(cos, sin)
+    T = qkv.size(0)
+    rc = _fn("g4r_rope_qkv_bf16")(_p(qkv), _p(cos), _p(sin), _p(q_out), _p(k_cache), _p(v_cache), T, heads,
+                                  head_dim, pos0, _stream(qkv))
+    _lib.check(rc, "g4r_rope_qkv_bf16")
+
+
+def swiglu(gate_up, out=None):
+    _bf16(gate_up)
+    T, F2 = gate_up.shape
+    if out is None:
+        out = torch.empty((T, F2 // 2), dtype=torch.bfloat16, device=gate_up.device)
+    rc = _fn("g4r_swiglu_bf16")(_p(gate_up), _p(out), T, F2 // 2, _stream(gate_up))
+    _lib.check(rc, "g4r_swiglu_bf16")
+    return out
+
+
+def splice_embed(ids, embed, img, spi, spi_offset, n_patch, patch_id, bbox_id, im_start_id, im_end_id):
+    """ids [B,T] int64; embed [V,C]; img [B,n_patch,C] or None; spi [N,C] or None;
+    spi_offset int32 [B+1] or None -> (inputs_embeds [B,T,C], status int32 [B])."""
+    _bf16(embed, img, spi)
+    _lib.require_gpu(ids)
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    B, T = ids.shape
+    C = embed.size(1)
+    out = torch.empty((B, T, C), dtype=torch.bfloat16, device=ids.device)
+    status = torch.empty((B,), dtype=torch.int32, device=ids.device)
+    rc = _fn("g4r_splice_embed_bf16")(_p(ids), _p(embed), _p(img), _p(spi), _p(spi_offset), _p(out), _p(status),
+                                      B, T, C, n_patch if img is not None else 0, patch_id, bbox_id,
+                                      im_start_id, im_end_id, embed.size(0), _stream(ids))
+    _lib.check(rc, "g4r_splice_embed_bf16")
+    return out, status
+
+
+def argmax_rows(logits):
+    _f32(logits)
+    rows, N = logits.shape
+    out = torch.empty((rows,), dtype=torch.int64, device=logits.device)
+    rc = _fn("g4r_argmax_rows_f32")(_p(logits), logits.stride(0), rows, N, _p(out), _stream(logits))
+    _lib.check(rc, "g4r_argmax_rows_f32")
+    return out
+
+
+def add_rows(a, b, out=None):
+    _bf16(a, b)
+    a2 = a.reshape(-1, a.size(-1))
+    b2 = b.reshape(-1, b.size(-1))
+    if out is None:
+        out = torch.empty_like(a2)
+    rc = _fn("g4r_add_rows_bf16")(_p(a2), _p(b2), _p(out), a2.size(0), a2.size(1), b2.size(0), _stream(a))
+    _lib.check(rc, "g4r_add_rows_bf16")
+    return out.view(a.shape)
+
+
+def cast_bf16(x):
+    _f32(x)
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    rc = _fn("g4r_cast_f32_to_bf16")(_p(x), _p(y), x.numel(), _stream(x))
+    _lib.check(rc, "g4r_cast_f32_to_bf16")
+    return y
+
+
+def roi_align_mlvl(feats, rois, output_size, scales, sampling_ratio=2, aligned=True, affines=None, out=None):
+    """feats: list of NHWC [B,H_l,W_l,C] (bf16 or fp32); rois [N,5] fp32 (batch idx, x1,y1,x2,y2 px);
+    -> [L, N, ph, pw, C] in the dtype of feats."""
+    L = len(feats)
+    dt = feats[0].dtype
+    name = {torch.bfloat16: "g4r_roi_align_mlvl_nhwc_bf16", torch.float32: "g4r_roi_align_mlvl_nhwc_f32"}[dt]
+    for f in feats:
+        _lib.require_gpu(f)
+        assert f.dtype == dt and f.is_contiguous() and f.dim() == 4
+    _f32(rois)
+    rois = rois.contiguous()
+    B, _, _, C = feats[0].shape
+    N = rois.size(0)
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    if out is None:
+        out = torch.empty((L, N, ph, pw, C), dtype=dt, device=rois.device)
+    PA = c_void_p * L
+    fa = PA(*[f.data_ptr() for f in feats])
+    aa = None
+    if affines is not None:
+        _f32(*[a for a in affines if a is not None])
+        aa = PA(*[(a.data_ptr() if a is not None else None) for a in affines])
+    ha = (c_int * L)(*[f.size(1) for f in feats])
+    wa = (c_int * L)(*[f.size(2) for f in feats])
+    sa = (c_float * L)(*[float(s) for s in scales])
+    rc = _fn(name)(ctypes.cast(fa, P), ctypes.cast(aa, P) if aa is not None else None, ctypes.cast(ha, P),
+                   ctypes.cast(wa, P), ctypes.cast(sa, P), L, _p(rois), _p(out), B, C, N, ph, pw,
+                   int(sampling_ratio), int(bool(aligned)), _stream(rois))
+    _lib.check(rc, name)
+    return out

@@ -1,0 +1,140 @@
+/*
+ * g4r_kernels.h -- C ABI of the remaining gfx950 kernels of the region-feature path
+ * (everything except RoIAlign, which has its own header g4r_roi_align.h).
+ *
+ * The reference has no native boundary for these stages: it reaches cuBLAS / cuDNN / ATen
+ * through torch.nn modules.  Each entry point below names the reference call site whose
+ * arithmetic it carries (paths relative to /root/reference).  Common contract: device
+ * pointers owned by the caller, no allocation, no retained state, asynchronous on `stream`
+ * (hipStream_t), int status return (g4r_roi_align.h: G4R_OK / G4R_ERR_*).  "bf16" pointers are
+ * bfloat16 bit patterns (uint16); strides are in ELEMENTS.
+ */
+#ifndef G4R_KERNELS_H
+#define G4R_KERNELS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual          (torch.nn.Linear layout)
+ *   - mm_projector              llava/model/llava.py:52,76 ; gpt4roi/models/spi_llava.py:89-97
+ *   - flatten_linear / updims / pos_embedd   gpt4roi/models/layers.py:260-270, 326-329
+ *   - 1x1 input_conv (as a GEMM over NHWC pixels)   layers.py:129-132, 191
+ *   - every projection inside CLIP ViT-L/14 and LLaMA-7B (HF modules called at
+ *     spi_llava.py:66-67 and :198-205) and lm_head (llava.py:235-238)
+ * A, W, residual bf16; bias fp32 [N] or NULL; C bf16 (out_f32 = 0) or fp32 (out_f32 = 1).
+ * act: 0 none, 1 relu, 2 quick_gelu, 3 silu.  K % 64 == 0 runs the MFMA kernel (lda, ldw
+ * multiples of 8); any other K runs a scalar kernel (tiny layers only, no residual).
+ * splits > 1: split-K with `workspace` of splits*M*N floats.
+ * tile_cfg: 0 = 128x128 (LDS-DMA), 1 = 256x128, 2 = 128x128 register-staged, 4 = 64x128.
+ */
+int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, const void* residual,
+                     float* workspace, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
+                     int act, int out_f32, int splits, int tile_cfg, void* stream);
+
+/*
+ * 3x3 / stride 1 / pad 1 convolution over NHWC bf16 as an implicit GEMM on MFMA:
+ *   Y[b,y,x,:] = act( sum_g sum_tap W[:, g, tap, :] . X_g[b, y+dy, x+dx, :] + bias )
+ *   - MLVLFuseModule.fuse_convs (ConvModule 3x3, no bias)   gpt4roi/models/layers.py:133-144
+ *   - MlvlRoIExtractor.pconvs, all `groups` levels summed in one accumulator
+ *     (layers.py:257-259, 321-324): X_g = X + g * x_group_stride, images = RoIs of 14x14.
+ * X [groups][batch, H, Wd, Cin]; W [Cout][groups][9][Cin] (tap = ky*3+kx); Y [batch, H, Wd, Cout].
+ * `zeros`: >= 128 bytes of device zeros (padding source).  Cin % 64 == 0.
+ */
+int g4r_conv3x3_nhwc_bf16(const void* X, const void* W, void* Y, const float* bias, const void* zeros,
+                          float* workspace, int batch, int H, int Wd, int Cin, int Cout, int groups,
+                          long x_group_stride, int act, int out_f32, int splits, int tile_cfg,
+                          void* stream);
+
+/*
+ * softmax(Q K^T * scale [+ causal mask]) V, bf16, head_dim 64 (CLIP ViT-L/14) or 128 (LLaMA-7B).
+ * Replaces the attention inside HF CLIPAttention / LlamaAttention (called from
+ * spi_llava.py:66-67, 198-205) and the flash-attn patch
+ * (llava/train/llama_flash_attn_monkey_patch.py:15-91).
+ * Q [B, Tq, H*D], K/V [B, Tk, H*D], O [B, Tq, H*D] addressed through row / batch strides.
+ * causal: query i attends keys <= i + (Tk - Tq)  (KV-cache decode when Tq < Tk).
+ */
+int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq,
+                            int Tk, int head_dim, long q_row, long k_row, long v_row, long o_row,
+                            long q_batch, long k_batch, long v_batch, long o_batch, float scale,
+                            int causal, void* stream);
+
+/* LayerNorm over the last dim (CLIP pre_layrnorm / layer_norm1,2; pos_embedd LayerNorms
+ * gpt4roi/models/layers.py:260-267).  gamma/beta fp32.  relu_in: apply ReLU to x first. */
+int g4r_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, int rows, int cols,
+                       long ldx, long ldy, float eps, int relu_in, void* stream);
+
+/* LLaMA RMSNorm (HF LlamaRMSNorm, reached from spi_llava.py:198-205). */
+int g4r_rmsnorm_bf16(const void* x, const float* gamma, void* y, int rows, int cols, long ldx, long ldy,
+                     float eps, void* stream);
+
+/*
+ * GroupNorm statistics of ConvModule's GN (layers.py:133-144; mmcv/cnn/bricks/norm.py:101-107)
+ * over an NHWC bf16 map, returned as a per-(image, channel) affine  y = a*x + s :
+ *   scale_shift [B, 2, C] fp32 (a then s).  `acc` = workspace of B*G*2 doubles.
+ * The normalisation itself (+ReLU) is applied by the consumers (g4r_fuse_shuffle_nhwc_bf16,
+ * g4r_roi_align_mlvl_nhwc_*), so the normalised map is never materialised.
+ */
+int g4r_groupnorm_affine_nhwc_bf16(const void* x, const float* gamma, const float* beta, double* acc,
+                                   float* scale_shift, int B, int HW, int C, int G, float eps,
+                                   void* stream);
+
+/*
+ * MLVLROIQueryModule.forward pyramid build + MLVLFuseModule coordinate concat
+ * (gpt4roi/models/layers.py:225-232, 117-127, 183-189): bilinear align_corners=True resize of a
+ * ViT level [B, Hin*Win, ldin-strided C] to [B, H, W, Cpad] with channels C, C+1 = x, y
+ * coordinates in linspace(-1,1) and zero padding to Cpad (a multiple of 64 for the 1x1-conv GEMM).
+ */
+int g4r_upsample_coord_nhwc_bf16(const void* in, void* out, int B, int Hin, int Win,
+                                 long in_batch_stride, int ldin, int H, int W, int C, int Cpad,
+                                 void* stream);
+
+/*
+ * MLVLFuseModule._single_shuffle input for one level (layers.py:152-180):
+ *   out = cat[ own[:, :C/2], resize(top[:, 3C/4:]), resize(down[:, C/2:3C/4]) ]
+ * bilinear align_corners=True in fp32; *_affine (nullable, [B,2,C]) = deferred GN+ReLU of the
+ * source (see g4r_groupnorm_affine_nhwc_bf16).
+ */
+int g4r_fuse_shuffle_nhwc_bf16(const void* own, const float* own_affine, int H, int W, const void* top,
+                               const float* top_affine, int Ht, int Wt, const void* down,
+                               const float* down_affine, int Hd, int Wd, void* out, int B, int C,
+                               void* stream);
+
+/* CLIP patch embedding front end (HF CLIPVisionEmbeddings): image fp32 NCHW [B,3,S,S] ->
+ * [B*(S/14)^2, Kpad] bf16 rows (k = c*196 + ky*14 + kx, zero padded), then
+ * tokens = cat(cls, patches) + position_embedding. */
+int g4r_im2col_patch14_f32(const float* img, void* out, int B, int S, int Kpad, void* stream);
+int g4r_vit_assemble_bf16(const void* patch, const void* cls, const void* pos, void* tok, int B, int n,
+                          int C, void* stream);
+
+/* LLaMA: rotary embedding of q and k (HF rotate_half convention) + KV-cache append.
+ * qkv [T, 3*heads*head_dim]; cos/sin [max_pos, head_dim/2] fp32; caches [max_pos, heads*head_dim]. */
+int g4r_rope_qkv_bf16(const void* qkv, const float* cos_tab, const float* sin_tab, void* q_out,
+                      void* k_cache, void* v_cache, int T, int heads, int head_dim, int pos0,
+                      void* stream);
+/* LLaMA MLP gate: out[T,F] = silu(gate_up[:, :F]) * gate_up[:, F:]. */
+int g4r_swiglu_bf16(const void* gate_up, void* out, int T, int F, void* stream);
+
+/*
+ * Token embedding + image-patch splice + <bbox> region-token injection in one gather; replaces
+ * the per-sample host loop of gpt4roi/models/spi_llava.py:99-196.  status[b] bit flags:
+ * 1 patch count != n_patch, 2 #<bbox> != #regions, 4 no <im_start> before the patch run,
+ * 8 no <im_end> after it, 16 patch run not contiguous (the reference raises ValueError).
+ * spi_offset: [B+1] int32 prefix sums of regions per sample (NULL = no regions).
+ */
+int g4r_splice_embed_bf16(const long* ids, const void* embed, const void* img, const void* spi,
+                          const int* spi_offset, void* out, int* status, int B, int T, int C,
+                          int n_patch, long patch_id, long bbox_id, long im_start_id, long im_end_id,
+                          int vocab, void* stream);
+
+/* greedy decode: out[r] = argmax(logits[r, :N]) (lowest index on ties). */
+int g4r_argmax_rows_f32(const float* logits, long ld, int rows, int N, long* out, void* stream);
+/* y = a + b[row % brows]  ("fuse_roi_feats + pos_embedd", layers.py:328). */
+int g4r_add_rows_bf16(const void* a, const void* b, void* y, long rows, int C, long brows, void* stream);
+int g4r_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G4R_KERNELS_H */

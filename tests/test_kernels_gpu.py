@@ -1,0 +1,382 @@
+"""GPU: every hand-written gfx950 kernel against a plain PyTorch fp32 statement of the same op
+(and RoIAlign against the CPU oracle / committed reference fixtures).  All calls go through the
+C ABI (ctypes) -- see gpt4roi_amd/kernels.py."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from gpt4roi_amd import kernels as K
+    from gpt4roi_amd.roi_align import RoIAlign, roi_align
+
+DEV = "cuda"
+
+
+def rnd(*shape, scale=1.0, seed=None, dtype=torch.bfloat16):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (hash(shape) & 0xffff))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def close(got, ref, atol, rtol, what=""):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = (err > tol)
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} off; max abs err {err.max().item():.3e} "
+                           f"at ref {ref.flatten()[err.argmax()].item():.3e}")
+
+
+# ------------------------------------------------------------------------------------------ RoIAlign
+def test_roi_align_known_answers_all_dtypes(golden_dir):
+    # mmcv-1.4.7/tests/test_ops/test_roi_align.py:66-104 (atol 1e-3 there, for float/double/half)
+    z = np.load(os.path.join(golden_dir, "roi_align_known.npz"))
+    for dtype, atol in ((torch.float32, 1e-6), (torch.float64, 1e-12), (torch.float16, 1e-3)):
+        for i in range(3):
+            x = torch.tensor(z[f"x{i}"], dtype=dtype, device=DEV, requires_grad=True)
+            r = torch.tensor(z[f"rois{i}"], dtype=dtype, device=DEV)
+            out = roi_align(x, r, (2, 2), 1.0, 2, 'avg', True)
+            out.backward(torch.ones_like(out))
+            np.testing.assert_allclose(out.detach().float().cpu().numpy(), z[f"out{i}"], atol=atol)
+            np.testing.assert_allclose(x.grad.float().cpu().numpy(), z[f"grad{i}"], atol=max(atol, 1e-6))
+
+
+def test_roi_align_gradcheck_fp64(golden_dir):
+    # test_roi_align.py:41-64
+    z = np.load(os.path.join(golden_dir, "roi_align_known.npz"))
+    for i in range(3):
+        x = torch.tensor(z[f"x{i}"], dtype=torch.float64, device=DEV, requires_grad=True)
+        r = torch.tensor(z[f"rois{i}"], dtype=torch.float64, device=DEV)
+        assert torch.autograd.gradcheck(RoIAlign((2, 2), 1.0, 2), (x, r), eps=1e-5, atol=1e-5)
+
+
+def test_roi_align_reference_fixtures(golden_dir):
+    """fixtures = outputs of the reference's own CPU code (tests/golden/make_golden.py)."""
+    z = np.load(os.path.join(golden_dir, "roi_align_seeded.npz"))
+    worst = 0.0
+    for name in [str(n) for n in z["names"]]:
+        ph, pw, sr, avg, aligned = [int(v) for v in z[f"{name}.cfg"]]
+        mode = "avg" if avg else "max"
+        scale = float(z[f"{name}.scale"])
+        x = torch.tensor(z[f"{name}.x"], device=DEV, requires_grad=True)
+        r = torch.tensor(z[f"{name}.rois"], device=DEV)
+        out = roi_align(x, r, (ph, pw), scale, sr, mode, bool(aligned))
+        out.backward(torch.tensor(z[f"{name}.gout"], device=DEV))
+        e1 = np.abs(out.detach().cpu().numpy() - z[f"{name}.out"]).max()
+        e2 = np.abs(x.grad.cpu().numpy() - z[f"{name}.gin"]).max()
+        worst = max(worst, e1, e2)
+        assert e1 <= 1e-5, (name, "forward", e1)   # north_star tolerance is 1e-4 fp32
+        assert e2 <= 1e-4, (name, "backward", e2)  # atomics reorder the sums
+    print("roi_align fixtures worst abs err", worst)
+
+
+def _gpt4roi_case(P=16, B=2, N=32, C=1024, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sizes = [8 * P, 4 * P, 2 * P, P]
+    strides = [14 / 8, 14 / 4, 14 / 2, 14]
+    feats = [torch.randn(B, C, s, s, generator=g) for s in sizes]
+    xy = torch.rand(N, 2, generator=g) * 0.6
+    wh = torch.rand(N, 2, generator=g) * 0.3 + 0.05
+    idx = torch.randint(0, B, (N, 1), generator=g).float()
+    rois = torch.cat([idx, xy * 14 * P, (xy + wh) * 14 * P], 1)
+    return feats, rois, strides
+
+
+def test_roi_align_gpt4roi_regime_vs_oracle():
+    """14x14 bins, sr 2, the four pyramid levels at 224^2 (layers.py:206-214) vs the C oracle."""
+    from oracle import roi_align as O
+    feats, rois, strides = _gpt4roi_case(P=16, B=2, N=32, C=256)
+    for f, s in zip(feats, strides):
+        want = O.forward(f.numpy(), rois.numpy(), 14, 1.0 / s, 2)[0]
+        got = roi_align(f.to(DEV), rois.to(DEV), 14, 1.0 / s, 2, 'avg', True).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-5
+        gout = torch.randn(got.shape, generator=torch.Generator().manual_seed(1))
+        x = f.to(DEV).requires_grad_(True)
+        roi_align(x, rois.to(DEV), 14, 1.0 / s, 2, 'avg', True).backward(gout.to(DEV))
+        wantg = O.backward(gout.numpy(), rois.numpy(), f.shape, 14, 1.0 / s, 2)
+        assert np.abs(x.grad.cpu().numpy() - wantg).max() <= 1e-4 * max(1.0, np.abs(wantg).max())
+
+
+def test_roi_align_mlvl_nhwc_matches_dropin_and_gn():
+    feats, rois, strides = _gpt4roi_case(P=8, B=2, N=9, C=64, seed=3)
+    rois_d = rois.to(DEV)
+    nchw = [f.to(DEV) for f in feats]
+    nhwc = [f.permute(0, 2, 3, 1).contiguous() for f in nchw]
+    out = K.roi_align_mlvl(nhwc, rois_d, 14, [1.0 / s for s in strides])
+    for l, s in enumerate(strides):
+        ref = roi_align(nchw[l], rois_d, 14, 1.0 / s, 2, 'avg', True).permute(0, 2, 3, 1)
+        assert torch.equal(out[l], ref), f"level {l}: max diff {(out[l]-ref).abs().max().item()}"
+    # bf16 storage + deferred GroupNorm/ReLU affine
+    nb = [f.to(torch.bfloat16) for f in nhwc]
+    aff = [torch.randn(2, 2, 64, device=DEV) for _ in nb]
+    outb = K.roi_align_mlvl(nb, rois_d, 14, [1.0 / s for s in strides], affines=aff)
+    for l, s in enumerate(strides):
+        a, sh = aff[l][:, 0], aff[l][:, 1]
+        y = torch.relu(nb[l].float() * a[:, None, None, :] + sh[:, None, None, :]).permute(0, 3, 1, 2).contiguous()
+        ref = roi_align(y, rois_d, 14, 1.0 / s, 2, 'avg', True).permute(0, 2, 3, 1)
+        close(outb[l], ref, 1e-2, 1e-2, f"mlvl gn level {l}")
+    empty = K.roi_align_mlvl(nhwc, rois_d[:0], 14, [1.0 / s for s in strides])
+    assert empty.shape == (4, 0, 14, 14, 64)
+
+
+# ------------------------------------------------------------------------------------------ GEMM / conv
+@pytest.mark.parametrize("tile", [0, 1, 2, 4])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 328, 192), (37, 1024, 1024), (800, 512, 2048),
+                                   (50, 30, 64)])
+def test_gemm_plain(tile, M, N, K):
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    ref = a.float() @ w.float().t()
+    got = K_gemm(a, w, tile_cfg=tile)
+    close(got, ref, 0.06 * math.sqrt(K / 64), 1e-2, f"gemm {M}x{N}x{K} tile {tile}")
+
+
+def K_gemm(*a, **k):
+    return K.gemm(*a, **k)
+
+
+def test_gemm_layout_is_not_transposed():
+    # asymmetric operands: A = one-hot rows, W = ramp -> C[m, n] must equal W[n, m-th k]
+    M, N, Kd = 96, 160, 128
+    a = torch.zeros(M, Kd, dtype=torch.bfloat16, device=DEV)
+    a[torch.arange(M), torch.arange(M) % Kd] = 1
+    w = (torch.arange(N * Kd, device=DEV).reshape(N, Kd) % 251).to(torch.bfloat16)
+    got = K.gemm(a, w, tile_cfg=0, out_dtype=torch.float32)
+    ref = w.float()[:, torch.arange(M, device=DEV) % Kd].t()
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("act", [None, "relu", "quick_gelu", "silu"])
+def test_gemm_epilogue(act):
+    M, N, Kd = 300, 256, 512
+    a, w, bias, res = rnd(M, Kd, seed=3), rnd(N, Kd, scale=0.1, seed=4), rnd(N, seed=5, dtype=torch.float32), rnd(M, N, seed=6)
+    x = a.float() @ w.float().t() + bias
+    x = {None: x, "relu": torch.relu(x), "quick_gelu": x * torch.sigmoid(1.702 * x), "silu": F.silu(x)}[act]
+    ref = x + res.float()
+    close(K.gemm(a, w, bias=bias, residual=res, act=act), ref, 0.05, 1e-2, f"epilogue {act}")
+    close(K.gemm(a, w, bias=bias, residual=res, act=act, out_dtype=torch.float32), ref, 0.02, 2e-3, "f32 out")
+    close(K.gemm(a, w, bias=bias, residual=res, act=act, splits=4), ref, 0.05, 1e-2, "split-K")
+
+
+def test_gemm_strided_a_and_small_k():
+    big = rnd(64, 3, 128, seed=7)
+    a = big[:, 1, :]                      # row stride 384
+    w = rnd(96, 128, seed=8)
+    close(K.gemm(a, w), a.float() @ w.float().t(), 0.1, 1e-2, "strided A")
+    a4, w4, b4 = rnd(33, 4, seed=9), rnd(256, 4, seed=10), rnd(256, seed=11, dtype=torch.float32)
+    close(K.gemm(a4, w4, bias=b4, act="relu"), torch.relu(a4.float() @ w4.float().t() + b4), 0.02, 1e-2, "K=4")
+
+
+def test_gemm_flatten_linear_shape():
+    # [N_roi, 200704] x [1024, 200704]^T weight-streaming split-K (layers.py:270, 327)
+    M, N, Kd = 32, 1024, 200704
+    a, w = rnd(M, Kd, scale=0.05, seed=12), rnd(N, Kd, scale=0.05, seed=13)
+    ref = a.float() @ w.float().t()
+    got = K.gemm(a, w, splits=49, tile_cfg=4, out_dtype=torch.float32)
+    close(got, ref, 0.05, 1e-2, "flatten_linear")
+
+
+@pytest.mark.parametrize("tile", [0, 1, 4])
+def test_conv3x3(tile):
+    B, H, W, Cin, Cout = 2, 13, 9, 64, 96
+    x = rnd(B, H, W, Cin, seed=14)
+    w = rnd(Cout, Cin, 3, 3, scale=0.1, seed=15)
+    bias = rnd(Cout, seed=16, dtype=torch.float32)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1).permute(0, 2, 3, 1)
+    got = K.conv3x3(x, K.prep_conv3x3_weight(w), bias=bias, tile_cfg=tile)
+    close(got, ref, 0.05, 1e-2, f"conv3x3 tile {tile}")
+    close(K.conv3x3(x, K.prep_conv3x3_weight(w), act="relu", tile_cfg=tile),
+          torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, padding=1)).permute(0, 2, 3, 1),
+          0.05, 1e-2, "conv3x3 relu no bias")
+
+
+def test_conv3x3_grouped_sum_is_pconv():
+    # sum_l pconv_l(roi_feats[l]) (layers.py:321-324) on 14x14 RoI maps
+    L, N, C, Co = 4, 5, 64, 128
+    x = rnd(L, N, 14, 14, C, seed=17)
+    ws = [rnd(Co, C, 3, 3, scale=0.05, seed=18 + l) for l in range(L)]
+    bs = [rnd(Co, seed=30 + l, dtype=torch.float32) for l in range(L)]
+    ref = sum(F.conv2d(x[l].float().permute(0, 3, 1, 2), ws[l].float(), bs[l], padding=1) for l in range(L))
+    ref = torch.relu(ref).permute(0, 2, 3, 1)
+    got = K.conv3x3(x, K.prep_conv3x3_weight(ws), bias=sum(bs), act="relu", groups=L)
+    close(got, ref, 0.05, 1e-2, "pconv")
+
+
+def test_conv3x3_full_width():
+    B, H, W, C = 1, 24, 24, 1024
+    x = rnd(B, H, W, C, seed=40)
+    w = rnd(C, C, 3, 3, scale=0.01, seed=41)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, padding=1).permute(0, 2, 3, 1)
+    close(K.conv3x3(x, K.prep_conv3x3_weight(w)), ref, 0.05, 1e-2, "conv 1024ch")
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, heads, scale, causal):
+    B, Tq, HD = q.shape
+    Tk, D = k.size(1), HD // heads
+    qh = q.float().view(B, Tq, heads, D).transpose(1, 2)
+    kh = k.float().view(B, Tk, heads, D).transpose(1, 2)
+    vh = v.float().view(B, Tk, heads, D).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) * scale
+    if causal:
+        i = torch.arange(Tq, device=q.device)[:, None] + (Tk - Tq)
+        j = torch.arange(Tk, device=q.device)[None, :]
+        s = s.masked_fill(j > i, float("-inf"))
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Tq, HD)
+
+
+@pytest.mark.parametrize("B,H,D,Tq,Tk,causal", [(2, 16, 64, 577, 577, False), (1, 4, 64, 257, 257, False),
+                                                 (1, 32, 128, 300, 300, True), (1, 8, 128, 1, 200, True),
+                                                 (1, 8, 128, 5, 133, True), (2, 2, 128, 64, 64, True)])
+def test_flash_attention(B, H, D, Tq, Tk, causal):
+    q, k, v = rnd(B, Tq, H * D, seed=50), rnd(B, Tk, H * D, seed=51), rnd(B, Tk, H * D, seed=52)
+    scale = 1.0 / math.sqrt(D)
+    got = K.flash_attn(q, k, v, H, scale, causal)
+    close(got, _attn_ref(q, k, v, H, scale, causal), 2e-2, 2e-2, f"attn {B,H,D,Tq,Tk,causal}")
+
+
+def test_flash_attention_strided_qkv_and_peaked_rows():
+    # fused qkv buffer [B, T, 3*H*D] (ViT) and one dominant key per row (rescale path)
+    B, T, H, D = 1, 130, 4, 64
+    qkv = rnd(B, T, 3 * H * D, seed=53)
+    qkv[:, :, :H * D] *= 8.0
+    q, k, v = qkv[:, :, :H * D], qkv[:, :, H * D:2 * H * D], qkv[:, :, 2 * H * D:]
+    got = K.flash_attn(q, k, v, H, 0.125, False)
+    close(got, _attn_ref(q, k, v, H, 0.125, False), 3e-2, 3e-2, "attn strided")
+
+
+# ------------------------------------------------------------------------------------------ norms
+def test_layernorm_rmsnorm():
+    x = rnd(77, 1024, scale=3.0, seed=60)
+    g, b = rnd(1024, seed=61, dtype=torch.float32), rnd(1024, seed=62, dtype=torch.float32)
+    close(K.layernorm(x, g, b, 1e-5), F.layer_norm(x.float(), (1024,), g, b, 1e-5), 2e-2, 1e-2, "layernorm")
+    xf = x.float()
+    ref = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16).float() * g
+    close(K.rmsnorm(x, g, 1e-6), ref, 2e-2, 1e-2, "rmsnorm")
+    x2 = rnd(5, 256, seed=63)
+    close(K.layernorm(x2, g[:256].contiguous(), b[:256].contiguous()),
+          F.layer_norm(x2.float(), (256,), g[:256], b[:256]), 2e-2, 1e-2, "layernorm 256")
+
+
+def test_groupnorm_affine():
+    B, H, W, C, G = 2, 12, 10, 1024, 64
+    x = rnd(B, H, W, C, scale=2.0, seed=64) + 0.5
+    g, b = rnd(C, seed=65, dtype=torch.float32), rnd(C, seed=66, dtype=torch.float32)
+    ss = K.groupnorm_affine(x, g, b, G, 1e-5)
+    got = x.float() * ss[:, 0][:, None, None, :] + ss[:, 1][:, None, None, :]
+    ref = F.group_norm(x.float().permute(0, 3, 1, 2), G, g, b, 1e-5).permute(0, 2, 3, 1)
+    close(got, ref, 1e-3, 1e-3, "groupnorm affine")
+
+
+# ------------------------------------------------------------------------------------------ SPI glue
+def test_upsample_coord():
+    B, Pn, C, H = 2, 6, 64, 24
+    hs = rnd(B, Pn * Pn + 1, C, seed=70)
+    tok = hs[:, 1:]                                         # drop CLS: strided view
+    out = K.upsample_coord(tok, Pn, Pn, H, H, 128)
+    feat = tok.float().reshape(B, Pn, Pn, C).permute(0, 3, 1, 2)
+    up = F.interpolate(feat, size=(H, H), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    close(out[..., :C], up, 1e-2, 1e-2, "upsample")
+    xr = torch.linspace(-1, 1, H, device=DEV)
+    close(out[..., C], xr[None, None, :].expand(B, H, H), 4e-3, 0, "x coord")
+    close(out[..., C + 1], xr[None, :, None].expand(B, H, H), 4e-3, 0, "y coord")
+    assert (out[..., C + 2:] == 0).all()
+
+
+def _shuffle_ref(own, top, down, affs):
+    def fin(x, a):
+        x = x.float()
+        if a is not None:
+            x = torch.relu(x * a[:, 0][:, None, None, :] + a[:, 1][:, None, None, :])
+        return x.permute(0, 3, 1, 2)
+    o, t, d = fin(own, affs[0]), fin(top, affs[1]), fin(down, affs[2])
+    C = o.size(1)
+    R, S = C // 2, C // 4
+    size = o.shape[-2:]
+    ft = F.interpolate(t[:, R:][:, S:], size=size, mode="bilinear", align_corners=True)
+    fd = F.interpolate(d[:, R:][:, :S], size=size, mode="bilinear", align_corners=True)
+    return torch.cat([o[:, :R], ft, fd], 1).permute(0, 2, 3, 1)
+
+
+def test_fuse_shuffle():
+    B, C = 2, 64
+    own, top, down = rnd(B, 16, 16, C, seed=71), rnd(B, 8, 8, C, seed=72), rnd(B, 32, 32, C, seed=73)
+    close(K.fuse_shuffle(own, top, down), _shuffle_ref(own, top, down, (None, None, None)), 1e-2, 1e-2, "shuffle")
+    affs = tuple(torch.randn(B, 2, C, device=DEV) for _ in range(3))
+    close(K.fuse_shuffle(own, top, down, *affs), _shuffle_ref(own, top, down, affs), 2e-2, 1e-2, "shuffle+gn")
+    # ends of the pyramid: the level is its own neighbour (layers.py:108-112)
+    close(K.fuse_shuffle(own, own, down, affs[0], affs[0], affs[2]),
+          _shuffle_ref(own, own, down, (affs[0], affs[0], affs[2])), 2e-2, 1e-2, "shuffle top end")
+
+
+def test_vit_front_end():
+    B, S = 2, 56
+    img = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(74)).to(DEV)
+    w = rnd(128, 3, 14, 14, scale=0.05, seed=75)
+    cols = K.im2col_patch14(img, 640)
+    wp = torch.zeros(128, 640, dtype=torch.bfloat16, device=DEV)
+    wp[:, :588] = w.reshape(128, 588)
+    patch = K.gemm(cols, wp)
+    ref = F.conv2d(img.to(torch.bfloat16).float(), w.float(), stride=14).flatten(2).transpose(1, 2)
+    close(patch.view(B, 16, 128), ref, 3e-2, 1e-2, "patch embed")
+    cls, pos = rnd(128, seed=76), rnd(17, 128, seed=77)
+    tok = K.vit_assemble(patch, cls, pos, B)
+    reft = torch.cat([cls.float().expand(B, 1, 128), patch.float().view(B, 16, 128)], 1) + pos.float()
+    close(tok, reft, 2e-2, 1e-2, "vit assemble")
+
+
+def test_rope_swiglu_argmax():
+    T, Hh, D, maxT, pos0 = 9, 4, 128, 64, 5
+    qkv = rnd(T, 3 * Hh * D, seed=80)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(maxT).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().to(DEV), ang.sin().to(DEV)
+    qo = torch.zeros(T, Hh * D, dtype=torch.bfloat16, device=DEV)
+    kc = torch.zeros(maxT, Hh * D, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    K.rope_qkv(qkv, cos, sin, qo, kc, vc, Hh, D, pos0)
+
+    def rot(x, p0):
+        x = x.float().view(-1, Hh, D)
+        c = torch.cat([cos, cos], -1)[p0:p0 + x.size(0)][:, None, :]
+        s = torch.cat([sin, sin], -1)[p0:p0 + x.size(0)][:, None, :]
+        xr = torch.cat([-x[..., D // 2:], x[..., :D // 2]], -1)
+        return (x * c + xr * s).reshape(-1, Hh * D)
+    close(qo, rot(qkv[:, :Hh * D], pos0), 2e-2, 1e-2, "rope q")
+    close(kc[pos0:pos0 + T], rot(qkv[:, Hh * D:2 * Hh * D], pos0), 2e-2, 1e-2, "rope k")
+    assert torch.equal(vc[pos0:pos0 + T], qkv[:, 2 * Hh * D:]) and (kc[:pos0] == 0).all()
+    gu = rnd(7, 2 * 352, seed=81)
+    close(K.swiglu(gu), F.silu(gu[:, :352].float()) * gu[:, 352:].float(), 2e-2, 1e-2, "swiglu")
+    lg = torch.randn(3, 32006, device=DEV)
+    lg[1, 77] = lg[1, 31000] = 50.0
+    assert torch.equal(K.argmax_rows(lg), lg.argmax(-1)) and K.argmax_rows(lg)[1].item() == 77
+
+
+def test_splice_embed():
+    B, T, C, V, NP = 2, 40, 64, 100, 9
+    PATCH, BBOX, IMS, IME = 90, 91, 92, 93
+    ids = torch.randint(3, 80, (B, T), generator=torch.Generator().manual_seed(82))
+    ids[:, 4] = IMS
+    ids[:, 5:5 + NP] = PATCH
+    ids[:, 5 + NP] = IME
+    ids[0, [20, 25, 30]] = BBOX
+    ids[1, [22]] = BBOX
+    ids = ids.to(DEV)
+    embed, img, spi = rnd(V, C, seed=83), rnd(B, NP, C, seed=84), rnd(4, C, seed=85)
+    off = torch.tensor([0, 3, 4], dtype=torch.int32, device=DEV)
+    out, st = K.splice_embed(ids, embed, img, spi, off, NP, PATCH, BBOX, IMS, IME)
+    ref = embed[ids]
+    ref[:, 5:5 + NP] = img
+    ref[0, [20, 25, 30]] = spi[0:3]
+    ref[1, 22] = spi[3]
+    assert torch.equal(out, ref) and (st == 0).all()
+    bad = ids.clone()
+    bad[1, 30] = BBOX                       # one <bbox> too many
+    bad[0, 5 + NP] = 7                      # missing <im_end>
+    _, st = K.splice_embed(bad, embed, img, spi, off, NP, PATCH, BBOX, IMS, IME)
+    assert st[1].item() & 2 and st[0].item() & 8
