@@ -1,0 +1,61 @@
+"""CPU: pins the restated region module (oracle/spi_oracle.py) against outputs of the reference's
+own gpt4roi/models/layers.py (tests/golden/make_spi_golden.py), and the restated splice against a
+hand-built case."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spi_oracle as S
+
+
+def _run_fixture(golden_dir, name, emulate=False):
+    z = np.load(os.path.join(golden_dir, name))
+    C, B, P = int(z["embed_dims"]), int(z["B"]), int(z["P"])
+    m = S.MLVLROIQueryOracle(embed_dims=C, P=P)
+    m.load_state_dict(S.synthetic_state(m, int(z["wseed"])))
+    m.eval()
+    feats, boxes = S.synthetic_inputs(int(z["iseed"]), B, P, C, [int(n) for n in z["n_rois"]])
+    with torch.no_grad():
+        out = torch.cat(m(feats, boxes, emulate=emulate), 0).numpy()
+    return out, z["out"]
+
+
+def test_restated_module_matches_reference_code(golden_dir):
+    got, want = _run_fixture(golden_dir, "spi_module_ref_c64.npz")
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+
+
+def test_bf16_emulation_stays_close_to_fp32(golden_dir):
+    got, want = _run_fixture(golden_dir, "spi_module_ref_c64.npz", emulate=True)
+    rel = np.abs(got - want).max() / np.abs(want).max()
+    assert rel < 5e-2, rel
+
+
+def test_state_dict_keys_are_the_reference_checkpoint_keys():
+    # SURVEY.md section 5 (checkpoint row): key names the module must keep
+    keys = set(S.MLVLROIQueryOracle(embed_dims=64).state_dict().keys())
+    for k in ["mlvl_fuse.input_conv.0.weight", "mlvl_fuse.input_conv.3.bias", "mlvl_fuse.fuse_convs.0.conv.weight",
+              "mlvl_fuse.fuse_convs.4.gn.weight", "mlvl_fuse.fuse_convs.4.gn.bias", "roi_align.pconvs.3.weight",
+              "roi_align.pconvs.0.bias", "roi_align.pos_embedd.0.weight", "roi_align.pos_embedd.2.weight",
+              "roi_align.pos_embedd.3.bias", "roi_align.pos_embedd.5.bias", "roi_align.updims.weight",
+              "roi_align.flatten_linear.weight"]:
+        assert k in keys, k
+    assert not any("fuse_convs" in k and k.endswith("conv.bias") for k in keys)  # conv_module.py:104-105
+
+
+def test_splice_restatement():
+    # spi_llava.py:99-196: patches go between <im_start>/<im_end>, <bbox> rows take region features
+    IMS, IME, BBOX, T, C, NP = 50, 51, 52, 12, 4, 3
+    ids = torch.tensor([[1, IMS, 9, 9, 9, IME, 7, BBOX, 8, BBOX, 2, 2]])
+    emb = torch.arange(T * C, dtype=torch.float32).reshape(1, T, C)
+    img = -torch.ones(1, NP, C)
+    spi = [torch.full((2, C), 100.0) * torch.tensor([[1.0], [2.0]])]
+    out = S.splice(ids, emb, img, spi, IMS, IME, BBOX)
+    assert torch.equal(out[0, 2:5], img[0]) and torch.equal(out[0, 7], spi[0][0]) and torch.equal(out[0, 9], spi[0][1])
+    assert torch.equal(out[0, [0, 1, 5, 6, 8, 10, 11]], emb[0, [0, 1, 5, 6, 8, 10, 11]])
+    bad = ids.clone()
+    bad[0, 5] = 3
+    with pytest.raises(ValueError):
+        S.splice(bad, emb, img, spi, IMS, IME, BBOX)
