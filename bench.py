@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- region-tokens/s of the region-feature path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], the one the metric is quoted on): ONE 336x336 image, 32 RoIs,
+batch 1 per GPU: CLIP ViT-L/14 (23 of 24 blocks) -> 4-level pyramid + 5 fuse rounds -> multi-level
+RoIAlign -> pconvs / flatten_linear / pos-embed / updims -> mm_projector -> splice + <bbox>
+injection -> LLaMA-7B prefill forward with logits for every position.  A "step" is one such
+image; inputs (image, boxes, token ids) and all weights are resident in HBM before the timed
+region.  Weights are seeded random tensors of the real shapes (no checkpoints in this
+environment).  Multi-GPU: the path shards by image with no data-path collective (inference
+replicas), so scaling is weak and `value` = all ranks' region tokens / max-rank time.
+
+Extra objects on the JSON line:
+  roofline     -- the kernel family with the largest share of a step, timed per launch with HIP
+                  events on the launch stream in an instrumented (untimed) extra step
+  cpu_baseline -- the reference's CPU path for the stages north_star names (mmcv CPU RoIAlign as
+                  compiled in oracle/_ref, 1 thread by construction, + CLIP ViT-L/14 fp32 on the
+                  host cores), rank 0 / N = 1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA peak, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0       # HBM3E spec peak, same table
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--image-size", type=int, default=336)
+    ap.add_argument("--rois", type=int, default=32)
+    ap.add_argument("--llama-layers", type=int, default=32, help="debug only; anything but 32 marks the line invalid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(args, device, seed):
+    from gpt4roi_amd import synthetic as syn
+    from gpt4roi_amd.llama import LlamaDecoder
+    from gpt4roi_amd.spi_llava import SPILlavaLlamaModel
+    from gpt4roi_amd.vit import ClipVisionTower
+    ids = syn.token_ids(32000)
+    bf = torch.bfloat16
+    v = syn.CLIP_L14
+    vsd = syn.vit_state(v["hidden"], v["inter"], v["layers"], args.image_size, seed=seed, device=device, dtype=bf)
+    tower = ClipVisionTower(vsd, heads=v["heads"], device=device)
+    del vsd
+    l = syn.LLAMA_7B
+    lsd = syn.llama_state(l["hidden"], l["inter"], args.llama_layers, ids.vocab, seed=seed + 1, device=device, dtype=bf)
+    dec = LlamaDecoder(lsd, heads=l["heads"], max_positions=2048, device=device)
+    del lsd
+    model = SPILlavaLlamaModel(tower, dec, ids, embed_dims=v["hidden"])
+    model.spi_module.to(device)
+    model.mm_projector.to(device)
+    syn.spi_state_gpu(model.spi_module, seed=seed + 2)
+    model.prepare()
+    # the kernel-ready copies are what the path reads; drop the fp32 masters of the big layers
+    torch.cuda.empty_cache()
+    return model, ids
+
+
+def make_inputs(args, ids, device, seed):
+    from gpt4roi_amd import synthetic as syn
+    g = torch.Generator().manual_seed(seed)
+    P = args.image_size // 14
+    image = torch.randn(1, 3, args.image_size, args.image_size, generator=g).to(device)
+    boxes = [syn.boxes(args.rois, g).to(device)]
+    prompt = syn.prompt_ids(ids, P, args.rois, g)[None].to(device)
+    return image, boxes, prompt
+
+
+def cpu_baseline(args):
+    """Reference CPU RoIAlign (oracle/_ref: the reference's own sources, single-threaded by
+    construction) on the 4 pyramid levels + CLIP ViT-L/14 fp32 on the host cores, one image."""
+    import numpy as np
+    from oracle import roi_align as O
+    from oracle import transformer_oracle as T
+    from gpt4roi_amd import synthetic as syn
+    P = args.image_size // 14
+    g = torch.Generator().manual_seed(0)
+    kind = "reference" if O.load_ref() is not None else "port"
+    rois = torch.cat([torch.zeros(args.rois, 1), syn.boxes(args.rois, g) * 14 * P], 1).numpy().astype(np.float32)
+    t_roi = 0.0
+    for lvl, stride in enumerate([14 / 8, 14 / 4, 14 / 2, 14]):
+        side = P * 2 ** (3 - lvl)
+        x = torch.randn(1, 1024, side, side, generator=g).numpy()
+        t0 = time.perf_counter()
+        (O.ref_forward if kind == "reference" else O.forward)(x, rois, 14, np.float32(1.0 / stride), 2)
+        t_roi += time.perf_counter() - t0
+    torch.set_num_threads(os.cpu_count())
+    v = syn.CLIP_L14
+    sd = syn.vit_state(v["hidden"], v["inter"], 23, args.image_size, seed=0)
+    img = torch.randn(1, 3, args.image_size, args.image_size, generator=g)
+    with torch.no_grad():
+        T.clip_vit_hidden_states(sd, img, heads=16, n_layers=23)          # page-in / thread pool warm-up
+        t0 = time.perf_counter()
+        T.clip_vit_hidden_states(sd, img, heads=16, n_layers=23)
+        t_vit = time.perf_counter() - t0
+    return {"value": round(args.rois / (t_roi + t_vit), 3), "unit": "region-tokens/s", "cores": torch.get_num_threads(),
+            "kind": kind, "host_cpu_count": os.cpu_count(),
+            "sample": (f"1 image {args.image_size}^2, {args.rois} RoIs: mmcv CPU roi_align fp32 x4 levels (1 thread, "
+                       f"{t_roi:.3f} s) + CLIP ViT-L/14 fp32 23 blocks ({torch.get_num_threads()} threads, {t_vit:.3f} s); "
+                       "fuse convs / LLaMA-7B are not part of the CPU sample"),
+            "roi_align_s": round(t_roi, 4), "vit_s": round(t_vit, 4)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(device))   # "nccl" is RCCL on ROCm
+    from gpt4roi_amd import kernels as K
+
+    model, ids = build_model(args, device, seed=100 + rank)
+    image, boxes, prompt = make_inputs(args, ids, device, seed=rank)
+
+    def step():
+        return model(input_ids=prompt, images=image, bboxes=boxes)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    model.check_status()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(logits[0, -1]).all(), "non-finite logits"
+
+    roofline, kernels = None, None
+    if rank == 0 and not args.no_roofline:
+        K.PROFILER.start()
+        step()
+        agg = K.PROFILER.stop()
+        tot = sum(a["ms"] for a in agg.values())
+        kernels = {k: {"calls": a["calls"], "ms": round(a["ms"], 3), "share": round(a["ms"] / tot, 3),
+                       "avg_us": round(1e3 * a["ms"] / a["calls"], 2),
+                       "TFLOP/s": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 1) if a["flops"] else None,
+                       "GB/s": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)}
+                   for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        dom, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": a["calls"], "avg_launch_us": round(1e3 * a["ms"] / a["calls"], 2),
+                    "share_of_step": round(a["ms"] / tot, 3)}
+        ra = agg.get("roi_align_mlvl_nhwc")
+        if ra:
+            gbs = ra["bytes"] / (ra["ms"] * 1e-3) / 1e9
+            roofline["roi_align"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                     "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(ra["bytes"]),
+                                     "avg_launch_us": round(1e3 * ra["ms"] / ra["calls"], 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(args)
+        except Exception as ex:                                      # never lose the GPU number
+            cpu = {"error": repr(ex)}
+
+    if rank == 0:
+        P = args.image_size // 14
+        total_regions = args.rois * args.steps * world
+        line = {
+            "metric": "region-tokens/sec (336^2 img, 32 RoIs, CLIP ViT-L/14 + region module + LLaMA-7B fwd)",
+            "value": round(total_regions / dt, 2), "unit": "region-tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "value_per_gpu": round(total_regions / dt / world, 2),
+            "config": {"workload": f"configs[1]: 1x{args.image_size}^2 image, {args.rois} RoIs, batch 1 per GPU, "
+                                   f"ViT-L/14(23 blocks) + SPI(P={P}) + LLaMA-7B({args.llama_layers} layers) prefill "
+                                   f"T={prompt.size(1)} with full logits",
+                       "image_size": args.image_size, "rois_per_image": args.rois, "prompt_tokens": int(prompt.size(1)),
+                       "parallelism": f"replicas x{world} (no data-path collective)",
+                       "valid": args.llama_layers == 32 and args.image_size == 336 and args.rois == 32},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

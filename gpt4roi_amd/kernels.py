@@ -54,6 +54,49 @@ def _fn(name):
     return f
 
 
+class _Profiler:
+    """Optional per-launch HIP-event timing (bench.py's roofline leg).  Events are recorded on the
+    stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def start(self):
+        self.records, self.enabled = [], True
+
+    def stop(self):
+        """-> {tag: dict(calls, ms, flops, bytes)}"""
+        self.enabled = False
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, flops, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(tag, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            a["calls"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += flops
+            a["bytes"] += nbytes
+        self.records = []
+        return agg
+
+
+PROFILER = _Profiler()
+TILE_NAMES = {0: "128x128", 1: "256x128", 2: "128x128reg", 4: "64x128"}
+
+
+def _launch(name, args, tag=None, flops=0.0, nbytes=0.0):
+    f = _fn(name)
+    if PROFILER.enabled:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = f(*args)
+        e1.record()
+        PROFILER.records.append((tag or name, flops, nbytes, e0, e1))
+    else:
+        rc = f(*args)
+    _lib.check(rc, name)
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -116,11 +159,12 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
         tile_cfg = pick_tile(M, N)
     if splits > 1 and workspace is None:
         workspace = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
-    rc = _fn("g4r_gemm_bf16_nt")(
+    _launch("g4r_gemm_bf16_nt", (
         _p(a), _p(w), _p(out), _p(bias), _p(residual), _p(workspace), M, N, K, a.stride(0), w.stride(0),
         out.stride(0), residual.stride(0) if residual is not None else 0, ACT[act],
-        1 if out.dtype == torch.float32 else 0, splits, tile_cfg, _stream(a))
-    _lib.check(rc, "g4r_gemm_bf16_nt")
+        1 if out.dtype == torch.float32 else 0, splits, tile_cfg, _stream(a),),
+        tag=(f"gemm_bf16_nt<{TILE_NAMES.get(tile_cfg, tile_cfg)}>" + ("+splitk" if splits > 1 else "")) if K % 64 == 0
+        else "small_linear", flops=2.0 * M * N * K, nbytes=2.0 * (M * K + N * K) + out.element_size() * M * N)
     return out
 
 
@@ -147,10 +191,11 @@ def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=torch.bfloa
         tile_cfg = pick_tile(B * H * W, Cout)
     if splits > 1 and workspace is None:
         workspace = torch.empty((splits, B * H * W, Cout), dtype=torch.float32, device=x.device)
-    rc = _fn("g4r_conv3x3_nhwc_bf16")(
+    _launch("g4r_conv3x3_nhwc_bf16", (
         _p(x), _p(w), _p(out), _p(bias), _p(zeros_line(x.device)), _p(workspace), B, H, W, Cin, Cout, groups,
-        gstride, ACT[act], 1 if out.dtype == torch.float32 else 0, splits, tile_cfg, _stream(x))
-    _lib.check(rc, "g4r_conv3x3_nhwc_bf16")
+        gstride, ACT[act], 1 if out.dtype == torch.float32 else 0, splits, tile_cfg, _stream(x),),
+        tag=f"conv3x3_igemm<{TILE_NAMES.get(tile_cfg, tile_cfg)}>", flops=2.0 * B * H * W * Cout * groups * 9 * Cin,
+        nbytes=2.0 * (groups * B * H * W * Cin + Cout * groups * 9 * Cin + B * H * W * Cout))
     return out
 
 
@@ -171,10 +216,11 @@ def flash_attn(q, k, v, heads, scale, causal=False, out=None):
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
     if out is None:
         out = torch.empty((B, Tq, HD), dtype=torch.bfloat16, device=q.device)
-    rc = _fn("g4r_flash_attn_fwd_bf16")(
+    _launch("g4r_flash_attn_fwd_bf16", (
         _p(q), _p(k), _p(v), _p(out), B, heads, Tq, Tk, D, q.stride(1), k.stride(1), v.stride(1), out.stride(1),
-        q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), int(bool(causal)), _stream(q))
-    _lib.check(rc, "g4r_flash_attn_fwd_bf16")
+        q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), int(bool(causal)), _stream(q),),
+        tag=f"flash_attn<{D}>", flops=4.0 * B * heads * Tq * Tk * D * (0.5 if causal and Tq == Tk else 1.0),
+        nbytes=2.0 * B * HD * (2 * Tq + 2 * Tk))
     return out
 
 
@@ -185,9 +231,9 @@ def layernorm(x, gamma, beta, eps=1e-5, relu_in=False, out=None):
     assert x2.dim() == 2 and x2.stride(1) == 1
     if out is None:
         out = torch.empty((x2.size(0), x2.size(1)), dtype=torch.bfloat16, device=x.device)
-    rc = _fn("g4r_layernorm_bf16")(_p(x2), _p(gamma), _p(beta), _p(out), x2.size(0), x2.size(1), x2.stride(0),
-                                   out.stride(0), float(eps), int(relu_in), _stream(x))
-    _lib.check(rc, "g4r_layernorm_bf16")
+    _launch("g4r_layernorm_bf16", (
+        _p(x2), _p(gamma), _p(beta), _p(out), x2.size(0), x2.size(1), x2.stride(0),
+                                   out.stride(0), float(eps), int(relu_in), _stream(x),))
     return out.view(x.shape) if x.is_contiguous() else out
 
 
@@ -197,9 +243,9 @@ def rmsnorm(x, gamma, eps=1e-6, out=None):
     x2 = x.reshape(-1, x.size(-1))
     if out is None:
         out = torch.empty_like(x2)
-    rc = _fn("g4r_rmsnorm_bf16")(_p(x2), _p(gamma), _p(out), x2.size(0), x2.size(1), x2.stride(0), out.stride(0),
-                                 float(eps), _stream(x))
-    _lib.check(rc, "g4r_rmsnorm_bf16")
+    _launch("g4r_rmsnorm_bf16", (
+        _p(x2), _p(gamma), _p(out), x2.size(0), x2.size(1), x2.stride(0), out.stride(0),
+                                 float(eps), _stream(x),))
     return out.view(x.shape)
 
 
@@ -210,9 +256,9 @@ def groupnorm_affine(x, gamma, beta, groups, eps=1e-5):
     B, H, W, C = x.shape
     acc = torch.empty((B, groups, 2), dtype=torch.float64, device=x.device)
     ss = torch.empty((B, 2, C), dtype=torch.float32, device=x.device)
-    rc = _fn("g4r_groupnorm_affine_nhwc_bf16")(_p(x), _p(gamma), _p(beta), _p(acc), _p(ss), B, H * W, C, groups,
-                                               float(eps), _stream(x))
-    _lib.check(rc, "g4r_groupnorm_affine_nhwc_bf16")
+    _launch("g4r_groupnorm_affine_nhwc_bf16", (
+        _p(x), _p(gamma), _p(beta), _p(acc), _p(ss), B, H * W, C, groups,
+                                               float(eps), _stream(x),))
     return ss
 
 
@@ -222,9 +268,9 @@ def upsample_coord(tokens, hin, win, H, W, cpad):
     B, n, C = tokens.shape
     assert n == hin * win and tokens.stride(2) == 1
     out = torch.empty((B, H, W, cpad), dtype=torch.bfloat16, device=tokens.device)
-    rc = _fn("g4r_upsample_coord_nhwc_bf16")(_p(tokens), _p(out), B, hin, win, tokens.stride(0), tokens.stride(1),
-                                             H, W, C, cpad, _stream(tokens))
-    _lib.check(rc, "g4r_upsample_coord_nhwc_bf16")
+    _launch("g4r_upsample_coord_nhwc_bf16", (
+        _p(tokens), _p(out), B, hin, win, tokens.stride(0), tokens.stride(1),
+                                             H, W, C, cpad, _stream(tokens),))
     return out
 
 
@@ -234,10 +280,10 @@ def fuse_shuffle(own, top, down, own_aff=None, top_aff=None, down_aff=None, out=
     B, H, W, C = own.shape
     if out is None:
         out = torch.empty_like(own)
-    rc = _fn("g4r_fuse_shuffle_nhwc_bf16")(_p(own), _p(own_aff), H, W, _p(top), _p(top_aff), top.size(1),
+    _launch("g4r_fuse_shuffle_nhwc_bf16", (
+        _p(own), _p(own_aff), H, W, _p(top), _p(top_aff), top.size(1),
                                            top.size(2), _p(down), _p(down_aff), down.size(1), down.size(2),
-                                           _p(out), B, C, _stream(own))
-    _lib.check(rc, "g4r_fuse_shuffle_nhwc_bf16")
+                                           _p(out), B, C, _stream(own),))
     return out
 
 
@@ -247,8 +293,8 @@ def im2col_patch14(img, kpad=640):
     B, _, S, _ = img.shape
     Pn = S // 14
     out = torch.empty((B * Pn * Pn, kpad), dtype=torch.bfloat16, device=img.device)
-    rc = _fn("g4r_im2col_patch14_f32")(_p(img), _p(out), B, S, kpad, _stream(img))
-    _lib.check(rc, "g4r_im2col_patch14_f32")
+    _launch("g4r_im2col_patch14_f32", (
+        _p(img), _p(out), B, S, kpad, _stream(img),))
     return out
 
 
@@ -257,8 +303,8 @@ def vit_assemble(patch, cls, pos, B):
     n = patch.size(0) // B
     C = patch.size(1)
     tok = torch.empty((B, n + 1, C), dtype=torch.bfloat16, device=patch.device)
-    rc = _fn("g4r_vit_assemble_bf16")(_p(patch), _p(cls), _p(pos), _p(tok), B, n, C, _stream(patch))
-    _lib.check(rc, "g4r_vit_assemble_bf16")
+    _launch("g4r_vit_assemble_bf16", (
+        _p(patch), _p(cls), _p(pos), _p(tok), B, n, C, _stream(patch),))
     return tok
 
 
@@ -266,9 +312,9 @@ def rope_qkv(qkv, cos, sin, q_out, k_cache, v_cache, heads, head_dim, pos0):
     _bf16(qkv, q_out, k_cache, v_cache)
     _f32(cos, sin)
     T = qkv.size(0)
-    rc = _fn("g4r_rope_qkv_bf16")(_p(qkv), _p(cos), _p(sin), _p(q_out), _p(k_cache), _p(v_cache), T, heads,
-                                  head_dim, pos0, _stream(qkv))
-    _lib.check(rc, "g4r_rope_qkv_bf16")
+    _launch("g4r_rope_qkv_bf16", (
+        _p(qkv), _p(cos), _p(sin), _p(q_out), _p(k_cache), _p(v_cache), T, heads,
+                                  head_dim, pos0, _stream(qkv),))
 
 
 def swiglu(gate_up, out=None):
@@ -276,8 +322,8 @@ def swiglu(gate_up, out=None):
     T, F2 = gate_up.shape
     if out is None:
         out = torch.empty((T, F2 // 2), dtype=torch.bfloat16, device=gate_up.device)
-    rc = _fn("g4r_swiglu_bf16")(_p(gate_up), _p(out), T, F2 // 2, _stream(gate_up))
-    _lib.check(rc, "g4r_swiglu_bf16")
+    _launch("g4r_swiglu_bf16", (
+        _p(gate_up), _p(out), T, F2 // 2, _stream(gate_up),))
     return out
 
 
@@ -291,10 +337,10 @@ def splice_embed(ids, embed, img, spi, spi_offset, n_patch, patch_id, bbox_id, i
     C = embed.size(1)
     out = torch.empty((B, T, C), dtype=torch.bfloat16, device=ids.device)
     status = torch.empty((B,), dtype=torch.int32, device=ids.device)
-    rc = _fn("g4r_splice_embed_bf16")(_p(ids), _p(embed), _p(img), _p(spi), _p(spi_offset), _p(out), _p(status),
+    _launch("g4r_splice_embed_bf16", (
+        _p(ids), _p(embed), _p(img), _p(spi), _p(spi_offset), _p(out), _p(status),
                                       B, T, C, n_patch if img is not None else 0, patch_id, bbox_id,
-                                      im_start_id, im_end_id, embed.size(0), _stream(ids))
-    _lib.check(rc, "g4r_splice_embed_bf16")
+                                      im_start_id, im_end_id, embed.size(0), _stream(ids),))
     return out, status
 
 
@@ -302,8 +348,8 @@ def argmax_rows(logits):
     _f32(logits)
     rows, N = logits.shape
     out = torch.empty((rows,), dtype=torch.int64, device=logits.device)
-    rc = _fn("g4r_argmax_rows_f32")(_p(logits), logits.stride(0), rows, N, _p(out), _stream(logits))
-    _lib.check(rc, "g4r_argmax_rows_f32")
+    _launch("g4r_argmax_rows_f32", (
+        _p(logits), logits.stride(0), rows, N, _p(out), _stream(logits),))
     return out
 
 
@@ -313,8 +359,8 @@ def add_rows(a, b, out=None):
     b2 = b.reshape(-1, b.size(-1))
     if out is None:
         out = torch.empty_like(a2)
-    rc = _fn("g4r_add_rows_bf16")(_p(a2), _p(b2), _p(out), a2.size(0), a2.size(1), b2.size(0), _stream(a))
-    _lib.check(rc, "g4r_add_rows_bf16")
+    _launch("g4r_add_rows_bf16", (
+        _p(a2), _p(b2), _p(out), a2.size(0), a2.size(1), b2.size(0), _stream(a),))
     return out.view(a.shape)
 
 
@@ -322,8 +368,8 @@ def cast_bf16(x):
     _f32(x)
     x = x.contiguous()
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    rc = _fn("g4r_cast_f32_to_bf16")(_p(x), _p(y), x.numel(), _stream(x))
-    _lib.check(rc, "g4r_cast_f32_to_bf16")
+    _launch("g4r_cast_f32_to_bf16", (
+        _p(x), _p(y), x.numel(), _stream(x),))
     return y
 
 
@@ -352,8 +398,10 @@ def roi_align_mlvl(feats, rois, output_size, scales, sampling_ratio=2, aligned=T
     ha = (c_int * L)(*[f.size(1) for f in feats])
     wa = (c_int * L)(*[f.size(2) for f in feats])
     sa = (c_float * L)(*[float(s) for s in scales])
-    rc = _fn(name)(ctypes.cast(fa, P), ctypes.cast(aa, P) if aa is not None else None, ctypes.cast(ha, P),
+    # algorithmic bytes: every map texel once + every output element once
+    alg = sum(f.numel() for f in feats) * feats[0].element_size() + out.numel() * out.element_size() + rois.numel() * 4
+    _launch(name, (ctypes.cast(fa, P), ctypes.cast(aa, P) if aa is not None else None, ctypes.cast(ha, P),
                    ctypes.cast(wa, P), ctypes.cast(sa, P), L, _p(rois), _p(out), B, C, N, ph, pw,
-                   int(sampling_ratio), int(bool(aligned)), _stream(rois))
-    _lib.check(rc, name)
+                   int(sampling_ratio), int(bool(aligned)), _stream(rois)),
+            tag="roi_align_mlvl_nhwc", flops=0.0, nbytes=float(alg))
     return out

@@ -1,0 +1,262 @@
+"""MI355X drop-in for `gpt4roi.models.layers` (the region-feature module).
+
+Mirrors /root/reference/gpt4roi/models/layers.py: `MLVLFuseModule` (:96-195),
+`MLVLROIQueryModule` (:198-236) and `MlvlRoIExtractor` (:239-335) keep their constructor
+arguments, attribute names and therefore their `state_dict` keys
+(`mlvl_fuse.input_conv.N.*`, `mlvl_fuse.fuse_convs.N.conv|gn.*`, `roi_align.pconvs.N.*`,
+`roi_align.pos_embedd.{0,2,3,5}.*`, `roi_align.updims.*`, `roi_align.flatten_linear.*`), and
+`MLVLROIQueryModule.forward(mlvl_feats, bboxes) -> list[B] of [n_i, out_dims]` keeps its
+contract.  The arithmetic runs on the hand-written gfx950 kernels (gpt4roi_amd/csrc) in a
+different decomposition than the reference's op-by-op PyTorch graph:
+
+  reference (per level, per round)              here (NHWC, bf16 storage, fp32 math)
+  --------------------------------------------  ---------------------------------------------
+  interpolate -> cat(coords) -> conv1x1         upsample_coord kernel -> one MFMA GEMM (K padded)
+  slice/interp(fp32)/cat -> conv3x3 -> GN -> ReLU  fuse_shuffle gather (applies the PREVIOUS round's
+                                                GN+ReLU on the fly) -> implicit-GEMM conv ->
+                                                GN statistics only (normalised map never stored)
+  4 x roi_align(fp32) on normalised maps        one multi-level NHWC RoIAlign launch that applies
+                                                the last GN+ReLU per texel
+  4 x conv3x3 + sum + ReLU                      one implicit GEMM with K = 4*9*C (+bias sum, ReLU)
+  flatten (c-major) -> Linear                   split-K GEMM on a weight permuted once to NHWC order
+
+Differences from the reference, all parameterised and the reference's values the default:
+  * the hard-wired 16x16 / 224 constants (layers.py:220-222, 289-291, 297) are derived from the
+    input (P = sqrt(tokens), image side 14*P);
+  * `out_dims` is honoured (the reference hard-codes Linear(1024, 4096) and ignores the argument);
+  * this is the inference/forward path: parameters are read under no_grad and converted once
+    into kernel-ready buffers (`prepare()`); call `prepare()` again after changing weights.
+    The backward of the fused module is a later row; RoIAlign's own backward
+    exists (gpt4roi_amd/roi_align.py).
+There is no CPU path: on a machine without the HIP library or a GPU the module raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .roi_align import RoIAlign
+
+
+def normal_init(module, mean=0, std=1, bias=0):
+    if getattr(module, 'weight', None) is not None:
+        nn.init.normal_(module.weight, mean, std)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+class ConvModule(nn.Module):
+    """Parameter container with mmcv ConvModule's layout for (3x3 conv, GN): `conv` without
+    bias (conv_module.py:104-105), `gn` = GroupNorm(num_groups, eps 1e-5) (norm.py:101-107)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, conv_cfg=None,
+                 norm_cfg=None):
+        super().__init__()
+        assert conv_cfg is None and norm_cfg is not None and norm_cfg['type'] == 'GN'
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False)
+        self.gn = nn.GroupNorm(norm_cfg['num_groups'], out_channels, eps=1e-5)
+        nn.init.kaiming_normal_(self.conv.weight, a=0, mode='fan_out', nonlinearity='relu')
+
+
+class MLVLFuseModule(nn.Module):
+
+    def __init__(self, input_dims=1024, embed_dims=1024, num_levels=3, num_fuse=4):
+        super().__init__()
+        self.embed_dims = embed_dims
+        self.num_levels = num_levels
+        self.num_fuse = num_fuse
+        self.input_dims = input_dims
+        self.shuffle_channles = embed_dims // 4
+        self.fuse_lvl_list = []
+        for lvl in range(num_levels):
+            self.fuse_lvl_list.append((lvl, min(lvl + 1, num_levels - 1), max(lvl - 1, 0)))
+        self.remain_chs = self.embed_dims - self.shuffle_channles * 2
+        self.input_conv = nn.ModuleList([nn.Conv2d(self.input_dims + 2, self.embed_dims, 1)
+                                         for _ in range(self.num_levels)])
+        self.fuse_convs = nn.ModuleList([
+            ConvModule(self.embed_dims, self.embed_dims, 3, stride=1, padding=1, conv_cfg=None,
+                       norm_cfg=dict(type='GN', num_groups=64, requires_grad=True))
+            for _ in range(self.num_fuse)])
+        self._ready = None
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                normal_init(m, std=0.01)
+
+    def prepare(self):
+        dev = self.input_conv[0].weight.device
+        cin = self.input_dims + 2
+        self.cpad = -(-cin // 64) * 64
+        bf = torch.bfloat16
+        w_in, b_in = [], []
+        with torch.no_grad():
+            for conv in self.input_conv:
+                w = torch.zeros(self.embed_dims, self.cpad, dtype=bf, device=dev)
+                w[:, :cin] = conv.weight.reshape(self.embed_dims, cin).to(bf)
+                w_in.append(w)
+                b_in.append(conv.bias.to(bf).float().contiguous())
+            w_f = [K.prep_conv3x3_weight(m.conv.weight.detach()) for m in self.fuse_convs]
+            gn = [(m.gn.weight.detach().float().contiguous(), m.gn.bias.detach().float().contiguous(),
+                   m.gn.num_groups, m.gn.eps) for m in self.fuse_convs]
+        self._ready = dict(w_in=w_in, b_in=b_in, w_f=w_f, gn=gn)
+
+    def forward(self, tokens, P, sizes):
+        """tokens: list[num_levels] of [B, P*P, C] bf16 (row/batch strided views allowed).
+        Returns (raw conv maps [B,H_l,W_l,C] bf16, deferred GN+ReLU affines [B,2,C] fp32)."""
+        if self._ready is None:
+            self.prepare()
+        r = self._ready
+        B = tokens[0].size(0)
+        maps, affs = [], [None] * self.num_levels
+        for lvl, tok in enumerate(tokens):
+            H = sizes[lvl]
+            x = K.upsample_coord(tok, P, P, H, H, self.cpad)
+            y = K.gemm(x.view(B * H * H, self.cpad), r['w_in'][lvl], bias=r['b_in'][lvl])
+            maps.append(y.view(B, H, H, self.embed_dims))
+        for rnd in range(self.num_fuse):
+            g, bt, groups, eps = r['gn'][rnd]
+            new_maps, new_affs = [], []
+            for tar, top, dow in self.fuse_lvl_list:
+                inp = K.fuse_shuffle(maps[tar], maps[top], maps[dow], affs[tar], affs[top], affs[dow])
+                z = K.conv3x3(inp, r['w_f'][rnd])
+                new_maps.append(z)
+                new_affs.append(K.groupnorm_affine(z, g, bt, groups, eps))
+            maps, affs = new_maps, new_affs
+        return maps, affs
+
+
+class BaseRoIExtractor(nn.Module):
+    """mmdet BaseRoIExtractor.build_roi_layers (base_roi_extractor.py:37-60): one RoIAlign per
+    stride, resolved here to gpt4roi_amd.roi_align.RoIAlign instead of `getattr(mmcv.ops, ...)`."""
+
+    def __init__(self, roi_layer, out_channels, featmap_strides, init_cfg=None):
+        super().__init__()
+        cfg = dict(roi_layer)
+        layer_type = cfg.pop('type')
+        assert layer_type == 'RoIAlign', layer_type
+        self.roi_layers = nn.ModuleList([RoIAlign(spatial_scale=1 / s, **cfg) for s in featmap_strides])
+        self.out_channels = out_channels
+        self.featmap_strides = featmap_strides
+        self.fp16_enabled = False
+
+    @property
+    def num_inputs(self):
+        return len(self.featmap_strides)
+
+
+class MlvlRoIExtractor(BaseRoIExtractor):
+
+    def __init__(self, roi_layer, out_channels, featmap_strides, embed_dims=1024, stride=1, norm_init=True,
+                 fuse_level=3, finest_scale=56, init_cfg=None, out_dims=4096):
+        super().__init__(roi_layer, out_channels, featmap_strides, init_cfg)
+        self.embed_dims = embed_dims
+        self.finest_scale = finest_scale      # stored, unused (as in the reference, layers.py:248)
+        self.fuse_level = fuse_level
+        self.norm_init = norm_init
+        self.pconvs = nn.ModuleList(nn.Conv2d(self.embed_dims, self.embed_dims, 3, stride=1, padding=1)
+                                    for _ in range(self.fuse_level))
+        self.pos_embedd = nn.Sequential(nn.Linear(4, 256), nn.ReLU(inplace=True), nn.LayerNorm(256),
+                                        nn.Linear(256, 1024), nn.ReLU(inplace=True), nn.LayerNorm(1024))
+        self.updims = nn.Linear(1024, out_dims)
+        self.flatten_linear = nn.Linear(self.embed_dims * self.roi_layers[0].output_size[0] ** 2, 1024)
+        self.norm_init_weights()
+        self._ready = None
+
+    def norm_init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                normal_init(m, 0, 0.01)
+
+    def prepare(self):
+        bf = torch.bfloat16
+        C = self.embed_dims
+        oh, ow = self.roi_layers[0].output_size
+        with torch.no_grad():
+            w_p = K.prep_conv3x3_weight([c.weight.detach() for c in self.pconvs])
+            b_p = sum(c.bias.detach().to(bf).float() for c in self.pconvs).contiguous()
+            # flatten is c-major in the reference (layers.py:326): column c*oh*ow + pos.  Our RoI
+            # features are NHWC, so permute the weight once: column pos*C + c.
+            wf = self.flatten_linear.weight.detach()
+            w_fl = wf.view(wf.size(0), C, oh * ow).permute(0, 2, 1).reshape(wf.size(0), oh * ow * C).to(bf).contiguous()
+
+            def lin(l):
+                return l.weight.detach().to(bf).contiguous(), l.bias.detach().to(bf).float().contiguous()
+
+            def ln(l):
+                return l.weight.detach().float().contiguous(), l.bias.detach().float().contiguous(), l.eps
+            self._ready = dict(w_p=w_p, b_p=b_p, w_fl=w_fl, b_fl=self.flatten_linear.bias.detach().to(bf).float().contiguous(),
+                               pe0=lin(self.pos_embedd[0]), ln2=ln(self.pos_embedd[2]), pe3=lin(self.pos_embedd[3]),
+                               ln5=ln(self.pos_embedd[5]), up=lin(self.updims))
+
+    def forward(self, feats, rois, roi_scale_factor=None, affines=None, image_size=224):
+        """feats: list of NHWC bf16 maps [B,H_l,W_l,C]; rois: list[B] of [n_i,4] normalised xyxy;
+        affines: deferred GN+ReLU per level (from MLVLFuseModule.forward) or None."""
+        if self._ready is None:
+            self.prepare()
+        r = self._ready
+        dev = feats[0].device
+        num_imgs = len(rois)
+        counts = [int(b.size(0)) for b in rois]
+        batch_rois = torch.cat([b.to(dev) for b in rois], 0).float()
+        N = batch_rois.size(0)
+        out_dims = self.updims.out_features
+        if N == 0:
+            return [feats[0].new_zeros((0, out_dims)) for _ in range(num_imgs)]
+        # pos_embedd(cat(bboxes)) on the raw normalised boxes (layers.py:284-285)
+        pe = K.gemm(batch_rois.to(torch.bfloat16), r['pe0'][0], bias=r['pe0'][1], act='relu')
+        pe = K.layernorm(pe, r['ln2'][0], r['ln2'][1], r['ln2'][2])
+        pe = K.gemm(pe, r['pe3'][0], bias=r['pe3'][1], act='relu')
+        pe = K.layernorm(pe, r['ln5'][0], r['ln5'][1], r['ln5'][2])
+        # rois = [img_id, box * image_size]  (layers.py:295-302; 224 in the reference)
+        img_id = torch.repeat_interleave(torch.arange(num_imgs, device=dev), torch.tensor(counts, device=dev))
+        rois5 = torch.cat([img_id[:, None].float(), batch_rois * float(image_size)], 1).contiguous()
+        rl = self.roi_layers[0]
+        roi_feats = K.roi_align_mlvl(feats, rois5, rl.output_size, [l.spatial_scale for l in self.roi_layers],
+                                     sampling_ratio=rl.sampling_ratio, aligned=rl.aligned, affines=affines)
+        # sum_l pconv_l(roi_feats[l]) -> ReLU   (layers.py:321-325), one implicit GEMM
+        fused = K.conv3x3(roi_feats, r['w_p'], bias=r['b_p'], act='relu', groups=self.fuse_level)
+        flat = fused.view(N, -1)
+        x = K.gemm(flat, r['w_fl'], bias=r['b_fl'], splits=64, tile_cfg=4)
+        x = K.add_rows(x, pe)
+        x = K.gemm(x, r['up'][0], bias=r['up'][1])
+        return list(torch.split(x, counts, 0))
+
+
+class MLVLROIQueryModule(nn.Module):
+
+    def __init__(self, embed_dims=1024, out_dims=4096, num_levels=3):
+        super().__init__()
+        self.mlvl_fuse = MLVLFuseModule(input_dims=embed_dims, embed_dims=embed_dims, num_levels=num_levels,
+                                        num_fuse=5)
+        strids = [14 / 8, 14 / 4, 14 / 2, 14]
+        assert len(strids) == num_levels
+        bbox_roi_extractor = dict(roi_layer=dict(type='RoIAlign', output_size=14, sampling_ratio=2),
+                                  out_channels=embed_dims, embed_dims=embed_dims, fuse_level=num_levels,
+                                  featmap_strides=strids, out_dims=out_dims)
+        self.roi_align = MlvlRoIExtractor(**bbox_roi_extractor)
+
+    def prepare(self):
+        self.mlvl_fuse.prepare()
+        self.roi_align.prepare()
+
+    @torch.no_grad()
+    def forward(self, mlvl_feats, bboxes):
+        """mlvl_feats: list[4] of [B, P*P, C] (token form, as spi_llava.py:80-82 passes) or
+        [B, C, P, P]; bboxes: list[B] of [n_i, 4] normalised xyxy.  Returns list[B] of
+        [n_i, out_dims] bf16."""
+        toks = []
+        for f in mlvl_feats:
+            if f.dim() == 4:                                   # NCHW -> token form
+                b, c, h, w = f.shape
+                f = f.permute(0, 2, 3, 1).reshape(b, h * w, c)
+            if f.dtype != torch.bfloat16:
+                f = f.to(torch.bfloat16)
+            toks.append(f)
+        P = int(math.isqrt(toks[0].shape[1]))
+        assert P * P == toks[0].shape[1], "level features must be square token grids"
+        n = len(toks)
+        sizes = [P * 2 ** l for l in range(n)][::-1]          # level 0 (shallowest ViT layer) is finest
+        maps, affs = self.mlvl_fuse(toks, P, sizes)
+        return self.roi_align(maps, bboxes, affines=affs, image_size=14 * P)

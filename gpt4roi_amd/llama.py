@@ -1,0 +1,113 @@
+"""LLaMA decoder stack (prefill + KV-cache decode) on the gfx950 kernels.
+
+Carries the arithmetic the reference delegates to HF `LlamaModel.forward(inputs_embeds=...)` at
+/root/reference/gpt4roi/models/spi_llava.py:198-205 and the `lm_head` of
+llava/model/llava.py:235-238: RMSNorm -> fused QKV GEMM -> rotary (rotate_half) + KV-cache append
+-> causal attention -> O GEMM (+residual) -> RMSNorm -> fused gate|up GEMM -> SiLU*up -> down GEMM
+(+residual); final RMSNorm; logits.  Weights from an HF-named state dict
+(`model.layers.N.self_attn.q_proj.weight`, ..., `lm_head.weight`).  One KV cache per batch element,
+sized once for `max_positions` (288 GB of HBM make whole-sequence residency the default).
+"""
+import math
+
+import torch
+
+from . import kernels as K
+
+
+class LlamaDecoder:
+    def __init__(self, state_dict, heads, eps=1e-6, theta=10000.0, max_positions=2048, device="cuda",
+                 num_layers=None, max_batch=1):
+        sd = state_dict
+        bf = torch.bfloat16
+
+        def g(name, dtype=bf):
+            return sd[name].detach().to(device=device, dtype=dtype).contiguous()
+
+        self.embed = g("model.embed_tokens.weight")
+        self.vocab, self.hidden = self.embed.shape
+        self.heads, self.eps = heads, eps
+        self.head_dim = self.hidden // heads
+        if num_layers is None:
+            num_layers = sum(1 for k in sd if k.endswith("input_layernorm.weight"))
+        self.layers = []
+        for i in range(num_layers):
+            p = f"model.layers.{i}."
+            self.layers.append(dict(
+                n1=g(p + "input_layernorm.weight", torch.float32),
+                wqkv=torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
+                                g(p + "self_attn.v_proj.weight")], 0).contiguous(),
+                wo=g(p + "self_attn.o_proj.weight"),
+                n2=g(p + "post_attention_layernorm.weight", torch.float32),
+                wgu=torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")], 0).contiguous(),
+                wd=g(p + "mlp.down_proj.weight")))
+        self.inter = self.layers[0]['wd'].size(1) if self.layers else 0
+        self.norm = g("model.norm.weight", torch.float32)
+        self.lm_head = g("lm_head.weight")
+        inv = 1.0 / (theta ** (torch.arange(0, self.head_dim, 2, dtype=torch.float32) / self.head_dim))
+        ang = torch.arange(max_positions, dtype=torch.float32)[:, None] * inv[None, :]
+        self.cos, self.sin = ang.cos().to(device).contiguous(), ang.sin().to(device).contiguous()
+        self.max_positions = max_positions
+        self.device = device
+        self._alloc_cache(max_batch)
+
+    def _alloc_cache(self, batch):
+        L = len(self.layers)
+        self.kc = torch.zeros((L, batch, self.max_positions, self.hidden), dtype=torch.bfloat16, device=self.device)
+        self.vc = torch.zeros_like(self.kc)
+        self.pos = 0
+
+    def reset(self, batch=1):
+        if self.kc.size(1) < batch:
+            self._alloc_cache(batch)
+        self.pos = 0
+
+    @torch.no_grad()
+    def forward(self, inputs_embeds, all_logits=True, return_hidden=False):
+        """inputs_embeds [B,T,C] bf16, appended at the current cache position.  Returns logits fp32
+        [B,T,V] (all_logits) or [B,1,V] (last position only)."""
+        B, T, C = inputs_embeds.shape
+        assert self.pos + T <= self.max_positions and B <= self.kc.size(1)
+        H, D, pos0 = self.heads, self.head_dim, self.pos
+        x = inputs_embeds.reshape(B * T, C)
+        if x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)
+        x = x.contiguous()
+        scale = 1.0 / math.sqrt(D)
+        q = torch.empty((B, T, C), dtype=torch.bfloat16, device=x.device)
+        for li, L in enumerate(self.layers):
+            h = K.rmsnorm(x, L['n1'], self.eps)
+            qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
+            for b in range(B):
+                K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, pos0)
+            a = K.flash_attn(q, self.kc[li, :B, :pos0 + T], self.vc[li, :B, :pos0 + T], H, scale, True)
+            x = K.gemm(a.view(B * T, C), L['wo'], residual=x)
+            h = K.rmsnorm(x, L['n2'], self.eps)
+            gu = K.gemm(h, L['wgu'])
+            f = K.swiglu(gu)
+            x = K.gemm(f, L['wd'], residual=x)
+        self.pos = pos0 + T
+        xn = K.rmsnorm(x, self.norm, self.eps).view(B, T, C)
+        if return_hidden:
+            return xn
+        if not all_logits:
+            xn = xn[:, -1:, :].contiguous()
+        logits = K.gemm(xn.reshape(-1, C), self.lm_head, out_dtype=torch.float32)
+        return logits.view(B, -1, self.vocab)
+
+    @torch.no_grad()
+    def greedy(self, inputs_embeds, max_new_tokens, stop_ids=()):
+        """generate(do_sample=False) for batch 1: prefill, then one token per step from the KV cache
+        (llava/model/llava.py:263-283 feeds only the last token after step 0)."""
+        assert inputs_embeds.size(0) == 1
+        self.reset(1)
+        logits = self.forward(inputs_embeds, all_logits=False)
+        out = []
+        for _ in range(max_new_tokens):
+            nxt = K.argmax_rows(logits.view(1, -1))
+            tok = int(nxt.item())
+            out.append(tok)
+            if tok in stop_ids:
+                break
+            logits = self.forward(self.embed[nxt].view(1, 1, -1), all_logits=False)
+        return out

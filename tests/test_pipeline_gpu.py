@@ -1,0 +1,227 @@
+"""GPU: stage-by-stage and end-to-end parity of the HIP pipeline (gpt4roi_amd/{vit,layers,llama,
+spi_llava}.py, everything through the C ABI) against the CPU oracles on the same seeded inputs.
+
+Tolerances: the pipeline stores bf16 between kernels, the reference semantics are fp32.
+  * vs the oracle run with bf16 rounding at the pipeline's storage points ("emulate"): tight --
+    this is the check that catches kernel bugs;
+  * vs the pure-fp32 oracle / the reference-code fixture: loose (bf16 noise through ~40 layers).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import spi_oracle as S  # noqa: E402
+from oracle import transformer_oracle as T  # noqa: E402
+
+if torch.cuda.is_available():
+    from gpt4roi_amd import kernels as K
+    from gpt4roi_amd import synthetic as syn
+    from gpt4roi_amd.layers import MLVLROIQueryModule
+    from gpt4roi_amd.llama import LlamaDecoder
+    from gpt4roi_amd.spi_llava import SPILlavaLlamaModel, SPILlavaMPTForCausalLM
+    from gpt4roi_amd.vit import ClipVisionTower
+
+DEV = "cuda"
+
+
+def relerr(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return ((got - want).abs().max() / want.abs().max().clamp_min(1e-6)).item()
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+# ------------------------------------------------------------------------------------------ region module
+def test_spi_module_against_reference_code_fixture(golden_dir):
+    """fixture = output of the reference's own gpt4roi/models/layers.py (fp32, 224^2, embed 512)."""
+    z = np.load(os.path.join(golden_dir, "spi_module_ref_c512.npz"))
+    C, B, P = int(z["embed_dims"]), int(z["B"]), int(z["P"])
+    m = MLVLROIQueryModule(embed_dims=C, out_dims=4096, num_levels=4)
+    m.load_state_dict(S.synthetic_state(m, int(z["wseed"])))
+    m.to(DEV)
+    feats, boxes = S.synthetic_inputs(int(z["iseed"]), B, P, C, [int(n) for n in z["n_rois"]])
+    out = torch.cat(m([f.to(DEV) for f in feats], [b.to(DEV) for b in boxes]), 0)
+    want = torch.from_numpy(z["out"])
+    e = relerr(out, want)
+    print("spi module vs reference-code fixture: rel-to-max err", e)
+    assert e < 4e-2, e
+    # and against the restated oracle with bf16 rounding points (same weights, bf16-rounded inputs)
+    o = S.MLVLROIQueryOracle(embed_dims=C, P=P)
+    o.load_state_dict(S.synthetic_state(o, int(z["wseed"])))
+    with torch.no_grad():
+        emu = torch.cat(o([bf(f) for f in feats], boxes, emulate=True), 0)
+    e2 = relerr(out, emu)
+    print("spi module vs bf16-emulating oracle: rel-to-max err", e2)
+    assert e2 < 1.5e-2, e2
+
+
+def test_spi_module_intermediates_p8():
+    """Smaller grid (P=8), two images, per-stage comparison against the emulating oracle."""
+    C, P, B = 512, 8, 2
+    m = MLVLROIQueryModule(embed_dims=C, out_dims=512, num_levels=4)
+    o = S.MLVLROIQueryOracle(embed_dims=C, P=P)
+    o.roi_align.updims = torch.nn.Linear(1024, 512)
+    sd = S.synthetic_state(o, 5)
+    o.load_state_dict(sd)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    feats, boxes = S.synthetic_inputs(6, B, P, C, [4, 1])
+    with torch.no_grad():
+        want, inter = o([bf(f) for f in feats], boxes, emulate=True, return_intermediates=True)
+    toks = [f.to(DEV).to(torch.bfloat16) for f in feats]
+    sizes = [P * 2 ** l for l in range(4)][::-1]
+    maps, affs = m.mlvl_fuse(toks, P, sizes)
+    for l in range(4):
+        y = torch.relu(maps[l].float() * affs[l][:, 0][:, None, None, :] + affs[l][:, 1][:, None, None, :])
+        e = relerr(y.permute(0, 3, 1, 2), inter["fused"][l])
+        assert e < 2e-2, (l, e)
+    out = m(toks, [b.to(DEV) for b in boxes])
+    assert [x.shape for x in out] == [(4, 512), (1, 512)]
+    assert relerr(torch.cat(out), torch.cat(want)) < 1.5e-2
+    # no regions in any image -> empty outputs, no launch (layers.py:314-317 keeps the graph alive)
+    empty = m(toks, [torch.zeros(0, 4, device=DEV), torch.zeros(0, 4, device=DEV)])
+    assert [x.shape for x in empty] == [(0, 512), (0, 512)]
+
+
+# ------------------------------------------------------------------------------------------ ViT
+def _mini_vit(hidden=256, heads=4, layers=12, image=112):
+    sd = syn.vit_state(hidden, 4 * hidden, layers, image, seed=3)
+    return sd, ClipVisionTower(sd, heads=heads, device=DEV)
+
+
+def test_vit_hidden_states():
+    sd, tower = _mini_vit()
+    assert tower.level_indices == [2, 5, 8, 11] and tower.image_feature_index == 11 and len(tower.layers) == 11
+    img = torch.randn(2, 3, 112, 112, generator=torch.Generator().manual_seed(4))
+    keep = tower.forward(img.to(DEV))
+    sdb = {k: bf(v) for k, v in sd.items()}
+    emu = T.clip_vit_hidden_states(sdb, img, heads=4, n_layers=11, emulate=True)
+    ref = T.clip_vit_hidden_states(sd, img, heads=4, n_layers=11)
+    for i in tower.level_indices:
+        e_emu, e_ref = relerr(keep[i], emu[i]), relerr(keep[i], ref[i])
+        print(f"vit hs[{i}] vs emulate {e_emu:.4f} vs fp32 {e_ref:.4f}")
+        assert e_emu < 2e-2 and e_ref < 6e-2
+    img_feat, lv = tower.select(keep)
+    assert img_feat.shape == (2, 64, 256) and len(lv) == 4
+
+
+# ------------------------------------------------------------------------------------------ LLaMA
+def _mini_llama(hidden=512, heads=4, inter=1408, layers=4, vocab=1000):
+    sd = syn.llama_state(hidden, inter, layers, vocab, seed=5)
+    return sd, LlamaDecoder(sd, heads=heads, max_positions=256, device=DEV)
+
+
+def test_llama_prefill_decode_and_greedy_ids():
+    sd, dec = _mini_llama()
+    sdb = {k: bf(v) for k, v in sd.items()}
+    ids = torch.randint(0, 1000, (1, 37), generator=torch.Generator().manual_seed(6))
+    emb = bf(sd["model.embed_tokens.weight"])[ids]
+    dec.reset(1)
+    logits = dec.forward(emb.to(DEV).to(torch.bfloat16))
+    h, cache = T.llama_forward(sdb, emb, heads=4, emulate=True)
+    want = T.lm_logits(sdb, h, emulate=True)
+    e = relerr(logits, want)
+    print("llama prefill logits vs emulate", e)
+    assert logits.shape == (1, 37, 1000) and e < 2e-2
+    # cached single-token step
+    nxt = torch.tensor([[123]])
+    l2 = dec.forward(bf(sd["model.embed_tokens.weight"])[nxt].to(DEV).to(torch.bfloat16))
+    h2, _ = T.llama_forward(sdb, bf(sd["model.embed_tokens.weight"])[nxt], heads=4, kv_cache=cache, pos0=37, emulate=True)
+    assert relerr(l2, T.lm_logits(sdb, h2, emulate=True)) < 2e-2
+    # greedy decode: identical token ids (north_star) -- margins reported when a near-tie flips
+    got = dec.greedy(emb.to(DEV).to(torch.bfloat16), 12)
+    embed_fn = lambda t: bf(sd["model.embed_tokens.weight"])[t]
+    want_ids, trace = T.greedy_decode(sdb, emb, embed_fn, heads=4, n_new=12, emulate=True)
+    if got != want_ids:
+        k = next(i for i, (a, b) in enumerate(zip(got, want_ids)) if a != b)
+        top2 = trace[k].topk(2).values
+        pytest.fail(f"greedy ids diverge at step {k}: {got} vs {want_ids}; oracle top-2 margin {float(top2[0]-top2[1]):.2e}")
+
+
+def test_llama_batch2_matches_batch1():
+    sd, dec = _mini_llama(layers=2)
+    dec.reset(2)
+    emb = torch.randn(2, 20, 512, generator=torch.Generator().manual_seed(7)).to(DEV).to(torch.bfloat16)
+    both = dec.forward(emb)
+    dec.reset(1)
+    one = dec.forward(emb[1:2])
+    assert relerr(both[1], one[0]) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ end to end
+def test_end_to_end_embeds_logits_and_greedy_ids():
+    """ViT -> levels -> region module -> projector -> splice -> LLaMA, mini widths, P = 8 (112^2),
+    forward(input_ids, images, bboxes) signature of spi_llava.py:23-36."""
+    H, P, image = 512, 8, 112
+    ids = syn.token_ids(vocab_base=990)
+    vsd = syn.vit_state(H, 4 * H, 12, image, seed=8)
+    lsd = syn.llama_state(512, 1408, 3, ids.vocab, seed=9)
+    tower = ClipVisionTower(vsd, heads=8, device=DEV)
+    dec = LlamaDecoder(lsd, heads=4, max_positions=256, device=DEV)
+    model = SPILlavaLlamaModel(tower, dec, ids, embed_dims=H)
+    orc = S.MLVLROIQueryOracle(embed_dims=H, P=P)
+    orc.roi_align.updims = torch.nn.Linear(1024, 512)
+    spi_sd = S.synthetic_state(orc, 10)
+    orc.load_state_dict(spi_sd)
+    model.spi_module.load_state_dict(spi_sd)
+    g = torch.Generator().manual_seed(11)
+    pw, pb = torch.randn(512, H, generator=g) / H ** 0.5, torch.randn(512, generator=g) * 0.05
+    with torch.no_grad():
+        model.mm_projector.weight.copy_(pw)
+        model.mm_projector.bias.copy_(pb)
+    lm = SPILlavaMPTForCausalLM(model)
+    img = torch.randn(1, 3, image, image, generator=g)
+    boxes = [syn.boxes(3, g)]
+    prompt = syn.prompt_ids(ids, P, 3, g, sys_len=6, question_len=5, vocab_base=990)[None]
+    out = lm(input_ids=prompt.to(DEV), images=img.to(DEV), bboxes=[b.to(DEV) for b in boxes])
+    model.check_status()
+    # ---- oracle pipeline (bf16 rounding points) ----
+    vb = {k: bf(v) for k, v in vsd.items()}
+    lb = {k: bf(v) for k, v in lsd.items()}
+    hs = T.clip_vit_hidden_states(vb, img, heads=8, n_layers=11, emulate=True)
+    img_feat, lv = T.select_spi_levels(hs + [hs[-1]], -2, 4)   # pad: oracle ran 11 of the 12 layers
+    with torch.no_grad():
+        spi = orc(lv, boxes, emulate=True)
+    proj = bf(bf(img_feat) @ bf(pw).t() + bf(pb))
+    emb = bf(lsd["model.embed_tokens.weight"])[prompt]
+    spliced = S.splice(prompt, emb, proj, spi, ids.im_start_token, ids.im_end_token, ids.bbox_token)
+    got_emb = model.embed_inputs(prompt.to(DEV), img.to(DEV), [b.to(DEV) for b in boxes])
+    e_emb = relerr(got_emb, spliced)
+    print("inputs_embeds vs oracle", e_emb)
+    assert e_emb < 2e-2
+    h, _ = T.llama_forward(lb, spliced, heads=4, emulate=True)
+    want = T.lm_logits(lb, h, emulate=True)
+    e_log = relerr(out.logits, want)
+    print("end-to-end logits vs oracle", e_log)
+    assert out.logits.shape == (1, prompt.size(1), ids.vocab) and e_log < 3e-2
+    # greedy decode from the SAME spliced embeddings on both sides
+    got_ids = dec.greedy(spliced.to(DEV).to(torch.bfloat16), 8)
+    want_ids, trace = T.greedy_decode(lb, spliced, lambda t: bf(lsd["model.embed_tokens.weight"])[t], heads=4,
+                                      n_new=8, emulate=True)
+    if got_ids != want_ids:
+        k = next(i for i, (a, b) in enumerate(zip(got_ids, want_ids)) if a != b)
+        top2 = trace[k].topk(2).values
+        pytest.fail(f"greedy ids diverge at step {k}: {got_ids} vs {want_ids}; margin {float(top2[0]-top2[1]):.2e}")
+    gen = lm.generate(prompt.to(DEV), images=img.to(DEV), bboxes=[b.to(DEV) for b in boxes], max_new_tokens=4)
+    assert len(gen) == 4
+
+
+def test_malformed_prompt_raises_like_the_reference():
+    ids = syn.token_ids(vocab_base=990)
+    vsd = syn.vit_state(256, 1024, 12, 112, seed=8)
+    lsd = syn.llama_state(512, 1408, 1, ids.vocab, seed=9)
+    model = SPILlavaLlamaModel(ClipVisionTower(vsd, heads=4, device=DEV), LlamaDecoder(lsd, heads=4, device=DEV,
+                               max_positions=128), ids, embed_dims=256)
+    g = torch.Generator().manual_seed(12)
+    prompt = syn.prompt_ids(ids, 8, 1, g, sys_len=3, question_len=2, vocab_base=990)[None].clone()
+    prompt[0, (prompt[0] == ids.im_end_token).nonzero()[0, 0]] = 5       # drop <im_end>
+    img = torch.randn(1, 3, 112, 112, generator=g).to(DEV)
+    model.embed_inputs(prompt.to(DEV), img, None)
+    with pytest.raises(ValueError):
+        model.check_status()
