@@ -343,21 +343,29 @@ __global__ __launch_bounds__(256) void splice_embed_kernel(const long* __restric
     }
     __syncthreads();
   }
-  // structural checks (one thread; T is ~1-2k)
+  // structural checks, in parallel over the tokens
+  __shared__ int first_sh, flags_sh;
   if (tid == 0) {
-    int st = 0;
+    first_sh = -1;
+    flags_sh = 0;
+  }
+  __syncthreads();
+  for (int t = tid; t < T; t += 256)
+    if (prank[t] == 0) first_sh = t;  // rank 0 occurs at most once
+  __syncthreads();
+  const int first = first_sh;
+  for (int t = tid; t < T; t += 256)
+    if (prank[t] >= 0 && t - prank[t] != first) atomicOr(&flags_sh, 16);  // patch run not contiguous
+  __syncthreads();
+  if (tid == 0) {
+    int st = flags_sh;
     const int np = carry[0], nb = carry[1];
     if (np != 0 && np != n_patch) st |= 1;                       // wrong number of patch tokens
     const int want = spi_offset ? spi_offset[b + 1] - spi_offset[b] : 0;
     if (nb != want) st |= 2;                                       // #<bbox> != #regions
     if (np > 0) {
-      int first = -1;
-      for (int t = 0; t < T; ++t)
-        if (prank[t] == 0) { first = t; break; }
       if (first < 1 || row[first - 1] != im_start_id) st |= 4;    // <im_start> must precede
       if (first + n_patch >= T || row[first + n_patch] != im_end_id) st |= 8;  // <im_end> must follow
-      for (int t = first; t < first + n_patch && t < T; ++t)
-        if (prank[t] != t - first) { st |= 16; break; }           // run must be contiguous
     }
     status[b] = st;
   }

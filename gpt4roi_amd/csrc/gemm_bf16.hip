@@ -43,9 +43,19 @@ struct GemmArgs {
   int splits, tiles_per_split;  // K tiles (of 64) per z slice
   int H, Wd, Cin, groups;      // AMODE 1 geometry
   int tiles_m, tiles_n;
+  int dbg;  // ablation probe (tools only): 1 = skip the loads after the first tile, 2 = skip the MFMAs
 };
 
 constexpr int BK = 64;
+
+// waves per SIMD the kernel is allowed to assume = workgroups that fit the 160 KB LDS (<= 3)
+constexpr int gemm_waves_per_eu(int bm, int bn, int nw, int stages) {
+  int blocks = (160 * 1024) / (stages * (bm + bn) * BK * 2);
+  if (blocks > 3) blocks = 3;
+  if (blocks < 1) blocks = 1;
+  int w = blocks * nw / 4;
+  return w > 4 ? 4 : (w < 1 ? 1 : w);
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == 1) return v > 0.f ? v : 0.f;
@@ -54,8 +64,14 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 3 : 4)) void gemm_bf16_nt_kernel(GemmArgs p) {
+// STAGES == 2: double buffer, one __syncthreads per K tile, latency hidden by 2-3 co-resident
+//              workgroups per CU.
+// STAGES >= 3: ring of LDS buffers, STAGES-1 tiles of LDS-DMA in flight, counted s_waitcnt vmcnt
+//              (never 0 in steady state) + raw s_barrier, fragments double-buffered in registers;
+//              one workgroup per CU owns most of the 160 KB LDS.
+template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_eu(BM, BN, WM * WN, STAGES))
+void gemm_bf16_nt_kernel(GemmArgs p) {
   constexpr int NW = WM * WN;
   constexpr int NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
@@ -64,7 +80,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 3 : 4)) void gemm_bf16
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE_BYTES
+  static_assert(STAGES == 2 || GLDS, "the deep pipeline needs LDS-DMA staging");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES * STAGE_BYTES
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -184,35 +201,86 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? 3 : 4)) void gemm_bf16
   auto compute = [&](int buf) {
     const char* sa = smem + buf * STAGE_BYTES;
     const char* sb = sa + A_BYTES;
+    if constexpr (STAGES == 2) {
+      // 2-3 co-resident workgroups per CU: let the compiler interleave the 4 reads and 4 MFMAs of
+      // each k-step (few VGPRs -> more waves).  Measured on MI355X: faster end to end than
+      // issuing all 16 reads first (tools/gemm_ablate.py; DESIGN.md "GEMM experiments").
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int slot = ((kk * 2 + fhi) ^ fsw) << 4;
-      bf16x8 af[TM], wf[TN];
+      for (int kk = 0; kk < 4; ++kk) {
+        const int slot = ((kk * 2 + fhi) ^ fsw) << 4;
+        bf16x8 af[TM], wf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * 128 + slot);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * 128 + slot);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * 128 + slot);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * 128 + slot);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // one workgroup per CU: request every fragment of the K tile up front, then one MFMA burst
+      bf16x8 af[4][TM], wf[4][TN];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int slot = ((kk * 2 + fhi) ^ fsw) << 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[kk][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * 128 + slot);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          wf[kk][j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * 128 + slot);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the burst
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
     }
   };
 
-  if (t_begin < t_end) {
-    stage(t_begin, 0);
-    __syncthreads();  // drains the LDS-DMA queue (vmcnt(0)) and publishes the tile
-    int cur = 0;
-    for (int t = t_begin; t < t_end - 1; ++t) {
-      stage(t + 1, cur ^ 1);
+  if constexpr (STAGES == 2) {
+    if (t_begin < t_end) {
+      stage(t_begin, 0);
+      __syncthreads();  // drains the LDS-DMA queue (vmcnt(0)) and publishes the tile
+      int cur = 0;
+      for (int t = t_begin; t < t_end - 1; ++t) {
+        if (p.dbg != 1) stage(t + 1, cur ^ 1);
+        if (p.dbg != 2) compute(cur);
+        __syncthreads();
+        cur ^= 1;
+      }
       compute(cur);
-      __syncthreads();
-      cur ^= 1;
     }
-    compute(cur);
+  } else {
+    constexpr int NLD = NA + NB;  // LDS-DMA instructions per thread per tile
+    const int nt = t_end - t_begin;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (s < nt) stage(t_begin + s, s);
+    int rd = 0, wr = STAGES - 1;
+    for (int i = 0; i < nt; ++i) {
+      // tile i must have landed; up to STAGES-2 younger tiles stay in flight across the barrier
+      const int ahead = nt - 1 - i;
+      if (STAGES >= 4 && ahead >= 2)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+      else if (ahead >= 1)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // everyone's tile i is in LDS; everyone is done reading tile i-1
+      asm volatile("" ::: "memory");
+      if (i + STAGES - 1 < nt && p.dbg != 1) stage(t_begin + i + STAGES - 1, wr);
+      if (p.dbg != 2 || i + 1 == nt) compute(rd);
+      rd = rd + 1 == STAGES ? 0 : rd + 1;
+      wr = wr + 1 == STAGES ? 0 : wr + 1;
+    }
   }
 
   // ---- epilogue.  D[i = n][j = m]: m = lane & 31, n = 8*(r>>2) + 4*(lane>>5) + (r&3) ----
@@ -368,12 +436,12 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restr
   }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS>
+template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS, int STAGES = 2>
 int launch_tile(GemmArgs& p, hipStream_t stream) {
   p.tiles_m = g4r_ceil_div(p.M, BM);
   p.tiles_n = g4r_ceil_div(p.N, BN);
-  const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
-  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, AMODE, GLDS>;
+  const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
+  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, AMODE, GLDS, STAGES>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -401,13 +469,25 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 1: return launch_tile<256, 128, 4, 2, AMODE, true>(p, stream);
     case 2: return launch_tile<128, 128, 2, 2, AMODE, false>(p, stream);  // register-staged A/B probe
     case 4: return launch_tile<64, 128, 1, 4, AMODE, true>(p, stream);
+    case 5: return launch_tile<128, 128, 2, 2, AMODE, true, 3>(p, stream);   // 96 KB ring
+    case 6: return launch_tile<128, 128, 2, 2, AMODE, true, 4>(p, stream);   // 128 KB ring
+    case 7: return launch_tile<128, 128, 2, 4, AMODE, true, 4>(p, stream);   // 8 waves, 64x32 wave tiles
+    case 8: return launch_tile<256, 128, 4, 2, AMODE, true, 3>(p, stream);   // 144 KB ring, 8 waves
+    case 9: return launch_tile<256, 256, 2, 4, AMODE, true, 2>(p, stream);   // 128 KB, wave tile 128x64
+    case 10: return launch_tile<128, 128, 2, 4, AMODE, true, 2>(p, stream);  // 8 waves x (64x32), 2 wg/CU
+    case 11: return launch_tile<128, 64, 2, 2, AMODE, true, 2>(p, stream);   // 48 KB: 3 wg/CU
     default: return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");
   }
 }
 
 }  // namespace
 
+static int g_gemm_dbg = 0;
+
 extern "C" {
+
+// tools/ only: ablation switch for the GEMM main loop (0 = normal).  Not declared in include/.
+void g4r_gemm_debug_mode(int mode) { g_gemm_dbg = mode; }
 
 // See include/g4r_kernels.h for the contract.
 int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, const void* residual,
@@ -434,7 +514,7 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.ws = workspace; p.bias = bias;
   p.residual = (const bf16_t*)residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
-  p.act = act; p.out_f32 = out_f32;
+  p.act = act; p.out_f32 = out_f32; p.dbg = g_gemm_dbg;
   const int nt = K / BK;
   if (splits > nt) splits = nt;
   p.tiles_per_split = g4r_ceil_div(nt, splits);

@@ -16,164 +16,185 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// One wave per row.  cols % 8 == 0.  y = (x - mean) * rstd * gamma + beta   (eps inside sqrt)
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+constexpr int NORM_MAXV = 4;  // 16-B vectors per thread: rows up to 256*4*8 = 8192 elements
+
+// One workgroup per row; the row lives in registers (single HBM read).  cols % 8 == 0.
+//   y = (x - mean) * rstd * gamma + beta   (biased variance, eps inside the sqrt)
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const bf16_t* __restrict__ x,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              bf16_t* __restrict__ y, int rows, int cols,
                                                              long ldx, long ldy, float eps, int relu_in) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int lane = threadIdx.x & 63;
+  __shared__ float red[4];
+  const int row = blockIdx.x;
   const bf16_t* xr = x + (size_t)row * ldx;
   const int nvec = cols >> 3;
-  float s = 0.f, s2 = 0.f;
-  for (int v = lane; v < nvec; v += 64) {
-    const uint4v r = *reinterpret_cast<const uint4v*>(xr + v * 8);
-    float f[8] = {bf16lo(r.x), bf16hi(r.x), bf16lo(r.y), bf16hi(r.y),
-                  bf16lo(r.z), bf16hi(r.z), bf16lo(r.w), bf16hi(r.w)};
+  float f[NORM_MAXV][8];
+  float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (relu_in) f[k] = fmaxf(f[k], 0.f);
-      s += f[k];
+  for (int i = 0; i < NORM_MAXV; ++i) {
+    const int v = threadIdx.x + i * 256;
+    if (v < nvec) {
+      const uint4v r = *reinterpret_cast<const uint4v*>(xr + v * 8);
+      f[i][0] = bf16lo(r.x); f[i][1] = bf16hi(r.x); f[i][2] = bf16lo(r.y); f[i][3] = bf16hi(r.y);
+      f[i][4] = bf16lo(r.z); f[i][5] = bf16hi(r.z); f[i][6] = bf16lo(r.w); f[i][7] = bf16hi(r.w);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (relu_in) f[i][k] = fmaxf(f[i][k], 0.f);
+        s += f[i][k];
+      }
     }
   }
-  s = wave_sum(s);
-  const float mean = s / (float)cols;
-  for (int v = lane; v < nvec; v += 64) {
-    const uint4v r = *reinterpret_cast<const uint4v*>(xr + v * 8);
-    float f[8] = {bf16lo(r.x), bf16hi(r.x), bf16lo(r.y), bf16hi(r.y),
-                  bf16lo(r.z), bf16hi(r.z), bf16lo(r.w), bf16hi(r.w)};
+  const float mean = block_sum(s, red) / (float)cols;
+  float s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (relu_in) f[k] = fmaxf(f[k], 0.f);
-      const float d = f[k] - mean;
-      s2 += d * d;
+  for (int i = 0; i < NORM_MAXV; ++i)
+    if (threadIdx.x + i * 256 < nvec) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float d = f[i][k] - mean;
+        s2 += d * d;
+      }
     }
-  }
-  s2 = wave_sum(s2);
-  const float rstd = rsqrtf(s2 / (float)cols + eps);
+  const float rstd = rsqrtf(block_sum(s2, red) / (float)cols + eps);
   bf16_t* yr = y + (size_t)row * ldy;
-  for (int v = lane; v < nvec; v += 64) {
-    const uint4v r = *reinterpret_cast<const uint4v*>(xr + v * 8);
-    float f[8] = {bf16lo(r.x), bf16hi(r.x), bf16lo(r.y), bf16hi(r.y),
-                  bf16lo(r.z), bf16hi(r.z), bf16lo(r.w), bf16hi(r.w)};
-    const float4v g0 = *reinterpret_cast<const float4v*>(gamma + v * 8);
-    const float4v g1 = *reinterpret_cast<const float4v*>(gamma + v * 8 + 4);
-    const float4v b0 = *reinterpret_cast<const float4v*>(beta + v * 8);
-    const float4v b1 = *reinterpret_cast<const float4v*>(beta + v * 8 + 4);
-    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-    const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    float o[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (relu_in) f[k] = fmaxf(f[k], 0.f);
-      o[k] = (f[k] - mean) * rstd * g[k] + b[k];
+  for (int i = 0; i < NORM_MAXV; ++i) {
+    const int v = threadIdx.x + i * 256;
+    if (v < nvec) {
+      const float4v g0 = *reinterpret_cast<const float4v*>(gamma + v * 8);
+      const float4v g1 = *reinterpret_cast<const float4v*>(gamma + v * 8 + 4);
+      const float4v b0 = *reinterpret_cast<const float4v*>(beta + v * 8);
+      const float4v b1 = *reinterpret_cast<const float4v*>(beta + v * 8 + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (f[i][k] - mean) * rstd * g[k] + b[k];
+      uint4v w;
+      w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
+      w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+      *reinterpret_cast<uint4v*>(yr + v * 8) = w;
     }
-    uint4v w;
-    w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
-    w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
-    *reinterpret_cast<uint4v*>(yr + v * 8) = w;
   }
 }
 
-// One wave per row.  y = x * rsqrt(mean(x^2) + eps) * gamma   (HF LlamaRMSNorm: the normalised
-// value is rounded to the storage dtype BEFORE the gamma multiply).
+// One workgroup per row.  y = x * rsqrt(mean(x^2) + eps) * gamma   (HF LlamaRMSNorm: the
+// normalised value is rounded to the storage dtype BEFORE the gamma multiply).
 __global__ __launch_bounds__(256) void rmsnorm_bf16_kernel(const bf16_t* __restrict__ x,
                                                            const float* __restrict__ gamma,
                                                            bf16_t* __restrict__ y, int rows, int cols,
                                                            long ldx, long ldy, float eps) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int lane = threadIdx.x & 63;
+  __shared__ float red[4];
+  const int row = blockIdx.x;
   const bf16_t* xr = x + (size_t)row * ldx;
   const int nvec = cols >> 3;
+  float f[NORM_MAXV][8];
   float s2 = 0.f;
-  for (int v = lane; v < nvec; v += 64) {
-    const uint4v r = *reinterpret_cast<const uint4v*>(xr + v * 8);
-    const float f[8] = {bf16lo(r.x), bf16hi(r.x), bf16lo(r.y), bf16hi(r.y),
-                        bf16lo(r.z), bf16hi(r.z), bf16lo(r.w), bf16hi(r.w)};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s2 += f[k] * f[k];
+  for (int i = 0; i < NORM_MAXV; ++i) {
+    const int v = threadIdx.x + i * 256;
+    if (v < nvec) {
+      const uint4v r = *reinterpret_cast<const uint4v*>(xr + v * 8);
+      f[i][0] = bf16lo(r.x); f[i][1] = bf16hi(r.x); f[i][2] = bf16lo(r.y); f[i][3] = bf16hi(r.y);
+      f[i][4] = bf16lo(r.z); f[i][5] = bf16hi(r.z); f[i][6] = bf16lo(r.w); f[i][7] = bf16hi(r.w);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s2 += f[i][k] * f[i][k];
+    }
   }
-  s2 = wave_sum(s2);
-  const float rstd = rsqrtf(s2 / (float)cols + eps);
+  const float rstd = rsqrtf(block_sum(s2, red) / (float)cols + eps);
   bf16_t* yr = y + (size_t)row * ldy;
-  for (int v = lane; v < nvec; v += 64) {
-    const uint4v r = *reinterpret_cast<const uint4v*>(xr + v * 8);
-    const float f[8] = {bf16lo(r.x), bf16hi(r.x), bf16lo(r.y), bf16hi(r.y),
-                        bf16lo(r.z), bf16hi(r.z), bf16lo(r.w), bf16hi(r.w)};
-    const float4v g0 = *reinterpret_cast<const float4v*>(gamma + v * 8);
-    const float4v g1 = *reinterpret_cast<const float4v*>(gamma + v * 8 + 4);
-    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-    float o[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = bf16_to_f32(f32_to_bf16(f[k] * rstd)) * g[k];
-    uint4v w;
-    w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
-    w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
-    *reinterpret_cast<uint4v*>(yr + v * 8) = w;
+  for (int i = 0; i < NORM_MAXV; ++i) {
+    const int v = threadIdx.x + i * 256;
+    if (v < nvec) {
+      const float4v g0 = *reinterpret_cast<const float4v*>(gamma + v * 8);
+      const float4v g1 = *reinterpret_cast<const float4v*>(gamma + v * 8 + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = bf16_to_f32(f32_to_bf16(f[i][k] * rstd)) * g[k];
+      uint4v w;
+      w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
+      w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+      *reinterpret_cast<uint4v*>(yr + v * 8) = w;
+    }
   }
 }
 
-// GroupNorm statistics over NHWC bf16: acc[b][g] += (sum, sumsq) in fp64 (few atomics per block).
-// grid = (pixel chunks, B); block = 256 threads; thread = one 8-channel vector, strided pixels.
+// GroupNorm statistics over NHWC bf16, two launches, no atomics:
+//   (1) partial[b][chunk][g] = (sum, sumsq) over a chunk of pixels   grid = (chunks, B)
+//   (2) reduce the chunks in fp64 and emit the per-(b, channel) affine y = a*x + s
+// block = 256 threads; thread = one 8-channel vector, strided pixels.
 __global__ __launch_bounds__(256) void gn_stats_nhwc_kernel(const bf16_t* __restrict__ x,
-                                                            double* __restrict__ acc, int HW, int C,
+                                                            float* __restrict__ partial, int HW, int C,
                                                             int G, int pix_per_block) {
-  extern __shared__ float red[];  // [2][256]
+  __shared__ float red[2][256];
   const int b = blockIdx.y;
-  const int nvec = C >> 3;             // vectors per pixel
+  const int nvec = C >> 3;             // vectors per pixel (divides 256)
   const int tid = threadIdx.x;
-  const int cv = tid % nvec;           // requires 256 % nvec == 0 or nvec >= 256 handled below
+  const int cv = tid % nvec;
   const int pl = tid / nvec;           // pixel lane
-  const int plc = 256 / nvec;          // pixel lanes per block (>=1)
+  const int plc = 256 / nvec;          // pixel lanes per block (>= 1)
   const int p0 = blockIdx.x * pix_per_block;
   int p1 = p0 + pix_per_block;
   if (p1 > HW) p1 = HW;
   float s = 0.f, s2 = 0.f;
-  if (pl < plc) {
-    const bf16_t* base = x + ((size_t)b * HW) * C + cv * 8;
-    for (int p = p0 + pl; p < p1; p += plc) {
-      const uint4v r = *reinterpret_cast<const uint4v*>(base + (size_t)p * C);
-      const float f[8] = {bf16lo(r.x), bf16hi(r.x), bf16lo(r.y), bf16hi(r.y),
-                          bf16lo(r.z), bf16hi(r.z), bf16lo(r.w), bf16hi(r.w)};
+  const bf16_t* base = x + ((size_t)b * HW) * C + cv * 8;
+  for (int p = p0 + pl; p < p1; p += plc) {
+    const uint4v r = *reinterpret_cast<const uint4v*>(base + (size_t)p * C);
+    const float f[8] = {bf16lo(r.x), bf16hi(r.x), bf16lo(r.y), bf16hi(r.y),
+                        bf16lo(r.z), bf16hi(r.z), bf16lo(r.w), bf16hi(r.w)};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        s += f[k];
-        s2 += f[k] * f[k];
-      }
+    for (int k = 0; k < 8; ++k) {
+      s += f[k];
+      s2 += f[k] * f[k];
     }
   }
-  red[tid] = s;
-  red[256 + tid] = s2;
+  red[0][tid] = s;
+  red[1][tid] = s2;
   __syncthreads();
   // group g owns vectors [g*vpg, (g+1)*vpg), vpg = (C/G)/8
   const int vpg = (C / G) >> 3;
   if (tid < G) {
-    double ts = 0.0, ts2 = 0.0;
+    float ts = 0.f, ts2 = 0.f;
     for (int l = 0; l < plc; ++l)
       for (int v = 0; v < vpg; ++v) {
         const int t = l * nvec + tid * vpg + v;
-        ts += (double)red[t];
-        ts2 += (double)red[256 + t];
+        ts += red[0][t];
+        ts2 += red[1][t];
       }
-    unsafeAtomicAdd(acc + ((size_t)b * G + tid) * 2, ts);
-    unsafeAtomicAdd(acc + ((size_t)b * G + tid) * 2 + 1, ts2);
+    float* dst = partial + (((size_t)b * gridDim.x + blockIdx.x) * G + tid) * 2;
+    dst[0] = ts;
+    dst[1] = ts2;
   }
 }
 
-// (sum, sumsq) -> per-(b, channel) affine  y = a*x + s  with a = gamma*rstd, s = beta - mean*a
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ acc,
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           float* __restrict__ scale_shift, int B, int C,
-                                                          int G, double count, float eps) {
+                                                          int G, int chunks, double count, float eps) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= B * C) return;
   const int b = i / C, c = i % C, g = c / (C / G);
-  const double mean = acc[((size_t)b * G + g) * 2] / count;
-  double var = acc[((size_t)b * G + g) * 2 + 1] / count - mean * mean;
+  double sum = 0.0, sq = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    const float* src = partial + (((size_t)b * chunks + k) * G + g) * 2;
+    sum += (double)src[0];
+    sq += (double)src[1];
+  }
+  const double mean = sum / count;
+  double var = sq / count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float a = gamma[c] * rstd;
@@ -190,7 +211,8 @@ int g4r_layernorm_bf16(const void* x, const float* gamma, const float* beta, voi
   G4R_REQUIRE(rows >= 0 && cols > 0 && (cols % 8) == 0, "layernorm: cols must be a multiple of 8");
   if (rows == 0) return G4R_OK;
   G4R_REQUIRE(x && gamma && beta && y && (ldx % 8) == 0 && (ldy % 8) == 0, "layernorm: bad pointer/stride");
-  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(g4r_ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+  G4R_REQUIRE(cols <= 256 * NORM_MAXV * 8, "layernorm: cols <= 8192");
+  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, gamma, beta, (bf16_t*)y, rows, cols, ldx, ldy, eps, relu_in);
   G4R_CHECK_LAUNCH("layernorm");
   return G4R_OK;
@@ -201,33 +223,31 @@ int g4r_rmsnorm_bf16(const void* x, const float* gamma, void* y, int rows, int c
   G4R_REQUIRE(rows >= 0 && cols > 0 && (cols % 8) == 0, "rmsnorm: cols must be a multiple of 8");
   if (rows == 0) return G4R_OK;
   G4R_REQUIRE(x && gamma && y && (ldx % 8) == 0 && (ldy % 8) == 0, "rmsnorm: bad pointer/stride");
-  hipLaunchKernelGGL(rmsnorm_bf16_kernel, dim3(g4r_ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+  G4R_REQUIRE(cols <= 256 * NORM_MAXV * 8, "rmsnorm: cols <= 8192");
+  hipLaunchKernelGGL(rmsnorm_bf16_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, gamma, (bf16_t*)y, rows, cols, ldx, ldy, eps);
   G4R_CHECK_LAUNCH("rmsnorm");
   return G4R_OK;
 }
 
-// acc: [B, G, 2] doubles (workspace, zeroed here); scale_shift: [B, 2, C] floats (a then s).
-int g4r_groupnorm_affine_nhwc_bf16(const void* x, const float* gamma, const float* beta, double* acc,
+// partial: workspace of B * G4R_GN_MAX_CHUNKS(256) * G * 2 floats; scale_shift: [B, 2, C] floats.
+int g4r_groupnorm_affine_nhwc_bf16(const void* x, const float* gamma, const float* beta, float* partial,
                                    float* scale_shift, int B, int HW, int C, int G, float eps,
                                    void* stream) {
   G4R_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && (C / G) % 8 == 0,
               "groupnorm: channels per group must be a multiple of 8");
   const int nvec = C / 8;
   G4R_REQUIRE(nvec <= 256 && 256 % nvec == 0 && G <= 256, "groupnorm: C/8 must divide 256");
-  G4R_REQUIRE(x && gamma && beta && acc && scale_shift, "groupnorm: null pointer");
-  hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * 2 * B * G, (hipStream_t)stream);
-  if (e != hipSuccess) return g4r_note_hip_error(e, "groupnorm: memset");
-  // ~2048 workgroups overall
-  int chunks = g4r_ceil_div(2048, B);
+  G4R_REQUIRE(x && gamma && beta && partial && scale_shift, "groupnorm: null pointer");
+  int chunks = 256;                       // x B workgroups, each streaming >= 32 pixels
   int ppb = g4r_ceil_div(HW, chunks);
-  if (ppb < 16) ppb = 16;
+  if (ppb < 32) ppb = 32;
   chunks = g4r_ceil_div(HW, ppb);
-  hipLaunchKernelGGL(gn_stats_nhwc_kernel, dim3(chunks, B), dim3(256), 2 * 256 * sizeof(float),
-                     (hipStream_t)stream, (const bf16_t*)x, acc, HW, C, G, ppb);
+  hipLaunchKernelGGL(gn_stats_nhwc_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, partial, HW, C, G, ppb);
   G4R_CHECK_LAUNCH("gn_stats");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(g4r_ceil_div((long)B * C, 256)), dim3(256), 0,
-                     (hipStream_t)stream, acc, gamma, beta, scale_shift, B, C, G,
+                     (hipStream_t)stream, partial, gamma, beta, scale_shift, B, C, G, chunks,
                      (double)HW * (double)(C / G), eps);
   G4R_CHECK_LAUNCH("gn_finalize");
   return G4R_OK;

@@ -81,7 +81,8 @@ class _Profiler:
 
 
 PROFILER = _Profiler()
-TILE_NAMES = {0: "128x128", 1: "256x128", 2: "128x128reg", 4: "64x128"}
+TILE_NAMES = {0: "128x128", 1: "256x128", 2: "128x128reg", 4: "64x128", 5: "128x128s3", 6: "128x128s4",
+              7: "128x128w8s4", 8: "256x128s3", 9: "256x256", 10: "128x128w8", 11: "128x64"}
 
 
 def _launch(name, args, tag=None, flops=0.0, nbytes=0.0):
@@ -132,13 +133,22 @@ def zeros_line(device):
     return z
 
 
-def pick_tile(M, N):
-    """Tile heuristic for a 256-CU part: prefer 128x128; fall back to 64x128 when the grid would
-    otherwise leave most CUs idle."""
+def pick_tile(M, N, K=0):
+    """Tile heuristic for a 256-CU part, from tools/microbench.py on MI355X: 128x128 two-stage when
+    the grid fills the chip; 64x128 (more workgroups) when it would not; for long-K / narrow-N shapes
+    (LLaMA down_proj 767x4096x11008) the 8-wave ring variant."""
     t128 = -(-M // 128) * -(-N // 128)
     if t128 >= 192:
-        return 0
+        return 7 if (K >= 8192 and t128 < 512) else 0
     return 4
+
+
+def pick_conv_tile(M, Cout, K):
+    """Implicit-GEMM conv: the 256x128 three-stage ring wins on the large maps (192^2: 805 vs 696 TF)
+    and on the K = 4*9*C pconv; the 128x128 kernel elsewhere."""
+    if M >= 16384 or K >= 18432:
+        return 8
+    return pick_tile(M, Cout, K) if M * Cout >= 192 * 128 * 128 else 4
 
 
 def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfloat16, splits=1,
@@ -156,7 +166,12 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
     if tile_cfg is None:
-        tile_cfg = pick_tile(M, N)
+        tile_cfg = pick_tile(M, N, K)
+        if splits == 1 and tile_cfg == 4 and K >= 2048 and K % 64 == 0:
+            # few tiles and a long K: split K so the grid covers the 256 CUs (e.g. ViT fc2 577x1024x4096)
+            tiles = -(-M // 64) * -(-N // 128)
+            if tiles < 160:
+                splits = max(1, min(4, 256 // tiles, K // 1024))
     if splits > 1 and workspace is None:
         workspace = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
     _launch("g4r_gemm_bf16_nt", (
@@ -188,7 +203,7 @@ def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=torch.bfloa
     if out is None:
         out = torch.empty((B, H, W, Cout), dtype=out_dtype, device=x.device)
     if tile_cfg is None:
-        tile_cfg = pick_tile(B * H * W, Cout)
+        tile_cfg = pick_conv_tile(B * H * W, Cout, groups * 9 * Cin)
     if splits > 1 and workspace is None:
         workspace = torch.empty((splits, B * H * W, Cout), dtype=torch.float32, device=x.device)
     _launch("g4r_conv3x3_nhwc_bf16", (
@@ -254,7 +269,7 @@ def groupnorm_affine(x, gamma, beta, groups, eps=1e-5):
     _bf16(x)
     _f32(gamma, beta)
     B, H, W, C = x.shape
-    acc = torch.empty((B, groups, 2), dtype=torch.float64, device=x.device)
+    acc = torch.empty((B, 256, groups, 2), dtype=torch.float32, device=x.device)
     ss = torch.empty((B, 2, C), dtype=torch.float32, device=x.device)
     _launch("g4r_groupnorm_affine_nhwc_bf16", (
         _p(x), _p(gamma), _p(beta), _p(acc), _p(ss), B, H * W, C, groups,

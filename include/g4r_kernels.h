@@ -72,11 +72,11 @@ int g4r_rmsnorm_bf16(const void* x, const float* gamma, void* y, int rows, int c
 /*
  * GroupNorm statistics of ConvModule's GN (layers.py:133-144; mmcv/cnn/bricks/norm.py:101-107)
  * over an NHWC bf16 map, returned as a per-(image, channel) affine  y = a*x + s :
- *   scale_shift [B, 2, C] fp32 (a then s).  `acc` = workspace of B*G*2 doubles.
+ *   scale_shift [B, 2, C] fp32 (a then s).  `partial` = workspace of B*256*G*2 floats.
  * The normalisation itself (+ReLU) is applied by the consumers (g4r_fuse_shuffle_nhwc_bf16,
  * g4r_roi_align_mlvl_nhwc_*), so the normalised map is never materialised.
  */
-int g4r_groupnorm_affine_nhwc_bf16(const void* x, const float* gamma, const float* beta, double* acc,
+int g4r_groupnorm_affine_nhwc_bf16(const void* x, const float* gamma, const float* beta, float* partial,
                                    float* scale_shift, int B, int HW, int C, int G, float eps,
                                    void* stream);
 

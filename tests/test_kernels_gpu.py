@@ -126,9 +126,9 @@ def test_roi_align_mlvl_nhwc_matches_dropin_and_gn():
 
 
 # ------------------------------------------------------------------------------------------ GEMM / conv
-@pytest.mark.parametrize("tile", [0, 1, 2, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 328, 192), (37, 1024, 1024), (800, 512, 2048),
-                                   (50, 30, 64)])
+                                   (50, 30, 64), (300, 256, 128)])
 def test_gemm_plain(tile, M, N, K):
     a, w = rnd(M, K, seed=1), rnd(N, K, seed=2)
     ref = a.float() @ w.float().t()
@@ -181,7 +181,7 @@ def test_gemm_flatten_linear_shape():
     close(got, ref, 0.05, 1e-2, "flatten_linear")
 
 
-@pytest.mark.parametrize("tile", [0, 1, 4])
+@pytest.mark.parametrize("tile", [0, 1, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_conv3x3(tile):
     B, H, W, Cin, Cout = 2, 13, 9, 64, 96
     x = rnd(B, H, W, Cin, seed=14)

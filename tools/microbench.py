@@ -28,7 +28,7 @@ def R(*s): return (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
 for (M, N, Kd) in [(800, 4096, 4096), (800, 12288, 4096), (800, 22016, 4096), (800, 4096, 11008), (800, 32064, 4096),
                    (4096, 4096, 4096), (577, 3072, 1024), (577, 4096, 1024), (577, 1024, 4096), (48960, 1024, 1088)]:
     a, w = R(M, Kd), R(N, Kd)
-    for tile in (0, 1, 2, 4):
+    for tile in (0, 1, 4, 5, 6, 7, 8):
         try:
             t = timeit(lambda: K.gemm(a, w, tile_cfg=tile))
             rec(f"gemm {M}x{N}x{Kd} tile{tile}", t, 2.0 * M * N * Kd)
@@ -41,12 +41,12 @@ for (M, N, Kd) in [(800, 4096, 4096), (800, 12288, 4096), (800, 22016, 4096), (8
 # conv3x3 at the fuse-round shapes (P=24): 192,96,48,24
 for Hs in (192, 96, 48, 24):
     x = R(1, Hs, Hs, 1024); w = R(1024, 9 * 1024)
-    for tile in (0, 1):
+    for tile in (0, 1, 5, 6, 7, 8):
         t = timeit(lambda: K.conv3x3(x, w, tile_cfg=tile), iters=5)
         rec(f"conv3x3 {Hs}x{Hs}x1024 tile{tile}", t, 2.0 * Hs * Hs * 1024 * 9216)
 # pconv: 32 rois, 4 levels
 x = R(4, 32, 14, 14, 1024); w = R(1024, 4 * 9 * 1024)
-for tile in (0, 1, 4):
+for tile in (0, 1, 4, 5, 6, 7, 8):
     t = timeit(lambda: K.conv3x3(x, w, groups=4, tile_cfg=tile), iters=5)
     rec(f"pconv 32 rois tile{tile}", t, 2.0 * 32 * 196 * 1024 * 4 * 9216)
 # flatten_linear
@@ -74,6 +74,10 @@ x = R(1, 577, 1024)
 t = timeit(lambda: K.upsample_coord(x[:, 1:], 24, 24, 192, 192, 1088)); rec("upsample_coord 192", t, None, 192 * 192 * 1088 * 2)
 own, top = R(1, 192, 192, 1024), R(1, 96, 96, 1024)
 t = timeit(lambda: K.fuse_shuffle(own, top, own)); rec("fuse_shuffle 192", t, None, 192 * 192 * 1024 * 2 * 2)
+h = R(767, 4096); gam = torch.ones(4096, device=dev)
+t = timeit(lambda: K.rmsnorm(h, gam)); rec("rmsnorm 767x4096", t, None, 767 * 4096 * 4)
+h1 = R(577, 1024); g1 = torch.ones(1024, device=dev)
+t = timeit(lambda: K.layernorm(h1, g1, g1)); rec("layernorm 577x1024", t, None, 577 * 1024 * 4)
 gm, bt = torch.ones(1024, device=dev), torch.zeros(1024, device=dev)
 t = timeit(lambda: K.groupnorm_affine(own, gm, bt, 64)); rec("gn_stats 192", t, None, 192 * 192 * 1024 * 2)
 os.makedirs("gpurun_out", exist_ok=True)
