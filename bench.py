@@ -136,27 +136,19 @@ def main():
     model, ids = build_model(args, device, seed=100 + rank)
     image, boxes, prompt = make_inputs(args, ids, device, seed=rank)
 
-    def step():
-        return model(input_ids=prompt, images=image, bboxes=boxes)
+    from gpt4roi_amd import replicas
+    last = {}
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step():
+        last["logits"] = model(input_ids=prompt, images=image, bboxes=boxes)
 
     for _ in range(args.warmup):
         step()
     model.check_status()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        logits = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # barrier + synchronize on both sides of exactly `steps` steps; MAX over ranks
+    dt_local = replicas.timed_steps(step, args.steps, torch.cuda.synchronize, dist)
+    _, dt = replicas.aggregate(args.rois * args.steps, dt_local, dist, device=device)
+    logits = last["logits"]
     assert torch.isfinite(logits[0, -1]).all(), "non-finite logits"
 
     roofline, kernels = None, None

@@ -6,7 +6,7 @@
 // The reference delegates this arithmetic to HF transformers (spi_llava.py:66-67, 198-205) or to
 // flash-attn (llava/train/llama_flash_attn_monkey_patch.py:15-91).
 //
-// Mapping: workgroup = 4 waves = 128 query rows of one (batch, head); wave = 32 query rows.
+// Mapping: workgroup = 2 waves = 64 query rows of one (batch, head); wave = 32 query rows.
 //   S^T = K Q^T  with v_mfma_f32_32x32x16_bf16 (K tile from LDS as the A operand, Q fragments in
 //   registers as B) so that every lane owns ONE query column: its 32 score registers, its running
 //   max / sum and all of its O^T accumulator registers belong to the same query -> softmax needs
@@ -40,18 +40,26 @@ __device__ __forceinline__ int k_swz(int row) {
   return D == 128 ? (row & 15) : ((row >> 1) & 7);
 }
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs p) {
+// NW waves per workgroup = 32*NW query rows.  K/V tiles are software-pipelined through registers:
+// the global loads of tile j+1 are issued right after tile j has been written to LDS and stay in
+// flight during the QK^T / softmax / PV of tile j.
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p) {
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;             // query rows per workgroup
   constexpr int SLOTS = D / 8;            // 16-B slots per key row
   constexpr int KSTEPS = D / 16;          // MFMA k-steps over the head dim
   constexpr int DB = D / 32;              // 32-row blocks of O^T
+  constexpr int NK = KVB * SLOTS / NT;    // K slots staged per thread
+  constexpr int NVU = 16 * SLOTS / NT;    // V units (4 keys x one 8-wide d slot) per thread
+  static_assert(KVB * SLOTS % NT == 0 && 16 * SLOTS % NT == 0, "staging split");
   __shared__ __attribute__((aligned(16))) bf16_t Ks[KVB * D];
   __shared__ __attribute__((aligned(16))) bf16_t Vt[D * VT_LD];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, ql = lane & 31;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int qblock = blockIdx.x * 128;
+  const int qblock = blockIdx.x * QB;
   const int qi = qblock + wave * 32 + ql;
   const int off = p.Tk - p.Tq;
   const bf16_t* Qb = p.Q + (size_t)b * p.q_batch + (size_t)h * D;
@@ -73,36 +81,67 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const float sc2 = p.scale * 1.4426950408889634f;  // scores are kept as s*scale*log2(e)
 
   int kend = p.Tk;
   if (p.causal) {
-    const int last = qblock + 127 + off + 1;  // one past the last key any row of this block sees
+    const int last = qblock + QB - 1 + off + 1;  // one past the last key any row of this block sees
     if (last < kend) kend = last;
   }
 
-  for (int j0 = 0; j0 < kend; j0 += KVB) {
-    // ---- stage K (row-major, swizzled) and V (transposed) ----
+  uint4v kreg[NK], vreg[NVU][4];
+  auto fetch = [&](int j0) {
 #pragma unroll
-    for (int it = 0; it < KVB * SLOTS / 256; ++it) {
-      const int pk = it * 256 + tid;
+    for (int it = 0; it < NK; ++it) {
+      const int pk = it * NT + tid;
       const int row = pk / SLOTS, s = pk % SLOTS;
       int key = j0 + row;
       if (key > p.Tk - 1) key = p.Tk - 1;
-      const uint4v kv = *reinterpret_cast<const uint4v*>(Kb + (size_t)key * p.k_row + s * 8);
-      *reinterpret_cast<uint4v*>(reinterpret_cast<char*>(Ks) + row * (D * 2) + ((s ^ k_swz<D>(row)) << 4)) = kv;
-      // V: lanes run along keys so the transposing 2-byte stores hit distinct banks
-      const int vrow = pk % KVB, vs = pk / KVB;
-      int vkey = j0 + vrow;
-      if (vkey > p.Tk - 1) vkey = p.Tk - 1;
-      const uint4v vv = *reinterpret_cast<const uint4v*>(Vb + (size_t)vkey * p.v_row + vs * 8);
-      const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
+      kreg[it] = *reinterpret_cast<const uint4v*>(Kb + (size_t)key * p.k_row + s * 8);
+    }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Vt[(vs * 8 + 2 * e) * VT_LD + vrow] = (bf16_t)(w[e] & 0xffffu);
-        Vt[(vs * 8 + 2 * e + 1) * VT_LD + vrow] = (bf16_t)(w[e] >> 16);
+    for (int u = 0; u < NVU; ++u) {
+      const int pu = u * NT + tid;
+      const int kq = pu % 16, vs = pu / 16;   // key quad, d slot
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int key = j0 + kq * 4 + j;
+        if (key > p.Tk - 1) key = p.Tk - 1;
+        vreg[u][j] = *reinterpret_cast<const uint4v*>(Vb + (size_t)key * p.v_row + vs * 8);
       }
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NK; ++it) {
+      const int pk = it * NT + tid;
+      const int row = pk / SLOTS, s = pk % SLOTS;
+      *reinterpret_cast<uint4v*>(reinterpret_cast<char*>(Ks) + row * (D * 2) + ((s ^ k_swz<D>(row)) << 4)) = kreg[it];
+    }
+    // V^T: this thread holds 4 consecutive keys x 8 d values -> for each d one 8-byte store of 4 keys
+#pragma unroll
+    for (int u = 0; u < NVU; ++u) {
+      const int pu = u * NT + tid;
+      const int kq = pu % 16, vs = pu / 16;
+      const unsigned w[4][4] = {{vreg[u][0].x, vreg[u][0].y, vreg[u][0].z, vreg[u][0].w},
+                                {vreg[u][1].x, vreg[u][1].y, vreg[u][1].z, vreg[u][1].w},
+                                {vreg[u][2].x, vreg[u][2].y, vreg[u][2].z, vreg[u][2].w},
+                                {vreg[u][3].x, vreg[u][3].y, vreg[u][3].z, vreg[u][3].w}};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // word e holds d = 2e (low half) and 2e+1 (high half)
+        const uint2v lo = {(w[0][e] & 0xffffu) | (w[1][e] << 16), (w[2][e] & 0xffffu) | (w[3][e] << 16)};
+        const uint2v hi2 = {(w[0][e] >> 16) | (w[1][e] & 0xffff0000u), (w[2][e] >> 16) | (w[3][e] & 0xffff0000u)};
+        *reinterpret_cast<uint2v*>(Vt + (vs * 8 + 2 * e) * VT_LD + kq * 4) = lo;
+        *reinterpret_cast<uint2v*>(Vt + (vs * 8 + 2 * e + 1) * VT_LD + kq * 4) = hi2;
+      }
+    }
+  };
+
+  if (kend > 0) fetch(0);
+  for (int j0 = 0; j0 < kend; j0 += KVB) {
+    commit();
     __syncthreads();
+    if (j0 + KVB < kend) fetch(j0 + KVB);  // in flight during this tile's MFMAs
 
     // ---- S^T = K Q^T for two 32-key blocks ----
     float16v sacc[2];
@@ -120,28 +159,40 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs p) {
       }
     }
 
-    // ---- online softmax for this lane's query (keys: j0 + kb*32 + (r&3) + 8*(r>>2) + 4*hi) ----
+    // ---- online softmax for this lane's query (keys: j0 + kb*32 + (r&3) + 8*(r>>2) + 4*hi),
+    //      in the log2 domain: p = 2^(s*scale*log2(e) - m) is one v_exp_f32 per score ----
+    const bool need_mask = (j0 + KVB > p.Tk) || (p.causal && j0 + KVB - 1 > qblock + wave * 32 + off);
     float mt = -INFINITY;
+    if (need_mask) {  // wave-uniform: only the diagonal / last tiles pay for the per-key tests
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float s = sacc[kb][r] * p.scale;
-        if (key >= p.Tk || (p.causal && key > qi + off)) s = -INFINITY;
-        sacc[kb][r] = s;
-        mt = fmaxf(mt, s);
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int key = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          float s = sacc[kb][r] * sc2;
+          if (key >= p.Tk || (p.causal && key > qi + off)) s = -INFINITY;
+          sacc[kb][r] = s;
+          mt = fmaxf(mt, s);
+        }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          sacc[kb][r] *= sc2;
+          mt = fmaxf(mt, sacc[kb][r]);
+        }
+    }
     mt = fmaxf(mt, __shfl_xor(mt, 32));
     const float m_new = fmaxf(m_run, mt);
-    const float m_use = m_new == -INFINITY ? 0.f : m_new;  // fully masked so far: exp(-inf - 0) = 0
-    const float alpha = __expf(m_run - m_use);             // m_run = -inf -> 0
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;  // fully masked so far: 2^(-inf - 0) = 0
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
     float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __expf(sacc[kb][r] - m_use);
+        const float e = __builtin_amdgcn_exp2f(sacc[kb][r] - m_use);
         sacc[kb][r] = e;
         rs += e;
       }
@@ -211,11 +262,16 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
   G4R_REQUIRE(!causal || Tk >= Tq, "flash_attn: causal needs Tk >= Tq");
   AttnArgs a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_row, k_row, v_row, o_row,
                 q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal};
-  dim3 grid(g4r_ceil_div(Tq, 128), H, B);
-  if (head_dim == 64)
-    hipLaunchKernelGGL(flash_attn_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(flash_attn_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  // 64 query rows per workgroup (2 waves): ~2x the workgroups of a 128-row block for the short
+  // sequences of this path (577 / ~800 tokens) and finer causal load balance
+  if (head_dim == 64) {
+    dim3 grid(g4r_ceil_div(Tq, 64), H, B);
+    hipLaunchKernelGGL((flash_attn_fwd_kernel<64, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
+  } else {
+    // head_dim 128: 4 waves share the staging registers of a tile (2 waves would spill)
+    dim3 grid(g4r_ceil_div(Tq, 128), H, B);
+    hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   G4R_CHECK_LAUNCH("flash_attn_fwd");
   return G4R_OK;
 }

@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ 
 //   spi_offset[b] ..); everything else takes embed[id].  The reference requires the patch run to
 //   sit right after <im_start> and be followed by <im_end> (:125-128) and #<bbox> == n_i (:149-157);
 //   violations set status[b] != 0 instead of raising on the device.
-// One workgroup per sample; ranks by a block-wide prefix scan.
+// grid = (token chunks, samples): every workgroup redoes the cheap block-wide rank scan of its sample
+// (T is ~1-2k ids) and then gathers `tok_per_block` token rows; chunk 0 writes status.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void splice_embed_kernel(const long* __restrict__ ids,
                                                            const bf16_t* __restrict__ embed,
@@ -304,13 +305,13 @@ __global__ __launch_bounds__(256) void splice_embed_kernel(const long* __restric
                                                            bf16_t* __restrict__ out, int* __restrict__ status,
                                                            int T, int C, int n_patch, long patch_id,
                                                            long bbox_id, long im_start_id, long im_end_id,
-                                                           int vocab) {
+                                                           int vocab, int tok_per_block) {
   extern __shared__ int sh[];  // [T] patch rank, [T] bbox rank, [8] scratch
   int* prank = sh;
   int* brank = sh + T;
   __shared__ int carry[2];
   __shared__ int wsum[2][4];
-  const int b = blockIdx.x;
+  const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long* row = ids + (size_t)b * T;
   if (tid == 0) carry[0] = carry[1] = 0;
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void splice_embed_kernel(const long* __restric
   for (int t = tid; t < T; t += 256)
     if (prank[t] >= 0 && t - prank[t] != first) atomicOr(&flags_sh, 16);  // patch run not contiguous
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && blockIdx.x == 0) {
     int st = flags_sh;
     const int np = carry[0], nb = carry[1];
     if (np != 0 && np != n_patch) st |= 1;                       // wrong number of patch tokens
@@ -371,7 +372,9 @@ __global__ __launch_bounds__(256) void splice_embed_kernel(const long* __restric
   }
   const int nvec = C >> 3;
   const int so = spi_offset ? spi_offset[b] : 0;
-  for (int i = tid; i < T * nvec; i += 256) {
+  const int t0 = blockIdx.x * tok_per_block;
+  const int t1 = min(T, t0 + tok_per_block);
+  for (int i = t0 * nvec + tid; i < t1 * nvec; i += 256) {
     const int t = i / nvec, v = i % nvec;
     const bf16_t* src;
     if (prank[t] >= 0 && prank[t] < n_patch)
@@ -539,9 +542,11 @@ int g4r_splice_embed_bf16(const long* ids, const void* embed, const void* img, c
   G4R_REQUIRE(T <= 16384, "splice_embed: T <= 16384");
   G4R_REQUIRE(ids && embed && out && status, "splice_embed: null pointer");
   G4R_REQUIRE(n_patch == 0 || img, "splice_embed: image features missing");
-  hipLaunchKernelGGL(splice_embed_kernel, dim3(B), dim3(256), 2 * T * sizeof(int), (hipStream_t)stream, ids,
-                     (const bf16_t*)embed, (const bf16_t*)img, (const bf16_t*)spi, spi_offset, (bf16_t*)out,
-                     status, T, C, n_patch, patch_id, bbox_id, im_start_id, im_end_id, vocab);
+  const int tpb = 4;
+  hipLaunchKernelGGL(splice_embed_kernel, dim3(g4r_ceil_div(T, tpb), B), dim3(256), 2 * T * sizeof(int),
+                     (hipStream_t)stream, ids, (const bf16_t*)embed, (const bf16_t*)img, (const bf16_t*)spi,
+                     spi_offset, (bf16_t*)out, status, T, C, n_patch, patch_id, bbox_id, im_start_id, im_end_id,
+                     vocab, tpb);
   G4R_CHECK_LAUNCH("splice_embed");
   return G4R_OK;
 }

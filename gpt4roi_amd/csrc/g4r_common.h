@@ -37,16 +37,15 @@ typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
 }
-// round-to-nearest-even, NaN kept quiet (same rule as torch's float->bfloat16)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// float -> bf16, round-to-nearest-even: gfx950 has the conversion in hardware
+// (v_cvt_pk_bf16_f32); the vector cast below compiles to exactly one such instruction per pair.
+typedef __bf16 g4r_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float g4r_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const g4r_f32x2 f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, g4r_bf16x2));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 

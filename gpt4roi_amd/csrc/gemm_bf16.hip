@@ -43,6 +43,7 @@ struct GemmArgs {
   int splits, tiles_per_split;  // K tiles (of 64) per z slice
   int H, Wd, Cin, groups;      // AMODE 1 geometry
   int tiles_m, tiles_n;
+  int n_fastest;  // tile order: 1 = consecutive workgroups walk N first (share the A / activation tile)
   int dbg;  // ablation probe (tools only): 1 = skip the loads after the first tile, 2 = skip the MFMAs
 };
 
@@ -95,9 +96,13 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  // tile order: M fastest inside a column panel group so consecutive workgroups of one XCD
-  // reuse the same W panel (weights are the big operand for M << N shapes).
-  const int tile_m = wg % p.tiles_m, tile_n = wg / p.tiles_m;
+  // Tile order = which operand the co-scheduled workgroups of one XCD share through its L2:
+  //   M fastest: same W panel (weights are the big operand when M << N: LLaMA / ViT projections);
+  //   N fastest: same A tile (activations are the big operand when M >> N: the implicit-GEMM convs,
+  //              whose 9-tap gather was re-fetched once per column tile -- 2.5 GB/launch of fabric
+  //              traffic at 192^2 against 170 MB algorithmic, profiles/r01_bench_rocprof.md).
+  const int tile_m = p.n_fastest ? wg / p.tiles_n : wg % p.tiles_m;
+  const int tile_n = p.n_fastest ? wg % p.tiles_n : wg / p.tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int split = blockIdx.y;
   const int t_begin = split * p.tiles_per_split;
@@ -515,6 +520,7 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
   p.residual = (const bf16_t*)residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.act = act; p.out_f32 = out_f32; p.dbg = g_gemm_dbg;
+  p.n_fastest = (long)M * 1 > (long)N * 2;
   const int nt = K / BK;
   if (splits > nt) splits = nt;
   p.tiles_per_split = g4r_ceil_div(nt, splits);
@@ -539,6 +545,7 @@ int g4r_conv3x3_nhwc_bf16(const void* X, const void* W, void* Y, const float* bi
   p.lda = Cin; p.ldw = p.K; p.ldc = Cout; p.ldr = 0;
   p.act = act; p.out_f32 = out_f32;
   p.H = H; p.Wd = Wd; p.Cin = Cin; p.groups = groups; p.a_group_stride = x_group_stride;
+  p.n_fastest = 1; p.dbg = g_gemm_dbg;
   const int nt = p.K / BK;
   if (splits > nt) splits = nt;
   p.tiles_per_split = g4r_ceil_div(nt, splits);

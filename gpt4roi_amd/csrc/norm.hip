@@ -179,27 +179,39 @@ __global__ __launch_bounds__(256) void gn_stats_nhwc_kernel(const bf16_t* __rest
   }
 }
 
+// one wave per (image, group): shuffle-reduce the chunk partials in fp64, then the wave writes the
+// affine of its C/G channels.  grid = ceil(B*G / 4), block = 256.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           float* __restrict__ scale_shift, int B, int C,
                                                           int G, int chunks, double count, float eps) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i % C, g = c / (C / G);
+  const int bg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bg >= B * G) return;
+  const int lane = threadIdx.x & 63;
+  const int b = bg / G, g = bg % G;
   double sum = 0.0, sq = 0.0;
-  for (int k = 0; k < chunks; ++k) {
+  for (int k = lane; k < chunks; k += 64) {
     const float* src = partial + (((size_t)b * chunks + k) * G + g) * 2;
     sum += (double)src[0];
     sq += (double)src[1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o);
+    sq += __shfl_xor(sq, o);
   }
   const double mean = sum / count;
   double var = sq / count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float a = gamma[c] * rstd;
-  scale_shift[(size_t)b * 2 * C + c] = a;
-  scale_shift[(size_t)b * 2 * C + C + c] = beta[c] - (float)mean * a;
+  const int cpg = C / G;
+  for (int i = lane; i < cpg; i += 64) {
+    const int c = g * cpg + i;
+    const float a = gamma[c] * rstd;
+    scale_shift[(size_t)b * 2 * C + c] = a;
+    scale_shift[(size_t)b * 2 * C + C + c] = beta[c] - (float)mean * a;
+  }
 }
 
 }  // namespace
@@ -246,7 +258,7 @@ int g4r_groupnorm_affine_nhwc_bf16(const void* x, const float* gamma, const floa
   hipLaunchKernelGGL(gn_stats_nhwc_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, partial, HW, C, G, ppb);
   G4R_CHECK_LAUNCH("gn_stats");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(g4r_ceil_div((long)B * C, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(g4r_ceil_div((long)B * G, 4)), dim3(256), 0,
                      (hipStream_t)stream, partial, gamma, beta, scale_shift, B, C, G, chunks,
                      (double)HW * (double)(C / G), eps);
   G4R_CHECK_LAUNCH("gn_finalize");
