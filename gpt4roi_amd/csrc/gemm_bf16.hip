@@ -38,7 +38,8 @@ struct GemmArgs {
   long a_group_stride;   // AMODE 1: elements between groups
   int M, N, K;
   int lda, ldw, ldc, ldr;
-  int act;               // 0 none, 1 relu, 2 quick_gelu (x*sigmoid(1.702x)), 3 silu
+  int act;               // 0 none, 1 relu, 2 quick_gelu (x*sigmoid(1.702x)), 3 silu,
+                         // 4 swiglu: columns are interleaved (gate, up) pairs, C has N/2 columns
   int out_f32;
   int splits, tiles_per_split;  // K tiles (of 64) per z slice
   int H, Wd, Cin, groups;      // AMODE 1 geometry
@@ -355,7 +356,21 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = c[r] / (1.f + __expf(-c[r]));
       }
-      if (m < p.M) {
+      if (m < p.M && p.act == 4) {
+        // SwiGLU epilogue (LLaMA MLP, HF LlamaMLP: down(silu(gate(x)) * up(x))): the weight rows were
+        // interleaved at prepare() so this lane's quad is (g0, u0, g1, u1); silu is rounded to bf16
+        // before the product, as the un-fused reference does.
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nw + j * 32 + q * 8;
+          if (n >= p.N) continue;
+          const float g0 = c[q * 4], u0 = c[q * 4 + 1], g1 = c[q * 4 + 2], u1 = c[q * 4 + 3];
+          const float s0 = bf16lo(pack_bf16x2(g0 / (1.f + __expf(-g0)), 0.f));
+          const float s1 = bf16lo(pack_bf16x2(g1 / (1.f + __expf(-g1)), 0.f));
+          bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + (n >> 1);
+          *reinterpret_cast<uint32_t*>(dst) = pack_bf16x2(s0 * u0, s1 * u1);
+        }
+      } else if (m < p.M) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n = nw + j * 32 + q * 8;
@@ -501,7 +516,9 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
   G4R_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative shape");
   if (M == 0 || N == 0) return G4R_OK;
   G4R_REQUIRE(A && W && C, "gemm: null pointer");
-  G4R_REQUIRE(act >= 0 && act <= 3, "gemm: act must be 0..3");
+  G4R_REQUIRE(act >= 0 && act <= 4, "gemm: act must be 0..4");
+  G4R_REQUIRE(act != 4 || (N % 4 == 0 && ldc % 2 == 0 && splits == 1 && !residual && !bias && !out_f32 && K % BK == 0),
+              "gemm: swiglu epilogue needs N % 4 == 0, bf16 output, no bias/residual/split-K");
   if (K % BK != 0 || K == 0) {
     G4R_REQUIRE(residual == nullptr, "gemm: residual unsupported on the small-K path");
     long total = (long)M * N;

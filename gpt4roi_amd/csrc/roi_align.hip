@@ -300,8 +300,17 @@ __device__ __forceinline__ void store8(float* p, const Vec8& a) {
 
 #define MLVL_MAX_XTAB 256
 #define MLVL_MAX_YTAB 16
+#define MLVL_STAGE_COLS 32    // LDS-staged path when the bin row touches <= 32 map columns
+#define MLVL_STAGE_CH 256     // channels per staging pass (32 cols x 256 ch x 4 B = 32 KB)
 
-template <typename TI>
+// STAGED = true (the bf16 region path): when the RoI is narrow on this level (bin width < ~2 px, so
+// neighbouring samples share texels) the workgroup first combines the map rows of its bin row
+// vertically into LDS,   S[x][c] = sum_iy ( hy * v[y_lo][x][c] + ly * v[y_hi][x][c] ),
+// reading every needed texel of the row pair ONCE with coalesced 16-B loads, and then resolves the
+// horizontal taps of all PW bins from LDS.  Wide RoIs (no texel sharing) keep the direct gather.
+// The staged path re-associates the 16-term sum (agreement ~1e-7 relative before the bf16
+// rounding); STAGED = false (fp32 instantiation) keeps the reference's summation order exactly.
+template <typename TI, bool STAGED>
 __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_kernel(MlvlArgs a,
                                                                   const float* __restrict__ rois,
                                                                   TI* __restrict__ out, int L, int B,
@@ -309,6 +318,8 @@ __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_kernel(MlvlArgs a,
                                                                   int aligned) {
   __shared__ Tap1D<float> xtab[MLVL_MAX_XTAB];
   __shared__ Tap1D<float> ytab[MLVL_MAX_YTAB];
+  __shared__ __attribute__((aligned(16))) float stage[STAGED ? MLVL_STAGE_COLS * MLVL_STAGE_CH : 4];
+  __shared__ int xrange[2];
   // XCD-aware decode: workgroup b runs on XCD b % 8 (observed dispatch); give all PH rows of
   // one (level, roi) group to the same XCD so its window of the map is fetched into one L2.
   const int bid = blockIdx.x;
@@ -322,9 +333,20 @@ __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_kernel(MlvlArgs a,
   const TI* feat = reinterpret_cast<const TI*>(a.feat[l]);
   const RoiGeom<float> g = roi_geometry<float>(rois + (size_t)5 * n, a.scale[l], aligned, PH, PW, sr);
   const int tid = threadIdx.x;
+  if (tid == 0) {
+    xrange[0] = 0x7fffffff;
+    xrange[1] = -1;
+  }
   if (tid < sr) ytab[tid] = make_tap1d<float>(sample_coord<float>(g.start_h, g.bin_h, ph, tid, sr), H);
-  for (int i = tid; i < PW * sr; i += 256)
-    xtab[i] = make_tap1d<float>(sample_coord<float>(g.start_w, g.bin_w, i / sr, i % sr, sr), W);
+  __syncthreads();
+  for (int i = tid; i < PW * sr; i += 256) {
+    const Tap1D<float> t = make_tap1d<float>(sample_coord<float>(g.start_w, g.bin_w, i / sr, i % sr, sr), W);
+    xtab[i] = t;
+    if (STAGED && t.valid) {
+      atomicMin(&xrange[0], t.lo);
+      atomicMax(&xrange[1], t.hi);
+    }
+  }
   __syncthreads();
   const bool batch_ok = g.batch >= 0 && g.batch < B;
   const int wave = tid >> 6, lane = tid & 63;
@@ -333,8 +355,81 @@ __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_kernel(MlvlArgs a,
   const int bi = batch_ok ? g.batch : 0;
   const TI* img = feat + (size_t)bi * H * W * C;
   const float* aff = a.affine[l] ? a.affine[l] + (size_t)bi * 2 * C : nullptr;
+  TI* obase = out + (((size_t)l * N + n) * PH + ph) * PW * C;
+
+  const int x_first = xrange[0];
+  const int ncols = xrange[1] - xrange[0] + 1;
+  if (STAGED && batch_ok && ncols >= 1 && ncols <= MLVL_STAGE_COLS) {
+    const int vl = tid & 31, sub = tid >> 5;  // 32 vector lanes (256 channels) x 8 column/bin lanes
+    for (int c0 = 0; c0 < C; c0 += MLVL_STAGE_CH) {
+      const int cv = c0 + vl * 8;
+      const bool ch_ok = cv < C;
+      Vec8 ga, gs;
+      if (aff && ch_ok) {
+        ga = load8(aff + cv);
+        gs = load8(aff + C + cv);
+      }
+      // phase 1: vertical combine of the <= 2*sr map rows into LDS, one texel vector per (col, lane)
+      for (int col = sub; col < ncols; col += 8) {
+        Vec8 acc;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc.v[k] = 0.f;
+        if (ch_ok) {
+          const int x = x_first + col;
+          for (int iy = 0; iy < sr; ++iy) {
+            const Tap1D<float> ty = ytab[iy];
+            if (!ty.valid) continue;
+            const float ly = ty.frac, hy = 1.f - ly;
+            Vec8 v1 = load8(img + ((size_t)ty.lo * W + x) * C + cv);
+            Vec8 v3 = load8(img + ((size_t)ty.hi * W + x) * C + cv);
+            if (aff) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                v1.v[k] = fmaxf(ga.v[k] * v1.v[k] + gs.v[k], 0.f);
+                v3.v[k] = fmaxf(ga.v[k] * v3.v[k] + gs.v[k], 0.f);
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc.v[k] += hy * v1.v[k] + ly * v3.v[k];
+          }
+        }
+        float* sp = stage + col * MLVL_STAGE_CH + vl * 8;
+        *reinterpret_cast<float4v*>(sp) = float4v{acc.v[0], acc.v[1], acc.v[2], acc.v[3]};
+        *reinterpret_cast<float4v*>(sp + 4) = float4v{acc.v[4], acc.v[5], acc.v[6], acc.v[7]};
+      }
+      __syncthreads();
+      // phase 2: horizontal taps of every bin from LDS
+      if (ch_ok) {
+        for (int pw = sub; pw < PW; pw += 8) {
+          Vec8 acc;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc.v[k] = 0.f;
+          for (int ix = 0; ix < sr; ++ix) {
+            const Tap1D<float> tx = xtab[pw * sr + ix];
+            if (!tx.valid) continue;
+            const float lx = tx.frac, hx = 1.f - lx;
+            const float* s0 = stage + (tx.lo - x_first) * MLVL_STAGE_CH + vl * 8;
+            const float* s1 = stage + (tx.hi - x_first) * MLVL_STAGE_CH + vl * 8;
+            const float4v a0 = *reinterpret_cast<const float4v*>(s0), a1 = *reinterpret_cast<const float4v*>(s0 + 4);
+            const float4v b0 = *reinterpret_cast<const float4v*>(s1), b1 = *reinterpret_cast<const float4v*>(s1 + 4);
+            acc.v[0] += hx * a0.x + lx * b0.x; acc.v[1] += hx * a0.y + lx * b0.y;
+            acc.v[2] += hx * a0.z + lx * b0.z; acc.v[3] += hx * a0.w + lx * b0.w;
+            acc.v[4] += hx * a1.x + lx * b1.x; acc.v[5] += hx * a1.y + lx * b1.y;
+            acc.v[6] += hx * a1.z + lx * b1.z; acc.v[7] += hx * a1.w + lx * b1.w;
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc.v[k] = acc.v[k] / count;
+          store8(obase + (size_t)pw * C + cv, acc);
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // direct gather (wide RoIs; fp32 instantiation; RoIs with a bad batch index -> zeros)
   for (int pw = wave; pw < PW; pw += 4) {
-    TI* orow = out + ((((size_t)l * N + n) * PH + ph) * PW + pw) * C;
+    TI* orow = obase + (size_t)pw * C;
     for (int v = lane; v < nvec; v += 64) {
       Vec8 acc;
 #pragma unroll
@@ -443,7 +538,7 @@ int launch_mlvl(const void* const* feats, const float* const* affines, const int
   const long groups = (long)levels * N;
   const long blocks = ((groups + 7) / 8) * 8 * PH;
   G4R_REQUIRE(blocks < 2147483647L, "roi_align_mlvl: grid too large");
-  hipLaunchKernelGGL((roi_align_mlvl_nhwc_kernel<TI>), dim3((unsigned)blocks), dim3(256), 0,
+  hipLaunchKernelGGL((roi_align_mlvl_nhwc_kernel<TI, sizeof(TI) == 2>), dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, a, rois, (TI*)output, levels, B, C, N, PH, PW, sr, aligned);
   G4R_CHECK_LAUNCH("roi_align_mlvl_nhwc");
   return G4R_OK;

@@ -41,7 +41,7 @@ _SIGS = {
 }
 _bound = {}
 
-ACT = {None: 0, "none": 0, "relu": 1, "quick_gelu": 2, "silu": 3}
+ACT = {None: 0, "none": 0, "relu": 1, "quick_gelu": 2, "silu": 3, "swiglu": 4}
 
 
 def _fn(name):
@@ -144,11 +144,17 @@ def pick_tile(M, N, K=0):
 
 
 def pick_conv_tile(M, Cout, K):
-    """Implicit-GEMM conv: the 256x128 three-stage ring wins on the large maps (192^2: 805 vs 696 TF)
-    and on the K = 4*9*C pconv; the 128x128 kernel elsewhere."""
-    if M >= 16384 or K >= 18432:
-        return 8
-    return pick_tile(M, Cout, K) if M * Cout >= 192 * 128 * 128 else 4
+    """Implicit-GEMM conv (tools/conv_tiles.py on MI355X, N-fastest tile order): the 256x256 tile wins on
+    the large maps (192^2: 897 vs 711 TF/s for 128x128; 96^2: 699 vs 630), the 256x128 two-stage kernel on
+    the K = 4*9*C pconv, and small maps want 64x128 tiles + split-K to cover the 256 CUs.
+    Returns (tile_cfg, splits)."""
+    if K >= 18432:
+        return 1, 1
+    if M >= 8192:
+        return 9, 1
+    blocks = -(-M // 64) * -(-Cout // 128)
+    splits = max(1, min(8, round(384 / blocks), K // 1024))
+    return 4, splits
 
 
 def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfloat16, splits=1,
@@ -160,9 +166,10 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
     assert a.stride(1) == 1 and w.stride(1) == 1
     M, K = a.shape
     N = w.size(0)
+    n_out = N // 2 if act == "swiglu" else N          # swiglu: interleaved (gate, up) weight rows
     if out is None:
-        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
-    assert out.stride(1) == 1 and out.shape == (M, N)
+        out = torch.empty((M, n_out), dtype=out_dtype, device=a.device)
+    assert out.stride(1) == 1 and out.shape == (M, n_out)
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
     if tile_cfg is None:
@@ -203,7 +210,9 @@ def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=torch.bfloa
     if out is None:
         out = torch.empty((B, H, W, Cout), dtype=out_dtype, device=x.device)
     if tile_cfg is None:
-        tile_cfg = pick_conv_tile(B * H * W, Cout, groups * 9 * Cin)
+        tile_cfg, auto_splits = pick_conv_tile(B * H * W, Cout, groups * 9 * Cin)
+        if splits == 1:
+            splits = auto_splits
     if splits > 1 and workspace is None:
         workspace = torch.empty((splits, B * H * W, Cout), dtype=torch.float32, device=x.device)
     _launch("g4r_conv3x3_nhwc_bf16", (
@@ -330,6 +339,11 @@ def rope_qkv(qkv, cos, sin, q_out, k_cache, v_cache, heads, head_dim, pos0):
     _launch("g4r_rope_qkv_bf16", (
         _p(qkv), _p(cos), _p(sin), _p(q_out), _p(k_cache), _p(v_cache), T, heads,
                                   head_dim, pos0, _stream(qkv),))
+
+
+def interleave_gate_up(gate_w, up_w):
+    """[F,K],[F,K] -> [2F,K] with rows g0,u0,g1,u1,... for gemm(act="swiglu")."""
+    return torch.stack([gate_w, up_w], 1).reshape(2 * gate_w.size(0), gate_w.size(1)).contiguous()
 
 
 def swiglu(gate_up, out=None):

@@ -3,7 +3,7 @@
 Carries the arithmetic the reference delegates to HF `LlamaModel.forward(inputs_embeds=...)` at
 /root/reference/gpt4roi/models/spi_llava.py:198-205 and the `lm_head` of
 llava/model/llava.py:235-238: RMSNorm -> fused QKV GEMM -> rotary (rotate_half) + KV-cache append
--> causal attention -> O GEMM (+residual) -> RMSNorm -> fused gate|up GEMM -> SiLU*up -> down GEMM
+-> causal attention -> O GEMM (+residual) -> RMSNorm -> fused gate|up GEMM with SiLU*up epilogue -> down GEMM
 (+residual); final RMSNorm; logits.  Weights from an HF-named state dict
 (`model.layers.N.self_attn.q_proj.weight`, ..., `lm_head.weight`).  One KV cache per batch element,
 sized once for `max_positions` (288 GB of HBM make whole-sequence residency the default).
@@ -39,7 +39,7 @@ class LlamaDecoder:
                                 g(p + "self_attn.v_proj.weight")], 0).contiguous(),
                 wo=g(p + "self_attn.o_proj.weight"),
                 n2=g(p + "post_attention_layernorm.weight", torch.float32),
-                wgu=torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")], 0).contiguous(),
+                wgu=K.interleave_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")),
                 wd=g(p + "mlp.down_proj.weight")))
         self.inter = self.layers[0]['wd'].size(1) if self.layers else 0
         self.norm = g("model.norm.weight", torch.float32)
@@ -83,8 +83,7 @@ class LlamaDecoder:
             a = K.flash_attn(q, self.kc[li, :B, :pos0 + T], self.vc[li, :B, :pos0 + T], H, scale, True)
             x = K.gemm(a.view(B * T, C), L['wo'], residual=x)
             h = K.rmsnorm(x, L['n2'], self.eps)
-            gu = K.gemm(h, L['wgu'])
-            f = K.swiglu(gu)
+            f = K.gemm(h, L['wgu'], act="swiglu")            # gate|up GEMM with the SiLU*up epilogue
             x = K.gemm(f, L['wd'], residual=x)
         self.pos = pos0 + T
         xn = K.rmsnorm(x, self.norm, self.eps).view(B, T, C)

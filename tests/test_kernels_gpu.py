@@ -125,6 +125,28 @@ def test_roi_align_mlvl_nhwc_matches_dropin_and_gn():
     assert empty.shape == (4, 0, 14, 14, 64)
 
 
+def test_roi_align_mlvl_staged_path_edge_boxes():
+    """bf16 kernel (LDS-staged rows for narrow RoIs, direct gather for wide ones) against the fp32
+    kernel (reference summation order) on boxes that hang off the map, are degenerate, tiny or full-frame."""
+    B, C, P = 2, 256, 8
+    sizes = [8 * P, 4 * P, 2 * P, P]
+    g = torch.Generator().manual_seed(9)
+    feats32 = [torch.randn(B, s, s, C, generator=g).to(DEV) for s in sizes]
+    img = 14.0 * P
+    rois = torch.tensor([[0, -20., -20., 30., 40.], [1, 0., 0., img, img], [0, 50., 50., 50., 50.],
+                         [1, 100., 90., 140., 111.9], [0, img - 3, img - 3, img + 30, img + 30],
+                         [1, 200., 200., 240., 250.], [0, 10.3, 20.7, 17.1, 25.2], [1, 5., 60., 110., 64.]], device=DEV)
+    scales = [8 / 14, 4 / 14, 2 / 14, 1 / 14]
+    feats16 = [f.to(torch.bfloat16) for f in feats32]
+    want = K.roi_align_mlvl([f.float() for f in feats16], rois, 14, scales)        # fp32 kernel, exact order
+    got = K.roi_align_mlvl(feats16, rois, 14, scales)
+    close(got, want, 2e-2, 1e-2, "staged bf16 vs fp32 kernel")
+    aff = [torch.randn(B, 2, C, device=DEV) for _ in sizes]
+    want_a = K.roi_align_mlvl([torch.relu(f.float() * a[:, 0][:, None, None, :] + a[:, 1][:, None, None, :])
+                               for f, a in zip(feats16, aff)], rois, 14, scales)
+    close(K.roi_align_mlvl(feats16, rois, 14, scales, affines=aff), want_a, 3e-2, 1e-2, "staged + deferred GN")
+
+
 # ------------------------------------------------------------------------------------------ GEMM / conv
 @pytest.mark.parametrize("tile", [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 328, 192), (37, 1024, 1024), (800, 512, 2048),
@@ -161,6 +183,17 @@ def test_gemm_epilogue(act):
     close(K.gemm(a, w, bias=bias, residual=res, act=act), ref, 0.05, 1e-2, f"epilogue {act}")
     close(K.gemm(a, w, bias=bias, residual=res, act=act, out_dtype=torch.float32), ref, 0.02, 2e-3, "f32 out")
     close(K.gemm(a, w, bias=bias, residual=res, act=act, splits=4), ref, 0.05, 1e-2, "split-K")
+
+
+def test_gemm_swiglu_epilogue():
+    M, Fd, Kd = 300, 704, 512
+    a, g, u = rnd(M, Kd, seed=20), rnd(Fd, Kd, scale=0.1, seed=21), rnd(Fd, Kd, scale=0.1, seed=22)
+    gate, up = a.float() @ g.float().t(), a.float() @ u.float().t()
+    ref = F.silu(gate).to(torch.bfloat16).float() * up
+    for tile in (0, 4, 7):
+        got = K.gemm(a, K.interleave_gate_up(g, u), act="swiglu", tile_cfg=tile)
+        assert got.shape == (M, Fd)
+        close(got, ref, 0.03, 2e-2, f"swiglu epilogue tile {tile}")
 
 
 def test_gemm_strided_a_and_small_k():

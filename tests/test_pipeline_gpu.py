@@ -212,6 +212,31 @@ def test_end_to_end_embeds_logits_and_greedy_ids():
     assert len(gen) == 4
 
 
+def test_end_to_end_batch_of_two_ragged_regions():
+    """B = 2 images with different numbers of regions (one has none): the batched call must equal
+    the two single-image calls (every stage of the path is per-image)."""
+    H, P, image = 512, 8, 112
+    ids = syn.token_ids(vocab_base=990)
+    tower = ClipVisionTower(syn.vit_state(H, 4 * H, 12, image, seed=8), heads=8, device=DEV)
+    dec = LlamaDecoder(syn.llama_state(512, 1408, 2, ids.vocab, seed=9), heads=4, max_positions=256, device=DEV,
+                       max_batch=2)
+    model = SPILlavaLlamaModel(tower, dec, ids, embed_dims=H)
+    model.spi_module.load_state_dict(syn.spi_state(model.spi_module, 3))
+    g = torch.Generator().manual_seed(13)
+    imgs = torch.randn(2, 3, image, image, generator=g).to(DEV)
+    boxes = [syn.boxes(2, g).to(DEV), torch.zeros(0, 4, device=DEV)]
+    p0 = syn.prompt_ids(ids, P, 2, g, sys_len=4, question_len=6, vocab_base=990)
+    p1 = syn.prompt_ids(ids, P, 0, g, sys_len=4, question_len=6 + 8, vocab_base=990)   # same length, no regions
+    assert p0.numel() == p1.numel()
+    prompts = torch.stack([p0, p1]).to(DEV)
+    both = model(input_ids=prompts, images=imgs, bboxes=boxes)
+    model.check_status()
+    for b in range(2):
+        one = model(input_ids=prompts[b:b + 1], images=imgs[b:b + 1], bboxes=[boxes[b]])
+        # not bit-equal: B changes the GEMM M, hence the tile / split-K choice and the fp32 summation order
+        assert relerr(both[b], one[0]) < 1.5e-2, b
+
+
 def test_malformed_prompt_raises_like_the_reference():
     ids = syn.token_ids(vocab_base=990)
     vsd = syn.vit_state(256, 1024, 12, 112, seed=8)
