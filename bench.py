@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--llama-layers", type=int, default=32, help="debug only; anything but 32 marks the line invalid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--decode-tokens", type=int, default=16,
+                    help="extra (not part of `value`): greedy KV-cache decode steps timed after the prefill")
     return ap.parse_args()
 
 
@@ -168,12 +170,45 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": a["calls"], "avg_launch_us": round(1e3 * a["ms"] / a["calls"], 2),
                     "share_of_step": round(a["ms"] / tot, 3)}
+        # HBM traffic per launch from the committed PMC passes (collected separately, as rocprofv3
+        # requires); null when no profile is committed for this kernel
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["per_launch_bytes"]
+        except Exception:
+            pass
+        if dom in pmc:
+            roofline["traffic"] = pmc[dom]["read"] + pmc[dom]["write"]
+            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (PMC FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+            roofline["algorithmic_bytes_per_launch"] = int(a["bytes"] / a["calls"])
         ra = agg.get("roi_align_mlvl_nhwc")
         if ra:
             gbs = ra["bytes"] / (ra["ms"] * 1e-3) / 1e9
             roofline["roi_align"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                      "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(ra["bytes"]),
-                                     "avg_launch_us": round(1e3 * ra["ms"] / ra["calls"], 2)}
+                                     "avg_launch_us": round(1e3 * ra["ms"] / ra["calls"], 2),
+                                     "traffic": (pmc["roi_align_mlvl_nhwc"]["read"] + pmc["roi_align_mlvl_nhwc"]["write"])
+                                     if "roi_align_mlvl_nhwc" in pmc else None}
+
+    decode = None
+    if rank == 0 and args.decode_tokens > 0:
+        # configs[1] continues with greedy decode from the KV cache; reported beside the headline,
+        # never inside it (weight-streaming bound: 13.5 GB of bf16 weights per token)
+        lg = model(input_ids=prompt, images=image, bboxes=boxes, all_logits=False)
+        nxt = K.argmax_rows(lg.view(1, -1))
+        for _ in range(2):
+            lg = model.llama.forward(model.llama.embed[nxt].view(1, 1, -1), all_logits=False)
+            nxt = K.argmax_rows(lg.view(1, -1))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.decode_tokens):
+            lg = model.llama.forward(model.llama.embed[nxt].view(1, 1, -1), all_logits=False)
+            nxt = K.argmax_rows(lg.view(1, -1))
+        torch.cuda.synchronize()
+        dtd = (time.perf_counter() - t0) / args.decode_tokens
+        wbytes = sum(L[k].numel() * 2 for L in model.llama.layers for k in ("wqkv", "wo", "wgu", "wd")) + model.llama.lm_head.numel() * 2
+        decode = {"ms_per_token": round(1e3 * dtd, 3), "tokens_per_s": round(1.0 / dtd, 1),
+                  "weight_stream_GBps": round(wbytes / dtd / 1e9, 1), "note": "eager launches, batch 1, KV cache"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -197,7 +232,7 @@ def main():
                        "image_size": args.image_size, "rois_per_image": args.rois, "prompt_tokens": int(prompt.size(1)),
                        "parallelism": f"replicas x{world} (no data-path collective)",
                        "valid": args.llama_layers == 32 and args.image_size == 336 and args.rois == 32},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -51,8 +51,8 @@ struct GemmArgs {
 constexpr int BK = 64;
 
 // waves per SIMD the kernel is allowed to assume = workgroups that fit the 160 KB LDS (<= 3)
-constexpr int gemm_waves_per_eu(int bm, int bn, int nw, int stages) {
-  int blocks = (160 * 1024) / (stages * (bm + bn) * BK * 2);
+constexpr int gemm_waves_per_eu(int bm, int bn, int nw, int stages, int bk) {
+  int blocks = (160 * 1024) / (stages * (bm + bn) * bk * 2);
   if (blocks > 3) blocks = 3;
   if (blocks < 1) blocks = 1;
   int w = blocks * nw / 4;
@@ -71,17 +71,24 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // STAGES >= 3: ring of LDS buffers, STAGES-1 tiles of LDS-DMA in flight, counted s_waitcnt vmcnt
 //              (never 0 in steady state) + raw s_barrier, fragments double-buffered in registers;
 //              one workgroup per CU owns most of the 160 KB LDS.
-template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS, int STAGES>
-__global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_eu(BM, BN, WM * WN, STAGES))
+// BKT = K depth of one staged tile (64, or 32: half the LDS per stage -> more co-resident workgroups
+// or a deeper ring at the same footprint).
+template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS, int STAGES, int BKT>
+__global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_eu(BM, BN, WM * WN, STAGES, BKT))
 void gemm_bf16_nt_kernel(GemmArgs p) {
   constexpr int NW = WM * WN;
   constexpr int NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 accumulators per wave
-  constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;  // 16-B slots staged per thread
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int ROWB = BKT * 2;          // bytes per tile row
+  constexpr int SPR = BKT / 8;           // 16-B slots per tile row
+  constexpr int KK = BKT / 16;           // MFMA k-steps per tile
+  constexpr int NA = BM * SPR / NT, NB = BN * SPR / NT;  // 16-B slots staged per thread
+  constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+  static_assert(BM * SPR % NT == 0 && BN * SPR % NT == 0, "tile/threads mismatch");
+  // bank-conflict swizzle of the 16-B slot index within a row (conflict-free ds_read_b128 lane groups)
+  auto swz = [](int row) { return BKT == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
   static_assert(STAGES == 2 || GLDS, "the deep pipeline needs LDS-DMA staging");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES * STAGE_BYTES
 
@@ -108,7 +115,7 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
   const int split = blockIdx.y;
   const int t_begin = split * p.tiles_per_split;
   int t_end = t_begin + p.tiles_per_split;
-  const int nt_total = p.K / BK;
+  const int nt_total = p.K / BKT;
   if (t_end > nt_total) t_end = nt_total;
 
   // ---- per-thread staging descriptors ----
@@ -118,8 +125,8 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int pslot = (j * NW + wave) * 64 + lane;
-    const int row = pslot >> 3, ps = pslot & 7;
-    const int kslot = ps ^ ((row >> 1) & 7);
+    const int row = pslot / SPR, ps = pslot % SPR;
+    const int kslot = ps ^ swz(row);
     int gm = m0 + row;
     if (gm > p.M - 1) gm = p.M - 1;
     if (AMODE == 0) {
@@ -136,8 +143,8 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int pslot = (j * NW + wave) * 64 + lane;
-    const int row = pslot >> 3, ps = pslot & 7;
-    const int kslot = ps ^ ((row >> 1) & 7);
+    const int row = pslot / SPR, ps = pslot % SPR;
+    const int kslot = ps ^ swz(row);
     int gn = n0 + row;
     if (gn > p.N - 1) gn = p.N - 1;
     b_src[j] = p.W + (size_t)gn * p.ldw + kslot * 8;
@@ -146,16 +153,16 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
   auto stage = [&](int t, int buf) {
     char* sa = smem + buf * STAGE_BYTES;
     char* sb = sa + A_BYTES;
-    const int k0 = t * BK;
+    const int k0 = t * BKT;
     // A operand
     long a_off;
     int dy = 0, dx = 0;
     if (AMODE == 0) {
       a_off = k0;
     } else {
-      const int per_tap = p.Cin / BK;           // K tiles per tap
+      const int per_tap = p.Cin / BKT;          // K tiles per tap
       const int tap_lin = t / per_tap;          // group * 9 + tap
-      const int c0 = (t - tap_lin * per_tap) * BK;
+      const int c0 = (t - tap_lin * per_tap) * BKT;
       const int grp = tap_lin / 9, tap = tap_lin - grp * 9;
       dy = tap / 3 - 1;
       dx = tap - (tap / 3) * 3 - 1;
@@ -163,6 +170,7 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
     }
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
+      if (p.dbg == 3 && t != t_begin) break;  // ablation: A staged once, W keeps streaming
       const bf16_t* src = a_src[j] + a_off;
       if (AMODE == 1) {
         const int yy = a_y[j] + dy, xx = a_x[j] + dx;
@@ -178,6 +186,7 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+      if (p.dbg == 5 && t != t_begin) break;  // ablation: W staged once, A keeps streaming
       const bf16_t* src = b_src[j] + k0;
       char* dst_wave = sb + (j * NW + wave) * 1024;
       if (GLDS) {
@@ -199,28 +208,28 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
 
   // fragment read offsets: row = base + (lane & 31), 16-B slot = (kk*2 + (lane>>5)) ^ ((row>>1)&7)
   const int frow = lane & 31;
-  const int fsw = (frow >> 1) & 7;
+  const int fsw = swz(frow);
   const int fhi = lane >> 5;
-  const int a_row_off = (wm * WTM + frow) * 128;
-  const int b_row_off = (wn * WTN + frow) * 128;
+  const int a_row_off = (wm * WTM + frow) * ROWB;
+  const int b_row_off = (wn * WTN + frow) * ROWB;
 
   auto compute = [&](int buf) {
     const char* sa = smem + buf * STAGE_BYTES;
     const char* sb = sa + A_BYTES;
-    if constexpr (STAGES == 2) {
+    if constexpr (STAGES * (BM + BN) * BKT * 2 <= 80 * 1024) {
       // 2-3 co-resident workgroups per CU: let the compiler interleave the 4 reads and 4 MFMAs of
       // each k-step (few VGPRs -> more waves).  Measured on MI355X: faster end to end than
       // issuing all 16 reads first (tools/gemm_ablate.py; DESIGN.md "GEMM experiments").
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < KK; ++kk) {
         const int slot = ((kk * 2 + fhi) ^ fsw) << 4;
         bf16x8 af[TM], wf[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          af[i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * 128 + slot);
+          af[i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + slot);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * 128 + slot);
+          wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -229,20 +238,20 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
       }
     } else {
       // one workgroup per CU: request every fragment of the K tile up front, then one MFMA burst
-      bf16x8 af[4][TM], wf[4][TN];
+      bf16x8 af[KK][TM], wf[KK][TN];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < KK; ++kk) {
         const int slot = ((kk * 2 + fhi) ^ fsw) << 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          af[kk][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * 128 + slot);
+          af[kk][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + slot);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          wf[kk][j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * 128 + slot);
+          wf[kk][j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the burst
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+      for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -456,12 +465,19 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restr
   }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS, int STAGES = 2>
+template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS, int STAGES = 2, int BKT = 64>
 int launch_tile(GemmArgs& p, hipStream_t stream) {
+  {  // split-K geometry in units of this kernel's K tile
+    const int nt = p.K / BKT;
+    int splits = p.splits < 1 ? 1 : p.splits;
+    if (splits > nt) splits = nt;
+    p.tiles_per_split = g4r_ceil_div(nt, splits);
+    p.splits = g4r_ceil_div(nt, p.tiles_per_split);
+  }
   p.tiles_m = g4r_ceil_div(p.M, BM);
   p.tiles_n = g4r_ceil_div(p.N, BN);
-  const size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
-  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, AMODE, GLDS, STAGES>;
+  const size_t lds = (size_t)STAGES * (BM + BN) * BKT * 2;
+  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, AMODE, GLDS, STAGES, BKT>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -496,6 +512,10 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 9: return launch_tile<256, 256, 2, 4, AMODE, true, 2>(p, stream);   // 128 KB, wave tile 128x64
     case 10: return launch_tile<128, 128, 2, 4, AMODE, true, 2>(p, stream);  // 8 waves x (64x32), 2 wg/CU
     case 11: return launch_tile<128, 64, 2, 2, AMODE, true, 2>(p, stream);   // 48 KB: 3 wg/CU
+    case 12: return launch_tile<128, 128, 2, 2, AMODE, true, 3, 32>(p, stream);  // BK 32 ring: 48 KB, 3 wg/CU
+    case 13: return launch_tile<128, 128, 2, 2, AMODE, true, 4, 32>(p, stream);  // BK 32 ring: 64 KB, 2 wg/CU
+    case 14: return launch_tile<128, 128, 2, 2, AMODE, true, 2, 32>(p, stream);  // BK 32 2-stage: 32 KB, 4 wg/CU
+    case 15: return launch_tile<256, 128, 4, 2, AMODE, true, 3, 32>(p, stream);  // BK 32 ring: 72 KB, 2 wg/CU x 8 waves
     default: return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");
   }
 }
@@ -538,10 +558,7 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.act = act; p.out_f32 = out_f32; p.dbg = g_gemm_dbg;
   p.n_fastest = (long)M * 1 > (long)N * 2;
-  const int nt = K / BK;
-  if (splits > nt) splits = nt;
-  p.tiles_per_split = g4r_ceil_div(nt, splits);
-  p.splits = g4r_ceil_div(nt, p.tiles_per_split);
+  p.splits = splits;
   return launch_gemm<0>(p, tile_cfg, (hipStream_t)stream);
 }
 
@@ -563,10 +580,7 @@ int g4r_conv3x3_nhwc_bf16(const void* X, const void* W, void* Y, const float* bi
   p.act = act; p.out_f32 = out_f32;
   p.H = H; p.Wd = Wd; p.Cin = Cin; p.groups = groups; p.a_group_stride = x_group_stride;
   p.n_fastest = 1; p.dbg = g_gemm_dbg;
-  const int nt = p.K / BK;
-  if (splits > nt) splits = nt;
-  p.tiles_per_split = g4r_ceil_div(nt, splits);
-  p.splits = g4r_ceil_div(nt, p.tiles_per_split);
+  p.splits = splits;
   return launch_gemm<1>(p, tile_cfg, (hipStream_t)stream);
 }
 

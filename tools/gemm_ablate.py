@@ -16,14 +16,15 @@ def timeit(fn, iters=10, warm=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e-3
 lib = _lib.lib()
-for (M, N, Kd) in [(4096, 4096, 4096), (768, 12288, 4096), (768, 22016, 4096)]:
+for (M, N, Kd) in [(768, 10880, 4096), (768, 12288, 4096), (768, 22016, 4096), (768, 4096, 4096), (768, 4096, 11008), (4096, 4096, 4096)]:
     a, w = R(M, Kd), R(N, Kd)
-    for tile in (0, 4, 10, 11):
+    for tile in (0, 12, 13, 14, 15):
         row = []
         for mode in (0, 1, 2):
             lib.g4r_gemm_debug_mode(mode)
             t = timeit(lambda: K.gemm(a, w, tile_cfg=tile))
-            row.append(f"{['full','mfma-only','loads-only'][mode]} {t*1e6:7.1f}us {2.0*M*N*Kd/t/1e12:7.1f}TF")
+            name = {0: 'full', 1: 'mfma-only', 2: 'loads-only', 3: 'W-only', 5: 'A-only'}[mode]
+            row.append(f"{name} {t*1e6:7.1f}us {2.0*M*N*Kd/t/1e12:7.1f}TF")
         lib.g4r_gemm_debug_mode(0)
         print(f"{M}x{N}x{Kd} tile{tile}: " + " | ".join(row), flush=True)
 x = R(1, 192, 192, 1024); w = R(1024, 9 * 1024)
