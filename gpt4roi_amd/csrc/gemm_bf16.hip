@@ -73,7 +73,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 //              one workgroup per CU owns most of the 160 KB LDS.
 // BKT = K depth of one staged tile (64, or 32: half the LDS per stage -> more co-resident workgroups
 // or a deeper ring at the same footprint).
-template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS, int STAGES, int BKT>
+template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS, int STAGES, int BKT, int STYLE>
 __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_eu(BM, BN, WM * WN, STAGES, BKT))
 void gemm_bf16_nt_kernel(GemmArgs p) {
   constexpr int NW = WM * WN;
@@ -216,7 +216,8 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
   auto compute = [&](int buf) {
     const char* sa = smem + buf * STAGE_BYTES;
     const char* sb = sa + A_BYTES;
-    if constexpr (STAGES * (BM + BN) * BKT * 2 <= 80 * 1024) {
+    // STYLE 0: by LDS footprint (interleaved when >= 2 workgroups fit a CU), 1: interleaved, 2: burst
+    if constexpr (STYLE == 1 || (STYLE == 0 && STAGES * (BM + BN) * BKT * 2 <= 80 * 1024)) {
       // 2-3 co-resident workgroups per CU: let the compiler interleave the 4 reads and 4 MFMAs of
       // each k-step (few VGPRs -> more waves).  Measured on MI355X: faster end to end than
       // issuing all 16 reads first (tools/gemm_ablate.py; DESIGN.md "GEMM experiments").
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restr
   }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS, int STAGES = 2, int BKT = 64>
+template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS, int STAGES = 2, int BKT = 64, int STYLE = 0>
 int launch_tile(GemmArgs& p, hipStream_t stream) {
   {  // split-K geometry in units of this kernel's K tile
     const int nt = p.K / BKT;
@@ -477,7 +478,7 @@ int launch_tile(GemmArgs& p, hipStream_t stream) {
   p.tiles_m = g4r_ceil_div(p.M, BM);
   p.tiles_n = g4r_ceil_div(p.N, BN);
   const size_t lds = (size_t)STAGES * (BM + BN) * BKT * 2;
-  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, AMODE, GLDS, STAGES, BKT>;
+  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, AMODE, GLDS, STAGES, BKT, STYLE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -516,6 +517,9 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 13: return launch_tile<128, 128, 2, 2, AMODE, true, 4, 32>(p, stream);  // BK 32 ring: 64 KB, 2 wg/CU
     case 14: return launch_tile<128, 128, 2, 2, AMODE, true, 2, 32>(p, stream);  // BK 32 2-stage: 32 KB, 4 wg/CU
     case 15: return launch_tile<256, 128, 4, 2, AMODE, true, 3, 32>(p, stream);  // BK 32 ring: 72 KB, 2 wg/CU x 8 waves
+    case 16: return launch_tile<128, 128, 2, 4, AMODE, true, 3, 64, 1>(p, stream);  // 8-wave ring, interleaved reads
+    case 17: return launch_tile<128, 128, 2, 2, AMODE, true, 3, 64, 1>(p, stream);  // 4-wave ring, interleaved reads
+    case 18: return launch_tile<256, 128, 4, 2, AMODE, true, 3, 64, 1>(p, stream);  // 256x128 ring, interleaved reads
     default: return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");
   }
 }

@@ -127,6 +127,30 @@ class MLVLFuseModule(nn.Module):
         return maps, affs
 
 
+class PreparedBoxes:
+    """Host-side preparation of a request's boxes, done ONCE outside the launch sequence so that the
+    per-image kernel sequence has no host<->device traffic and can be captured in a hipGraph:
+    the [img_id, box * image_size] RoI table of layers.py:295-302, the raw normalised boxes for
+    pos_embedd (layers.py:284-285), the per-image counts and their prefix sums (for the splice)."""
+
+    def __init__(self, bboxes, image_size, device):
+        self.counts = [int(b.size(0)) for b in bboxes]
+        self.num_imgs = len(bboxes)
+        n = sum(self.counts)
+        src = bboxes[0].device if self.num_imgs else torch.device("cpu")
+        boxes = torch.cat([b.detach().float() for b in bboxes], 0) if n else torch.zeros(0, 4, device=src)
+        img_id = torch.cat([torch.full((c,), float(i), device=src) for i, c in enumerate(self.counts)]) \
+            if self.num_imgs else torch.zeros(0, device=src)
+        self.rois5 = torch.cat([img_id[:, None], boxes * float(image_size)], 1).contiguous().to(device)
+        self.boxes_bf16 = boxes.to(torch.bfloat16).to(device)
+        off = [0]
+        for c in self.counts:
+            off.append(off[-1] + c)
+        self.offsets = torch.tensor(off, dtype=torch.int32, device=device)
+        self.image_size = image_size
+        self.n = n
+
+
 class BaseRoIExtractor(nn.Module):
     """mmdet BaseRoIExtractor.build_roi_layers (base_roi_extractor.py:37-60): one RoIAlign per
     stride, resolved here to gpt4roi_amd.roi_align.RoIAlign instead of `getattr(mmcv.ops, ...)`."""
@@ -191,27 +215,24 @@ class MlvlRoIExtractor(BaseRoIExtractor):
                                ln5=ln(self.pos_embedd[5]), up=lin(self.updims))
 
     def forward(self, feats, rois, roi_scale_factor=None, affines=None, image_size=224):
-        """feats: list of NHWC bf16 maps [B,H_l,W_l,C]; rois: list[B] of [n_i,4] normalised xyxy;
+        """feats: list of NHWC bf16 maps [B,H_l,W_l,C]; rois: list[B] of [n_i,4] normalised xyxy (or a
+        PreparedBoxes built for `image_size`);
         affines: deferred GN+ReLU per level (from MLVLFuseModule.forward) or None."""
         if self._ready is None:
             self.prepare()
         r = self._ready
         dev = feats[0].device
-        num_imgs = len(rois)
-        counts = [int(b.size(0)) for b in rois]
-        batch_rois = torch.cat([b.to(dev) for b in rois], 0).float()
-        N = batch_rois.size(0)
+        prep = rois if isinstance(rois, PreparedBoxes) else PreparedBoxes(rois, image_size, dev)
+        num_imgs, counts, N = prep.num_imgs, prep.counts, prep.n
         out_dims = self.updims.out_features
         if N == 0:
             return [feats[0].new_zeros((0, out_dims)) for _ in range(num_imgs)]
         # pos_embedd(cat(bboxes)) on the raw normalised boxes (layers.py:284-285)
-        pe = K.gemm(batch_rois.to(torch.bfloat16), r['pe0'][0], bias=r['pe0'][1], act='relu')
+        pe = K.gemm(prep.boxes_bf16, r['pe0'][0], bias=r['pe0'][1], act='relu')
         pe = K.layernorm(pe, r['ln2'][0], r['ln2'][1], r['ln2'][2])
         pe = K.gemm(pe, r['pe3'][0], bias=r['pe3'][1], act='relu')
         pe = K.layernorm(pe, r['ln5'][0], r['ln5'][1], r['ln5'][2])
-        # rois = [img_id, box * image_size]  (layers.py:295-302; 224 in the reference)
-        img_id = torch.repeat_interleave(torch.arange(num_imgs, device=dev), torch.tensor(counts, device=dev))
-        rois5 = torch.cat([img_id[:, None].float(), batch_rois * float(image_size)], 1).contiguous()
+        rois5 = prep.rois5                               # [img_id, box * image_size], layers.py:295-302
         rl = self.roi_layers[0]
         roi_feats = K.roi_align_mlvl(feats, rois5, rl.output_size, [l.spatial_scale for l in self.roi_layers],
                                      sampling_ratio=rl.sampling_ratio, aligned=rl.aligned, affines=affines)
@@ -259,4 +280,6 @@ class MLVLROIQueryModule(nn.Module):
         n = len(toks)
         sizes = [P * 2 ** l for l in range(n)][::-1]          # level 0 (shallowest ViT layer) is finest
         maps, affs = self.mlvl_fuse(toks, P, sizes)
+        if isinstance(bboxes, PreparedBoxes):
+            assert bboxes.image_size == 14 * P, "PreparedBoxes built for another image size"
         return self.roi_align(maps, bboxes, affines=affs, image_size=14 * P)

@@ -237,6 +237,68 @@ def test_end_to_end_batch_of_two_ragged_regions():
         assert relerr(both[b], one[0]) < 1.5e-2, b
 
 
+def test_two_request_contexts_on_two_streams_are_bit_identical():
+    """clone_context(): shared weights, private KV cache; interleaving two requests on two HIP streams
+    must not change either result (bench.py's default mode)."""
+    H, P, image = 512, 8, 112
+    ids = syn.token_ids(vocab_base=990)
+    tower = ClipVisionTower(syn.vit_state(H, 4 * H, 12, image, seed=8), heads=8, device=DEV)
+    dec = LlamaDecoder(syn.llama_state(512, 1408, 2, ids.vocab, seed=9), heads=4, max_positions=256, device=DEV)
+    a = SPILlavaLlamaModel(tower, dec, ids, embed_dims=H)
+    a.spi_module.load_state_dict(syn.spi_state(a.spi_module, 3))
+    a.prepare()
+    b = a.clone_context()
+    assert b.llama.kc.data_ptr() != a.llama.kc.data_ptr() and b.llama.layers is a.llama.layers
+    g = torch.Generator().manual_seed(14)
+    reqs = []
+    for n in (3, 1):
+        reqs.append((syn.prompt_ids(ids, P, n, g, sys_len=4, question_len=6 + 4 * (3 - n), vocab_base=990)[None].to(DEV),
+                     torch.randn(1, 3, image, image, generator=g).to(DEV), [syn.boxes(n, g).to(DEV)]))
+    want = [a(input_ids=p, images=im, bboxes=bx).clone() for p, im, bx in reqs]
+    torch.cuda.synchronize()
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    got = [None, None]
+    for rep in range(3):
+        with torch.cuda.stream(s0):
+            got[0] = a(input_ids=reqs[0][0], images=reqs[0][1], bboxes=reqs[0][2])
+        with torch.cuda.stream(s1):
+            got[1] = b(input_ids=reqs[1][0], images=reqs[1][1], bboxes=reqs[1][2])
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+def test_forward_is_hipgraph_capturable_with_prepared_boxes():
+    """With PreparedBoxes the launch sequence has no host<->device traffic: capture it once, replay it
+    with new image / token contents in the static input buffers, and get the eager result."""
+    H, P, image = 512, 8, 112
+    ids = syn.token_ids(vocab_base=990)
+    tower = ClipVisionTower(syn.vit_state(H, 4 * H, 12, image, seed=8), heads=8, device=DEV)
+    dec = LlamaDecoder(syn.llama_state(512, 1408, 2, ids.vocab, seed=9), heads=4, max_positions=256, device=DEV)
+    m = SPILlavaLlamaModel(tower, dec, ids, embed_dims=H)
+    m.spi_module.load_state_dict(syn.spi_state(m.spi_module, 3))
+    g = torch.Generator().manual_seed(15)
+    img = torch.randn(1, 3, image, image, generator=g).to(DEV)
+    prompt = syn.prompt_ids(ids, P, 2, g, sys_len=4, question_len=5, vocab_base=990)[None].to(DEV)
+    req = m.prepare_boxes([syn.boxes(2, g)], image)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        m(input_ids=prompt, images=img, bboxes=req)
+        m(input_ids=prompt, images=img, bboxes=req)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=st):
+        out = m(input_ids=prompt, images=img, bboxes=req)
+    # new request contents in the same buffers
+    img.copy_(torch.randn(1, 3, image, image, generator=g))
+    prompt[0, -3:] = torch.tensor([17, 23, 5], device=DEV)
+    with torch.cuda.stream(st):
+        graph.replay()
+    torch.cuda.synchronize()
+    want = m(input_ids=prompt, images=img, bboxes=req)
+    assert torch.equal(out, want)
+    m.check_status()
+
+
 def test_malformed_prompt_raises_like_the_reference():
     ids = syn.token_ids(vocab_base=990)
     vsd = syn.vit_state(256, 1024, 12, 112, seed=8)
