@@ -33,6 +33,7 @@ struct AttnArgs {
   int Tq, Tk, H;
   float scale;
   int causal;                            // query i sees keys <= i + (Tk - Tq)
+  const int* kv_len_dev;                 // optional: Tk = *kv_len_dev + Tq, read on the device (graph-replayed decode)
 };
 
 template <int D>
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p) 
   constexpr int NK = KVB * SLOTS / NT;    // K slots staged per thread
   constexpr int NVU = 16 * SLOTS / NT;    // V units (4 keys x one 8-wide d slot) per thread
   static_assert(KVB * SLOTS % NT == 0 && 16 * SLOTS % NT == 0, "staging split");
+  if (p.kv_len_dev) p.Tk = *p.kv_len_dev + p.Tq;  // cached positions before this call + the new rows
   __shared__ __attribute__((aligned(16))) bf16_t Ks[KVB * D];
   __shared__ __attribute__((aligned(16))) bf16_t Vt[D * VT_LD];
 
@@ -251,7 +253,8 @@ extern "C" {
 // elements (multiples of 8).  head_dim 64 or 128.  causal: query i attends keys <= i + (Tk - Tq).
 int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
                             int head_dim, long q_row, long k_row, long v_row, long o_row, long q_batch,
-                            long k_batch, long v_batch, long o_batch, float scale, int causal, void* stream) {
+                            long k_batch, long v_batch, long o_batch, float scale, int causal,
+                            const int* kv_len_dev, void* stream) {
   G4R_REQUIRE(B > 0 && H > 0 && Tq >= 0 && Tk > 0, "flash_attn: bad shape");
   G4R_REQUIRE(head_dim == 64 || head_dim == 128, "flash_attn: head_dim must be 64 or 128");
   if (Tq == 0) return G4R_OK;
@@ -261,7 +264,7 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
               "flash_attn: strides must keep 16-byte alignment");
   G4R_REQUIRE(!causal || Tk >= Tq, "flash_attn: causal needs Tk >= Tq");
   AttnArgs a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_row, k_row, v_row, o_row,
-                q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal};
+                q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal, kv_len_dev};
   // 64 query rows per workgroup (2 waves): ~2x the workgroups of a 128-row block for the short
   // sequences of this path (577 / ~800 tokens) and finer causal load balance
   if (head_dim == 64) {

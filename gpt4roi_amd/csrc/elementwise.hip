@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(const bf16_t* __restrict_
                                                        bf16_t* __restrict__ qout,
                                                        bf16_t* __restrict__ kcache,
                                                        bf16_t* __restrict__ vcache, int T, int Hh, int D,
-                                                       int pos0) {
+                                                       int pos0, const int* __restrict__ pos_dev) {
+  if (pos_dev) pos0 = *pos_dev;  // decode loop replayed from a hipGraph: the position lives on the device
   const int half = D >> 1;
   const int hv = half >> 3;  // 8-wide vectors per half head
   const long total = (long)T * Hh * hv;
@@ -425,6 +426,47 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   if (threadIdx.x == 0) out[blockIdx.x] = bi[0];
 }
 
+// Device-side greedy step (generate(do_sample=False), llava.py:263-283 feeds only the last token):
+// tok = argmax(logits[0, :N]); out_ids[*step] = tok; ++*step; ++*pos.  Everything stays on the GPU so
+// the whole decode step can be replayed from a hipGraph; the host reads out_ids when it wants to.
+__global__ __launch_bounds__(256) void greedy_advance_kernel(const float* __restrict__ logits, int N,
+                                                             long* __restrict__ tok, long* __restrict__ out_ids,
+                                                             int* __restrict__ step, int* __restrict__ pos,
+                                                             int max_steps) {
+  __shared__ float bv[256];
+  __shared__ int bi[256];
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float v = logits[i];
+    if (v > best || (v == best && i < idx)) {
+      best = v;
+      idx = i;
+    }
+  }
+  bv[threadIdx.x] = best;
+  bi[threadIdx.x] = idx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float v = bv[threadIdx.x + s];
+      const int i = bi[threadIdx.x + s];
+      if (v > bv[threadIdx.x] || (v == bv[threadIdx.x] && i < bi[threadIdx.x])) {
+        bv[threadIdx.x] = v;
+        bi[threadIdx.x] = i;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int st = *step;
+    tok[0] = bi[0];
+    if (st < max_steps) out_ids[st] = bi[0];
+    *step = st + 1;
+    *pos = *pos + 1;
+  }
+}
+
 // y[i] = a[i] + b[row(i) % brows]  (bf16; used for "+ pos_embedd" style adds), C % 8 == 0
 __global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ a,
                                                        const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
@@ -512,14 +554,14 @@ int g4r_vit_assemble_bf16(const void* patch, const void* cls, const void* pos, v
 }
 
 int g4r_rope_qkv_bf16(const void* qkv, const float* cos_tab, const float* sin_tab, void* q_out, void* k_cache,
-                      void* v_cache, int T, int heads, int head_dim, int pos0, void* stream) {
+                      void* v_cache, int T, int heads, int head_dim, int pos0, const int* pos_dev, void* stream) {
   G4R_REQUIRE(T >= 0 && heads > 0 && head_dim % 16 == 0 && pos0 >= 0, "rope_qkv: bad shape");
   if (T == 0) return G4R_OK;
   G4R_REQUIRE(qkv && cos_tab && sin_tab && q_out && k_cache && v_cache, "rope_qkv: null pointer");
   const long total = (long)T * heads * (head_dim / 16);
   hipLaunchKernelGGL(rope_qkv_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)qkv, cos_tab, sin_tab, (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache, T,
-                     heads, head_dim, pos0);
+                     heads, head_dim, pos0, pos_dev);
   G4R_CHECK_LAUNCH("rope_qkv");
   return G4R_OK;
 }
@@ -557,6 +599,16 @@ int g4r_argmax_rows_f32(const float* logits, long ld, int rows, int N, long* out
   G4R_REQUIRE(logits && out, "argmax_rows: null pointer");
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ld, N, out);
   G4R_CHECK_LAUNCH("argmax_rows");
+  return G4R_OK;
+}
+
+int g4r_greedy_advance_f32(const float* logits, int N, long* tok, long* out_ids, int* step, int* pos,
+                           int max_steps, void* stream) {
+  G4R_REQUIRE(N > 0 && max_steps >= 0, "greedy_advance: bad shape");
+  G4R_REQUIRE(logits && tok && out_ids && step && pos, "greedy_advance: null pointer");
+  hipLaunchKernelGGL(greedy_advance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, N, tok, out_ids,
+                     step, pos, max_steps);
+  G4R_CHECK_LAUNCH("greedy_advance");
   return G4R_OK;
 }
 

@@ -466,6 +466,71 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// GEMV for the single-token decode step (M = 1): pure weight streaming, HBM-bound (13.5 GB of bf16
+// LLaMA-7B weights per token).  One wave owns 4 consecutive W rows; lanes split K in 16-byte
+// pieces (one coalesced 1 KiB load per row per step, 4 rows in flight), fp32 accumulate, shuffle
+// reduction.  Same epilogues as the GEMM (bias, residual, SwiGLU over interleaved row pairs, fp32 out).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot8_bf16(const uint4v& a, const uint4v& b, float acc) {
+  acc += bf16lo(a.x) * bf16lo(b.x); acc += bf16hi(a.x) * bf16hi(b.x);
+  acc += bf16lo(a.y) * bf16lo(b.y); acc += bf16hi(a.y) * bf16hi(b.y);
+  acc += bf16lo(a.z) * bf16lo(b.z); acc += bf16hi(a.z) * bf16hi(b.z);
+  acc += bf16lo(a.w) * bf16lo(b.w); acc += bf16hi(a.w) * bf16hi(b.w);
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
+                                                        void* __restrict__ C, const float* __restrict__ bias,
+                                                        const bf16_t* __restrict__ residual, int N, int K, int ldw,
+                                                        int act, int out_f32) {
+  constexpr int R = 4;
+  const int lane = threadIdx.x & 63;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (n0 >= N) return;
+  float acc[R] = {0.f, 0.f, 0.f, 0.f};
+  const bf16_t* wrow[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) wrow[r] = W + (size_t)(n0 + r < N ? n0 + r : N - 1) * ldw;
+  for (int k0 = lane * 8; k0 < K; k0 += 512) {
+    const uint4v xv = *reinterpret_cast<const uint4v*>(x + k0);
+    uint4v wv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(wrow[r] + k0));
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = dot8_bf16(xv, wv[r], acc[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o);
+  if (lane != 0) return;
+  if (act == 4) {  // rows are (gate, up) pairs
+#pragma unroll
+    for (int r = 0; r < R; r += 2) {
+      if (n0 + r + 1 < N) {
+        const float g = acc[r], u = acc[r + 1];
+        const float sg = bf16lo(pack_bf16x2(g / (1.f + __expf(-g)), 0.f));
+        reinterpret_cast<bf16_t*>(C)[(n0 + r) >> 1] = f32_to_bf16(sg * u);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int n = n0 + r;
+    if (n >= N) break;
+    float v = acc[r];
+    if (bias) v += bias[n];
+    v = apply_act(v, act);
+    if (residual) v += bf16_to_f32(residual[n]);
+    if (out_f32)
+      reinterpret_cast<float*>(C)[n] = v;
+    else
+      reinterpret_cast<bf16_t*>(C)[n] = f32_to_bf16(v);
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS, int STAGES = 2, int BKT = 64, int STYLE = 0>
 int launch_tile(GemmArgs& p, hipStream_t stream) {
   {  // split-K geometry in units of this kernel's K tile
@@ -543,6 +608,14 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
   G4R_REQUIRE(act >= 0 && act <= 4, "gemm: act must be 0..4");
   G4R_REQUIRE(act != 4 || (N % 4 == 0 && ldc % 2 == 0 && splits == 1 && !residual && !bias && !out_f32 && K % BK == 0),
               "gemm: swiglu epilogue needs N % 4 == 0, bf16 output, no bias/residual/split-K");
+  if (M == 1 && K % 8 == 0 && (ldw % 8) == 0 && splits == 1 && K >= 512 && (act != 4 || N % 4 == 0)) {
+    // single-token decode: weight-streaming GEMV
+    const int waves = g4r_ceil_div(N, 4);
+    hipLaunchKernelGGL(gemv_bf16_kernel, dim3(g4r_ceil_div(waves, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)A, (const bf16_t*)W, C, bias, (const bf16_t*)residual, N, K, ldw, act, out_f32);
+    G4R_CHECK_LAUNCH("gemv_bf16");
+    return G4R_OK;
+  }
   if (K % BK != 0 || K == 0) {
     G4R_REQUIRE(residual == nullptr, "gemm: residual unsupported on the small-K path");
     long total = (long)M * N;

@@ -18,7 +18,7 @@ _SIGS = {
     "g4r_conv3x3_nhwc_bf16": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_int,
                               c_int, c_int, c_int, P],
     "g4r_flash_attn_fwd_bf16": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long,
-                                c_long, c_long, c_long, c_long, c_float, c_int, P],
+                                c_long, c_long, c_long, c_long, c_float, c_int, P, P],
     "g4r_layernorm_bf16": [P, P, P, P, c_int, c_int, c_long, c_long, c_float, c_int, P],
     "g4r_rmsnorm_bf16": [P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "g4r_groupnorm_affine_nhwc_bf16": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
@@ -27,7 +27,8 @@ _SIGS = {
                                    c_int, P],
     "g4r_im2col_patch14_f32": [P, P, c_int, c_int, c_int, P],
     "g4r_vit_assemble_bf16": [P, P, P, P, c_int, c_int, c_int, P],
-    "g4r_rope_qkv_bf16": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "g4r_rope_qkv_bf16": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P],
+    "g4r_greedy_advance_f32": [P, c_int, P, P, P, P, c_int, P],
     "g4r_swiglu_bf16": [P, P, c_int, c_int, P],
     "g4r_splice_embed_bf16": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_long, c_long, c_long,
                               c_long, c_int, P],
@@ -175,7 +176,7 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
         assert residual.shape == (M, N) and residual.stride(1) == 1
     if tile_cfg is None:
         tile_cfg = pick_tile(M, N, K)
-        if splits == 1 and tile_cfg == 4 and K >= 2048 and K % 64 == 0:
+        if splits == 1 and tile_cfg == 4 and K >= 2048 and K % 64 == 0 and M > 1:
             # few tiles and a long K: split K so the grid covers the 256 CUs (e.g. ViT fc2 577x1024x4096)
             tiles = -(-M // 64) * -(-N // 128)
             if tiles < 160:
@@ -186,8 +187,9 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
         _p(a), _p(w), _p(out), _p(bias), _p(residual), _p(workspace), M, N, K, a.stride(0), w.stride(0),
         out.stride(0), residual.stride(0) if residual is not None else 0, ACT[act],
         1 if out.dtype == torch.float32 else 0, splits, tile_cfg, _stream(a),),
-        tag=(f"gemm_bf16_nt<{TILE_NAMES.get(tile_cfg, tile_cfg)}>" + ("+splitk" if splits > 1 else "")) if K % 64 == 0
-        else "small_linear", flops=2.0 * M * N * K, nbytes=2.0 * (M * K + N * K) + out.element_size() * M * N)
+        tag="gemv_bf16" if (M == 1 and splits == 1 and K >= 512 and K % 8 == 0) else
+        ((f"gemm_bf16_nt<{TILE_NAMES.get(tile_cfg, tile_cfg)}>" + ("+splitk" if splits > 1 else "")) if K % 64 == 0
+         else "small_linear"), flops=2.0 * M * N * K, nbytes=2.0 * (M * K + N * K) + out.element_size() * M * N)
     return out
 
 
@@ -232,7 +234,7 @@ def prep_conv3x3_weight(ws):
     return torch.cat(parts, 1).reshape(ws[0].size(0), -1).to(torch.bfloat16).contiguous()
 
 
-def flash_attn(q, k, v, heads, scale, causal=False, out=None):
+def flash_attn(q, k, v, heads, scale, causal=False, out=None, kv_len_dev=None):
     """q [B, Tq, heads*D], k/v [B, Tk, heads*D] (row-strided views allowed) -> [B, Tq, heads*D]."""
     _bf16(q, k, v)
     B, Tq, HD = q.shape
@@ -243,7 +245,8 @@ def flash_attn(q, k, v, heads, scale, causal=False, out=None):
         out = torch.empty((B, Tq, HD), dtype=torch.bfloat16, device=q.device)
     _launch("g4r_flash_attn_fwd_bf16", (
         _p(q), _p(k), _p(v), _p(out), B, heads, Tq, Tk, D, q.stride(1), k.stride(1), v.stride(1), out.stride(1),
-        q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), int(bool(causal)), _stream(q),),
+        q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), int(bool(causal)), _p(kv_len_dev),
+        _stream(q),),
         tag=f"flash_attn<{D}>", flops=4.0 * B * heads * Tq * Tk * D * (0.5 if causal and Tq == Tk else 1.0),
         nbytes=2.0 * B * HD * (2 * Tq + 2 * Tk))
     return out
@@ -333,13 +336,13 @@ def vit_assemble(patch, cls, pos, B):
     return tok
 
 
-def rope_qkv(qkv, cos, sin, q_out, k_cache, v_cache, heads, head_dim, pos0):
+def rope_qkv(qkv, cos, sin, q_out, k_cache, v_cache, heads, head_dim, pos0, pos_dev=None):
     _bf16(qkv, q_out, k_cache, v_cache)
     _f32(cos, sin)
     T = qkv.size(0)
     _launch("g4r_rope_qkv_bf16", (
         _p(qkv), _p(cos), _p(sin), _p(q_out), _p(k_cache), _p(v_cache), T, heads,
-                                  head_dim, pos0, _stream(qkv),))
+                                  head_dim, pos0, _p(pos_dev), _stream(qkv),))
 
 
 def interleave_gate_up(gate_w, up_w):
@@ -372,6 +375,15 @@ def splice_embed(ids, embed, img, spi, spi_offset, n_patch, patch_id, bbox_id, i
                                       B, T, C, n_patch if img is not None else 0, patch_id, bbox_id,
                                       im_start_id, im_end_id, embed.size(0), _stream(ids),))
     return out, status
+
+
+def greedy_advance(logits_row, tok, out_ids, step, pos):
+    """tok[0] = argmax(logits_row); out_ids[step[0]] = tok; step += 1; pos += 1 -- all on the device."""
+    _f32(logits_row)
+    _lib.require_gpu(tok, out_ids, step, pos)
+    assert tok.dtype == torch.int64 and out_ids.dtype == torch.int64 and step.dtype == torch.int32 and pos.dtype == torch.int32
+    _launch("g4r_greedy_advance_f32", (_p(logits_row), logits_row.numel(), _p(tok), _p(out_ids), _p(step), _p(pos),
+                                       out_ids.numel(), _stream(logits_row),))
 
 
 def argmax_rows(logits):

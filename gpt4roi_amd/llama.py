@@ -56,6 +56,7 @@ class LlamaDecoder:
         self.kc = torch.zeros((L, batch, self.max_positions, self.hidden), dtype=torch.bfloat16, device=self.device)
         self.vc = torch.zeros_like(self.kc)
         self.pos = 0
+        self._dstate = None            # a captured decode graph points into the old cache
 
     def reset(self, batch=1):
         if self.kc.size(1) < batch:
@@ -93,6 +94,82 @@ class LlamaDecoder:
             xn = xn[:, -1:, :].contiguous()
         logits = K.gemm(xn.reshape(-1, C), self.lm_head, out_dtype=torch.float32)
         return logits.view(B, -1, self.vocab)
+
+    # ---- device-resident greedy decode, one hipGraph replay per token ----------------------------
+    def _decode_state(self, max_new):
+        st = getattr(self, "_dstate", None)
+        if st is None or st["out"].numel() < max_new:
+            dev = self.device
+            st = dict(tok=torch.zeros((1, 1), dtype=torch.int64, device=dev),
+                      pos=torch.zeros(1, dtype=torch.int32, device=dev),
+                      step=torch.zeros(1, dtype=torch.int32, device=dev),
+                      out=torch.zeros(max(max_new, 64), dtype=torch.int64, device=dev), graph=None)
+            self._dstate = st
+        return st
+
+    def _decode_step_device(self, st):
+        """One token: embedding of st['tok'] at position st['pos'] -> 32 layers (K/V appended at *pos,
+        attention over *pos + 1 keys) -> logits -> argmax -> st['tok'], st['out'][step]; counters
+        advance on the device.  No host value enters the launch sequence."""
+        C, H, D = self.hidden, self.heads, self.head_dim
+        x, _ = K.splice_embed(st["tok"], self.embed, None, None, None, 0, -1, -1, -1, -1)
+        x = x.view(1, C)
+        scale = 1.0 / math.sqrt(D)
+        q = torch.empty((1, 1, C), dtype=torch.bfloat16, device=x.device)
+        for li, L in enumerate(self.layers):
+            h = K.rmsnorm(x, L['n1'], self.eps)
+            qkv = K.gemm(h, L['wqkv'])
+            K.rope_qkv(qkv, self.cos, self.sin, q[0], self.kc[li, 0], self.vc[li, 0], H, D, 0, pos_dev=st["pos"])
+            a = K.flash_attn(q, self.kc[li, :1], self.vc[li, :1], H, scale, True, kv_len_dev=st["pos"])
+            x = K.gemm(a.view(1, C), L['wo'], residual=x)
+            h = K.rmsnorm(x, L['n2'], self.eps)
+            f = K.gemm(h, L['wgu'], act="swiglu")
+            x = K.gemm(f, L['wd'], residual=x)
+        xn = K.rmsnorm(x, self.norm, self.eps)
+        logits = K.gemm(xn, self.lm_head, out_dtype=torch.float32)
+        K.greedy_advance(logits.view(-1), st["tok"], st["out"], st["step"], st["pos"])
+
+    @torch.no_grad()
+    def greedy_graph(self, inputs_embeds, max_new_tokens, stop_ids=(), check_every=32, use_graph=True):
+        """generate(do_sample=False) for batch 1 with the per-token loop on the device: prefill eagerly,
+        then replay one captured hipGraph per token (token id, position and output slot live in device
+        memory).  The host only looks at the ids every `check_every` tokens to honour `stop_ids`."""
+        assert inputs_embeds.size(0) == 1
+        self.reset(1)
+        logits = self.forward(inputs_embeds, all_logits=False)
+        T = self.pos
+        assert T + max_new_tokens <= self.max_positions
+        st = self._decode_state(max_new_tokens)
+        st["pos"].fill_(T - 1)
+        st["step"].zero_()
+        K.greedy_advance(logits.view(-1), st["tok"], st["out"], st["step"], st["pos"])   # token 1, pos -> T
+        done = 1
+        if max_new_tokens > 1:
+            self._decode_step_device(st)                                                # token 2 (also warms up)
+            done = 2
+        if use_graph and st["graph"] is None and max_new_tokens > 2:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            with torch.cuda.graph(g, stream=side):
+                self._decode_step_device(st)
+            st["graph"] = g
+        while done < max_new_tokens:
+            n = min(check_every, max_new_tokens - done)
+            for _ in range(n):
+                if use_graph and st["graph"] is not None:
+                    st["graph"].replay()
+                else:
+                    self._decode_step_device(st)
+            done += n
+            if stop_ids:
+                ids = st["out"][:done].tolist()
+                hit = [i for i, t in enumerate(ids) if t in stop_ids]
+                if hit:
+                    done = hit[0] + 1
+                    break
+        self.pos = T + done
+        return st["out"][:done].tolist()
 
     @torch.no_grad()
     def greedy(self, inputs_embeds, max_new_tokens, stop_ids=()):

@@ -54,11 +54,14 @@ int g4r_conv3x3_nhwc_bf16(const void* X, const void* W, void* Y, const float* bi
  * (llava/train/llama_flash_attn_monkey_patch.py:15-91).
  * Q [B, Tq, H*D], K/V [B, Tk, H*D], O [B, Tq, H*D] addressed through row / batch strides.
  * causal: query i attends keys <= i + (Tk - Tq)  (KV-cache decode when Tq < Tk).
+ * kv_len_dev (nullable): when set, Tk = *kv_len_dev + Tq is computed on the device (the argument Tk is then
+ * only an upper bound): *kv_len_dev = positions already cached before this call, so a decode step can be
+ * replayed from a hipGraph while the cache grows.
  */
 int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq,
                             int Tk, int head_dim, long q_row, long k_row, long v_row, long o_row,
                             long q_batch, long k_batch, long v_batch, long o_batch, float scale,
-                            int causal, void* stream);
+                            int causal, const int* kv_len_dev, void* stream);
 
 /* LayerNorm over the last dim (CLIP pre_layrnorm / layer_norm1,2; pos_embedd LayerNorms
  * gpt4roi/models/layers.py:260-267).  gamma/beta fp32.  relu_in: apply ReLU to x first. */
@@ -112,7 +115,7 @@ int g4r_vit_assemble_bf16(const void* patch, const void* cls, const void* pos, v
  * qkv [T, 3*heads*head_dim]; cos/sin [max_pos, head_dim/2] fp32; caches [max_pos, heads*head_dim]. */
 int g4r_rope_qkv_bf16(const void* qkv, const float* cos_tab, const float* sin_tab, void* q_out,
                       void* k_cache, void* v_cache, int T, int heads, int head_dim, int pos0,
-                      void* stream);
+                      const int* pos_dev /* nullable: position read from device memory */, void* stream);
 /* LLaMA MLP gate: out[T,F] = silu(gate_up[:, :F]) * gate_up[:, F:]. */
 int g4r_swiglu_bf16(const void* gate_up, void* out, int T, int F, void* stream);
 
@@ -128,6 +131,11 @@ int g4r_splice_embed_bf16(const long* ids, const void* embed, const void* img, c
                           int n_patch, long patch_id, long bbox_id, long im_start_id, long im_end_id,
                           int vocab, void* stream);
 
+/* Device-side greedy step: tok = argmax(logits[:N]); out_ids[*step] = tok; ++*step; ++*pos  (nothing
+ * returns to the host, so generate(do_sample=False)'s per-token loop -- llava.py:263-283, app.py:294-300
+ * with sampling off -- can be replayed from a hipGraph). */
+int g4r_greedy_advance_f32(const float* logits, int N, long* tok, long* out_ids, int* step, int* pos,
+                           int max_steps, void* stream);
 /* greedy decode: out[r] = argmax(logits[r, :N]) (lowest index on ties). */
 int g4r_argmax_rows_f32(const float* logits, long ld, int rows, int N, long* out, void* stream);
 /* y = a + b[row % brows]  ("fuse_roi_feats + pos_embedd", layers.py:328). */

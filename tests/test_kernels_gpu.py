@@ -196,6 +196,20 @@ def test_gemm_swiglu_epilogue():
         close(got, ref, 0.03, 2e-2, f"swiglu epilogue tile {tile}")
 
 
+def test_gemv_single_token_path():
+    """M = 1 takes the weight-streaming GEMV kernel (decode step); same epilogues as the GEMM."""
+    for N, Kd in ((4096, 4096), (12288, 4096), (4096, 11008), (1000, 512), (32006, 4096)):
+        a, w = rnd(1, Kd, seed=23), rnd(N, Kd, scale=0.05, seed=24)
+        ref = a.float() @ w.float().t()
+        close(K.gemm(a, w), ref, 0.03, 1e-2, f"gemv {N}x{Kd}")
+        close(K.gemm(a, w, out_dtype=torch.float32), ref, 2e-3, 1e-3, f"gemv f32 {N}x{Kd}")
+    a, w, res, bias = rnd(1, 1024, seed=25), rnd(512, 1024, scale=0.05, seed=26), rnd(1, 512, seed=27), rnd(512, seed=28, dtype=torch.float32)
+    close(K.gemm(a, w, bias=bias, residual=res), a.float() @ w.float().t() + bias + res.float(), 0.03, 1e-2, "gemv epilogue")
+    g, u = rnd(352, 1024, scale=0.05, seed=29), rnd(352, 1024, scale=0.05, seed=30)
+    ref = F.silu(a.float() @ g.float().t()).to(torch.bfloat16).float() * (a.float() @ u.float().t())
+    close(K.gemm(a, K.interleave_gate_up(g, u), act="swiglu"), ref, 0.02, 2e-2, "gemv swiglu")
+
+
 def test_gemm_strided_a_and_small_k():
     big = rnd(64, 3, 128, seed=7)
     a = big[:, 1, :]                      # row stride 384

@@ -144,6 +144,20 @@ def test_llama_prefill_decode_and_greedy_ids():
         pytest.fail(f"greedy ids diverge at step {k}: {got} vs {want_ids}; oracle top-2 margin {float(top2[0]-top2[1]):.2e}")
 
 
+def test_device_resident_greedy_decode_matches_host_loop():
+    """greedy_graph (token id / position on the device, one hipGraph replay per token) == greedy (host loop)."""
+    sd, dec = _mini_llama()
+    emb = bf(sd["model.embed_tokens.weight"])[torch.randint(0, 1000, (1, 21), generator=torch.Generator().manual_seed(16))]
+    emb = emb.to(DEV).to(torch.bfloat16)
+    want = dec.greedy(emb, 20)
+    assert dec.greedy_graph(emb, 20, use_graph=False) == want
+    assert dec.greedy_graph(emb, 20) == want
+    assert dec.greedy_graph(emb, 20) == want                      # second call reuses the captured graph
+    stop = want[7]
+    first = want.index(stop)
+    assert dec.greedy_graph(emb, 20, stop_ids=(stop,), check_every=4) == want[:first + 1]
+
+
 def test_llama_batch2_matches_batch1():
     sd, dec = _mini_llama(layers=2)
     dec.reset(2)
