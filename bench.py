@@ -130,12 +130,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the path has no CPU fallback")
+    # test hooks (not used by the driver): run >1 rank on a 1-GPU box over gloo to exercise this code path
+    backend = os.environ.get("G4R_DIST_BACKEND", "nccl")                  # "nccl" is RCCL on ROCm
+    if "G4R_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["G4R_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(device))   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
     from gpt4roi_amd import kernels as K
 
     model, ids = build_model(args, device, seed=100 + rank)
@@ -195,7 +202,7 @@ def main():
     seg0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     dt_local = replicas.timed_steps(step, args.steps, torch.cuda.synchronize, dist)
     device_allocs_in_timed_region = torch.cuda.memory_stats(device).get("num_device_alloc", 0) - seg0
-    _, dt = replicas.aggregate(args.rois * args.steps, dt_local, dist, device=device)
+    _, dt = replicas.aggregate(args.rois * args.steps, dt_local, dist, device=device if backend == "nccl" else "cpu")
     # the same K steps strictly serial on one stream (per-image latency), reported beside the headline
     serial_step()
     dt_serial = replicas.timed_steps(serial_step, args.steps, torch.cuda.synchronize, dist) if len(ctxs) > 1 else dt_local
