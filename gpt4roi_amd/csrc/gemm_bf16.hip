@@ -585,6 +585,9 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 16: return launch_tile<128, 128, 2, 4, AMODE, true, 3, 64, 1>(p, stream);  // 8-wave ring, interleaved reads
     case 17: return launch_tile<128, 128, 2, 2, AMODE, true, 3, 64, 1>(p, stream);  // 4-wave ring, interleaved reads
     case 18: return launch_tile<256, 128, 4, 2, AMODE, true, 3, 64, 1>(p, stream);  // 256x128 ring, interleaved reads
+    case 19: return launch_tile<256, 256, 2, 4, AMODE, true, 4, 32, 1>(p, stream);  // 256x256, BK 32 ring x4 (128 KB), interleaved
+    case 20: return launch_tile<256, 256, 2, 4, AMODE, true, 4, 32, 2>(p, stream);  // same, burst reads
+    case 21: return launch_tile<256, 256, 2, 4, AMODE, true, 3, 32, 1>(p, stream);  // 256x256, BK 32 ring x3 (96 KB)
     default: return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");
   }
 }
