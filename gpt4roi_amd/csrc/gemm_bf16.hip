@@ -66,6 +66,135 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
+// Shared epilogue.  acc[i][j] is the 32x32 accumulator of rows mw + 32*i.. and columns nw + 32*j..,
+// in the swapped-operand layout D[n][m]: this lane holds m = mw + 32*i and, per register quad q,
+// the 4 consecutive columns nw + 32*j + 8*q .. +3 (mw / nw already include the lane offsets).
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float16v (&acc)[TM][TN], int mw, int nw,
+                                              int split) {
+  const bool vec_ok = (p.N & 3) == 0;  // then every in-range quad is a full, aligned quad
+  if (p.splits > 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = mw + i * 32, n = nw + j * 32 + q * 8;
+          if (m < p.M && n < p.N) {
+            float* dst = p.ws + ((size_t)split * p.M + m) * p.N + n;
+            if (vec_ok) {
+              *reinterpret_cast<float4v*>(dst) = float4v{acc[i][j][q * 4], acc[i][j][q * 4 + 1],
+                                                         acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) dst[r] = acc[i][j][q * 4 + r];
+            }
+          }
+        }
+    return;
+  }
+  // One 32x32 accumulator at a time (keeps the live range of epilogue temporaries short):
+  // bias (16-B loads) -> activation (wave-uniform branch) -> residual add -> packed store.
+  const bool res_vec = vec_ok && (p.ldr & 3) == 0;
+  const bool out_vec = vec_ok && (p.ldc & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float16v c = acc[i][j];
+      const int m = mw + i * 32;
+      if (p.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nw + j * 32 + q * 8;
+          float4v b = {0.f, 0.f, 0.f, 0.f};
+          if (n < p.N) {
+            if (vec_ok) {
+              b = *reinterpret_cast<const float4v*>(p.bias + n);
+            } else {
+              b.x = p.bias[n];
+              if (n + 1 < p.N) b.y = p.bias[n + 1];
+              if (n + 2 < p.N) b.z = p.bias[n + 2];
+              if (n + 3 < p.N) b.w = p.bias[n + 3];
+            }
+          }
+          c[q * 4 + 0] += b.x;
+          c[q * 4 + 1] += b.y;
+          c[q * 4 + 2] += b.z;
+          c[q * 4 + 3] += b.w;
+        }
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = fmaxf(c[r], 0.f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = c[r] / (1.f + __expf(-1.702f * c[r]));
+      } else if (p.act == 3) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = c[r] / (1.f + __expf(-c[r]));
+      }
+      if (m < p.M && p.act == 4) {
+        // SwiGLU epilogue (LLaMA MLP, HF LlamaMLP: down(silu(gate(x)) * up(x))): the weight rows were
+        // interleaved at prepare() so this lane's quad is (g0, u0, g1, u1); silu is rounded to bf16
+        // before the product, as the un-fused reference does.
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nw + j * 32 + q * 8;
+          if (n >= p.N) continue;
+          const float g0 = c[q * 4], u0 = c[q * 4 + 1], g1 = c[q * 4 + 2], u1 = c[q * 4 + 3];
+          const float s0 = bf16lo(pack_bf16x2(g0 / (1.f + __expf(-g0)), 0.f));
+          const float s1 = bf16lo(pack_bf16x2(g1 / (1.f + __expf(-g1)), 0.f));
+          bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + (n >> 1);
+          *reinterpret_cast<uint32_t*>(dst) = pack_bf16x2(s0 * u0, s1 * u1);
+        }
+      } else if (m < p.M) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nw + j * 32 + q * 8;
+          if (n >= p.N) continue;
+          float v0 = c[q * 4], v1 = c[q * 4 + 1], v2 = c[q * 4 + 2], v3 = c[q * 4 + 3];
+          if (p.residual) {
+            const bf16_t* rp = p.residual + (size_t)m * p.ldr + n;
+            if (res_vec) {
+              const uint2v rr = *reinterpret_cast<const uint2v*>(rp);
+              v0 += bf16lo(rr.x); v1 += bf16hi(rr.x); v2 += bf16lo(rr.y); v3 += bf16hi(rr.y);
+            } else {
+              v0 += bf16_to_f32(rp[0]);
+              if (n + 1 < p.N) v1 += bf16_to_f32(rp[1]);
+              if (n + 2 < p.N) v2 += bf16_to_f32(rp[2]);
+              if (n + 3 < p.N) v3 += bf16_to_f32(rp[3]);
+            }
+          }
+          if (p.out_f32) {
+            float* dst = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+            if (out_vec) {
+              *reinterpret_cast<float4v*>(dst) = float4v{v0, v1, v2, v3};
+            } else {
+              dst[0] = v0;
+              if (n + 1 < p.N) dst[1] = v1;
+              if (n + 2 < p.N) dst[2] = v2;
+              if (n + 3 < p.N) dst[3] = v3;
+            }
+          } else {
+            bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+            if (out_vec) {
+              *reinterpret_cast<uint2v*>(dst) = uint2v{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+            } else {
+              dst[0] = f32_to_bf16(v0);
+              if (n + 1 < p.N) dst[1] = f32_to_bf16(v1);
+              if (n + 2 < p.N) dst[2] = f32_to_bf16(v2);
+              if (n + 3 < p.N) dst[3] = f32_to_bf16(v3);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // STAGES == 2: double buffer, one __syncthreads per K tile, latency hidden by 2-3 co-resident
 //              workgroups per CU.
 // STAGES >= 3: ring of LDS buffers, STAGES-1 tiles of LDS-DMA in flight, counted s_waitcnt vmcnt
@@ -301,128 +430,8 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
 
   // ---- epilogue.  D[i = n][j = m]: m = lane & 31, n = 8*(r>>2) + 4*(lane>>5) + (r&3) ----
   const int em = lane & 31, en = 4 * (lane >> 5);
-  const bool vec_ok = (p.N & 3) == 0;  // then every in-range quad is a full, aligned quad
   const int mw = m0 + wm * WTM + em, nw = n0 + wn * WTN + en;
-  if (p.splits > 1) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int m = mw + i * 32, n = nw + j * 32 + q * 8;
-          if (m < p.M && n < p.N) {
-            float* dst = p.ws + ((size_t)split * p.M + m) * p.N + n;
-            if (vec_ok) {
-              *reinterpret_cast<float4v*>(dst) = float4v{acc[i][j][q * 4], acc[i][j][q * 4 + 1],
-                                                         acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (n + r < p.N) dst[r] = acc[i][j][q * 4 + r];
-            }
-          }
-        }
-    return;
-  }
-  // One 32x32 accumulator at a time (keeps the live range of epilogue temporaries short):
-  // bias (16-B loads) -> activation (wave-uniform branch) -> residual add -> packed store.
-  const bool res_vec = vec_ok && (p.ldr & 3) == 0;
-  const bool out_vec = vec_ok && (p.ldc & 3) == 0;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float16v c = acc[i][j];
-      const int m = mw + i * 32;
-      if (p.bias) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = nw + j * 32 + q * 8;
-          float4v b = {0.f, 0.f, 0.f, 0.f};
-          if (n < p.N) {
-            if (vec_ok) {
-              b = *reinterpret_cast<const float4v*>(p.bias + n);
-            } else {
-              b.x = p.bias[n];
-              if (n + 1 < p.N) b.y = p.bias[n + 1];
-              if (n + 2 < p.N) b.z = p.bias[n + 2];
-              if (n + 3 < p.N) b.w = p.bias[n + 3];
-            }
-          }
-          c[q * 4 + 0] += b.x;
-          c[q * 4 + 1] += b.y;
-          c[q * 4 + 2] += b.z;
-          c[q * 4 + 3] += b.w;
-        }
-      }
-      if (p.act == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = fmaxf(c[r], 0.f);
-      } else if (p.act == 2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = c[r] / (1.f + __expf(-1.702f * c[r]));
-      } else if (p.act == 3) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = c[r] / (1.f + __expf(-c[r]));
-      }
-      if (m < p.M && p.act == 4) {
-        // SwiGLU epilogue (LLaMA MLP, HF LlamaMLP: down(silu(gate(x)) * up(x))): the weight rows were
-        // interleaved at prepare() so this lane's quad is (g0, u0, g1, u1); silu is rounded to bf16
-        // before the product, as the un-fused reference does.
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = nw + j * 32 + q * 8;
-          if (n >= p.N) continue;
-          const float g0 = c[q * 4], u0 = c[q * 4 + 1], g1 = c[q * 4 + 2], u1 = c[q * 4 + 3];
-          const float s0 = bf16lo(pack_bf16x2(g0 / (1.f + __expf(-g0)), 0.f));
-          const float s1 = bf16lo(pack_bf16x2(g1 / (1.f + __expf(-g1)), 0.f));
-          bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + (n >> 1);
-          *reinterpret_cast<uint32_t*>(dst) = pack_bf16x2(s0 * u0, s1 * u1);
-        }
-      } else if (m < p.M) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = nw + j * 32 + q * 8;
-          if (n >= p.N) continue;
-          float v0 = c[q * 4], v1 = c[q * 4 + 1], v2 = c[q * 4 + 2], v3 = c[q * 4 + 3];
-          if (p.residual) {
-            const bf16_t* rp = p.residual + (size_t)m * p.ldr + n;
-            if (res_vec) {
-              const uint2v rr = *reinterpret_cast<const uint2v*>(rp);
-              v0 += bf16lo(rr.x); v1 += bf16hi(rr.x); v2 += bf16lo(rr.y); v3 += bf16hi(rr.y);
-            } else {
-              v0 += bf16_to_f32(rp[0]);
-              if (n + 1 < p.N) v1 += bf16_to_f32(rp[1]);
-              if (n + 2 < p.N) v2 += bf16_to_f32(rp[2]);
-              if (n + 3 < p.N) v3 += bf16_to_f32(rp[3]);
-            }
-          }
-          if (p.out_f32) {
-            float* dst = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-            if (out_vec) {
-              *reinterpret_cast<float4v*>(dst) = float4v{v0, v1, v2, v3};
-            } else {
-              dst[0] = v0;
-              if (n + 1 < p.N) dst[1] = v1;
-              if (n + 2 < p.N) dst[2] = v2;
-              if (n + 3 < p.N) dst[3] = v3;
-            }
-          } else {
-            bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
-            if (out_vec) {
-              *reinterpret_cast<uint2v*>(dst) = uint2v{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-            } else {
-              dst[0] = f32_to_bf16(v0);
-              if (n + 1 < p.N) dst[1] = f32_to_bf16(v1);
-              if (n + 2 < p.N) dst[2] = f32_to_bf16(v2);
-              if (n + 3 < p.N) dst[3] = f32_to_bf16(v3);
-            }
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<TM, TN>(p, acc, mw, nw, split);
 }
 
 // split-K combine + epilogue: C = act(sum_s ws[s] + bias) + residual
@@ -531,6 +540,282 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ping-pong kernel: 256 x 256 x 64 tile, 8 waves (2 x 4), wave tile 128 x 64, 128 KB LDS (2 K tiles).
+// The two waves that share a SIMD (wave w and w+4 = the two row halves) run HALF A K-TILE OUT OF
+// PHASE, separated by 4 workgroup barriers per K tile: while one does the 16 MFMAs of a k-half the other
+// reads its 12 fragments of the next k-half from LDS, so the matrix pipe of every SIMD always has a
+// wave whose operands are already in registers (the two-barrier loop leaves it idle during every
+// ds_read round trip: 44 % MFMA utilisation in the ablation).  LDS-DMA for K tile t+1 is issued at the
+// first phase of tile t and waited for (vmcnt(0)) at its last phase, four phases later.
+//        phase:      P0            P1            P2            P3
+//   waves 0-3:   read h0(t)     MFMA h0(t)    read h1(t)    MFMA h1(t)
+//   waves 4-7:   MFMA h1(t-1)   read h0(t)    MFMA h0(t)    read h1(t)
+// ---------------------------------------------------------------------------------------------
+#define G4R_PP_BARRIER()                                   \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    __builtin_amdgcn_s_barrier();                          \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  } while (0)
+
+template <int AMODE, bool PROBE = false>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, NW = 8, NT = 512, BKT = 64;
+  constexpr int ROWB = 128, SPR = 8;
+  constexpr int TM = 4, TN = 2;
+  constexpr int NA = BM * SPR / NT, NB = BN * SPR / NT;
+  constexpr int A_BYTES = BM * BKT * 2, STAGE_BYTES = (BM + BN) * BKT * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE_BYTES = 128 KB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int grp = wm;  // waves w and w+4 share a SIMD
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = p.n_fastest ? wg / p.tiles_n : wg % p.tiles_m;
+  const int tile_n = p.n_fastest ? wg % p.tiles_n : wg / p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int split = blockIdx.y;
+  const int t_begin = split * p.tiles_per_split;
+  int t_end = t_begin + p.tiles_per_split;
+  const int nt_total = p.K / BKT;
+  if (t_end > nt_total) t_end = nt_total;
+
+  const bf16_t* a_src[NA];
+  int a_y[NA], a_x[NA];
+  const bf16_t* b_src[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int pslot = (j * NW + wave) * 64 + lane;
+    const int row = pslot / SPR, ps = pslot % SPR;
+    const int kslot = ps ^ ((row >> 1) & 7);
+    int gm = m0 + row;
+    if (gm > p.M - 1) gm = p.M - 1;
+    a_src[j] = p.A + (size_t)gm * p.lda + kslot * 8;
+    a_y[j] = a_x[j] = 0;
+    if (AMODE == 1) {
+      const int hw = p.H * p.Wd;
+      const int b = gm / hw, rem = gm - b * hw;
+      a_y[j] = rem / p.Wd;
+      a_x[j] = rem - a_y[j] * p.Wd;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int pslot = (j * NW + wave) * 64 + lane;
+    const int row = pslot / SPR, ps = pslot % SPR;
+    const int kslot = ps ^ ((row >> 1) & 7);
+    int gn = n0 + row;
+    if (gn > p.N - 1) gn = p.N - 1;
+    b_src[j] = p.W + (size_t)gn * p.ldw + kslot * 8;
+  }
+  // One K tile = 8 LDS-DMA pieces per wave (j 0-3: A rows, 4-7: W rows), 1 KiB each.
+  struct TileSrc { long a_off; int k0, dy, dx; };
+  auto tile_src = [&](int t) {
+    TileSrc ts;
+    ts.k0 = t * BKT;
+    ts.a_off = ts.k0;
+    ts.dy = ts.dx = 0;
+    if (AMODE == 1) {
+      const int per_tap = p.Cin / BKT;
+      const int tap_lin = t / per_tap;
+      const int c0 = (t - tap_lin * per_tap) * BKT;
+      const int g = tap_lin / 9, tap = tap_lin - g * 9;
+      ts.dy = tap / 3 - 1;
+      ts.dx = tap - (tap / 3) * 3 - 1;
+      ts.a_off = (long)g * p.a_group_stride + ((long)ts.dy * p.Wd + ts.dx) * p.lda + c0;
+    }
+    return ts;
+  };
+  auto piece = [&](int j, const TileSrc& ts, int buf) {
+    char* sa = smem + buf * STAGE_BYTES;
+    if (j < NA) {
+      const bf16_t* src = a_src[j] + ts.a_off;
+      if (AMODE == 1) {
+        const int yy = a_y[j] + ts.dy, xx = a_x[j] + ts.dx;
+        if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.Wd) src = p.zeros + (lane & 7) * 8;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sa + (j * NW + wave) * 1024), 16, 0, 0);
+    } else {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[j - NA] + ts.k0),
+                                       (__attribute__((address_space(3))) void*)(sa + A_BYTES + ((j - NA) * NW + wave) * 1024), 16, 0, 0);
+    }
+  };
+
+  float16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frow = lane & 31, fsw = (frow >> 1) & 7, fhi = lane >> 5;
+  const int a_row_off = (wm * 128 + frow) * ROWB;
+  const int b_row_off = (wn * 64 + frow) * ROWB;
+  bf16x8 af[2][TM], wf[2][TN];  // the fragments of ONE k-half (2 of the 4 MFMA k-steps)
+  auto ldfrag = [&](int buf, int h) {
+    const char* sa = smem + buf * STAGE_BYTES;
+    const char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const int slot = (((h * 2 + k2) * 2 + fhi) ^ fsw) << 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[k2][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + slot);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[k2][j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
+    }
+  };
+  // 16 MFMAs with three issue slots (after the 3rd, 8th and 13th) for LDS-DMA pieces: among MFMAs a piece
+  // costs ~60 cycles of issue, against 100+ when all 8 are issued back to back in front of the reads.
+  auto mma = [&](auto&& slot) {
+    __builtin_amdgcn_s_setprio(1);
+    int n = 0;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+          ++n;
+          if (n == 3 || n == 8 || n == 13) {
+            __builtin_amdgcn_sched_barrier(0);
+            slot(n == 3 ? 0 : (n == 8 ? 1 : 2));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // Both groups run the SAME instruction stream; waves 4-7 take one extra barrier before the loop (and
+  // waves 0-3 one after it), which skews them by exactly one phase for the whole loop.  The 8 pieces of
+  // the next K tile are spread 3/3/2 over three consecutive GLOBAL phases (the buffer they go to is
+  // free from global phase 4i and must be full by the end of 4i+3), i.e. local phases 0,1,2 for group 0
+  // and 3(previous tile),0,1 for group 1; the wait (vmcnt(0)) is one phase after the last issue.
+  const int nt = t_end - t_begin;
+  if (nt > 0) {
+    {
+      const TileSrc ts0 = tile_src(t_begin);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) piece(j, ts0, 0);
+    }
+    TileSrc s1 = tile_src(t_begin + 1);
+    if (grp == 1 && nt > 1) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) piece(j, s1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (grp == 1) G4R_PP_BARRIER();
+    // PROBE (tools/pp_probe.py): workgroup 0, waves 0 and 4 stamp s_memtime around every phase of K tile 8
+    // and around the whole loop into p.ws (long long [2][8]).
+    long long* stamps = reinterpret_cast<long long*>(p.ws) + grp * 8;
+    const bool probing = PROBE && blockIdx.x == 0 && blockIdx.y == 0 && (wave & 3) == 0 && lane == 0;
+#define G4R_PP_STAMP(slot) \
+  if (PROBE) { if (probing && (i == 8 || (slot) >= 6)) stamps[slot] = __builtin_amdgcn_s_memtime(); }
+    {
+      const int i = 0;
+      G4R_PP_STAMP(6);
+    }
+    for (int i = 0; i < nt; ++i) {
+      const int buf = i & 1;
+      const bool n1 = i + 1 < nt, n2 = i + 2 < nt;
+      const TileSrc s2 = tile_src(t_begin + i + 2);
+      G4R_PP_STAMP(0);
+      // local phase 0: read k-half 0
+      ldfrag(buf, 0);
+      if (n1) {
+        if (grp == 0) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) piece(j, s1, buf ^ 1);
+        } else {
+#pragma unroll
+          for (int j = 3; j < 6; ++j) piece(j, s1, buf ^ 1);
+        }
+      }
+      G4R_PP_STAMP(5);
+      G4R_PP_BARRIER();
+      G4R_PP_STAMP(1);
+      // local phase 1: MFMA k-half 0
+      mma([&](int sl) {
+        if (n1) {
+          if (grp == 0) piece(3 + sl, s1, buf ^ 1);
+          else if (sl < 2) piece(6 + sl, s1, buf ^ 1);
+        }
+      });
+      G4R_PP_BARRIER();
+      G4R_PP_STAMP(2);
+      // local phase 2: read k-half 1
+      ldfrag(buf, 1);
+      if (grp == 0) {
+        if (n1) {
+#pragma unroll
+          for (int j = 6; j < 8; ++j) piece(j, s1, buf ^ 1);
+        }
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1's share of K tile i+1 is in LDS
+      }
+      G4R_PP_BARRIER();
+      G4R_PP_STAMP(3);
+      // local phase 3: MFMA k-half 1
+      mma([&](int sl) {
+        if (n2 && grp == 1) piece(sl, s2, buf);  // K tile i+2 goes where tile i was: both groups are done reading it
+      });
+      if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 0's share of K tile i+1
+      G4R_PP_BARRIER();
+      G4R_PP_STAMP(4);
+      s1 = s2;
+    }
+    {
+      const int i = 0;
+      G4R_PP_STAMP(7);
+    }
+    if (grp == 0) G4R_PP_BARRIER();
+  }
+  const int em = lane & 31, en = 4 * (lane >> 5);
+  gemm_epilogue<TM, TN>(p, acc, m0 + wm * 128 + em, n0 + wn * 64 + en, split);
+}
+
+template <int AMODE, bool PROBE = false>
+int launch_pp(GemmArgs& p, hipStream_t stream) {
+  {
+    const int nt = p.K / 64;
+    int splits = p.splits < 1 ? 1 : p.splits;
+    if (splits > nt) splits = nt;
+    p.tiles_per_split = g4r_ceil_div(nt, splits);
+    p.splits = g4r_ceil_div(nt, p.tiles_per_split);
+  }
+  p.tiles_m = g4r_ceil_div(p.M, 256);
+  p.tiles_n = g4r_ceil_div(p.N, 256);
+  const size_t lds = 2 * (256 + 256) * 64 * 2;
+  auto kern = gemm_bf16_pp_kernel<AMODE, PROBE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_pp: hipFuncSetAttribute");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(512), lds, stream, p);
+  G4R_CHECK_LAUNCH("gemm_bf16_pp");
+  if (p.splits > 1) {
+    long total = (long)p.M * p.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    G4R_CHECK_LAUNCH("splitk_reduce");
+  }
+  return G4R_OK;
+}
+
 template <int BM, int BN, int WM, int WN, int AMODE, bool GLDS, int STAGES = 2, int BKT = 64, int STYLE = 0>
 int launch_tile(GemmArgs& p, hipStream_t stream) {
   {  // split-K geometry in units of this kernel's K tile
@@ -588,6 +873,8 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 19: return launch_tile<256, 256, 2, 4, AMODE, true, 4, 32, 1>(p, stream);  // 256x256, BK 32 ring x4 (128 KB), interleaved
     case 20: return launch_tile<256, 256, 2, 4, AMODE, true, 4, 32, 2>(p, stream);  // same, burst reads
     case 21: return launch_tile<256, 256, 2, 4, AMODE, true, 3, 32, 1>(p, stream);  // 256x256, BK 32 ring x3 (96 KB)
+    case 22: return launch_pp<AMODE>(p, stream);                                 // 256x256 ping-pong (4 barriers / K tile)
+    case 23: return launch_pp<AMODE, true>(p, stream);                           // same + s_memtime stamps into ws (tools only)
     default: return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");
   }
 }

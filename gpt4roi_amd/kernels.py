@@ -85,7 +85,7 @@ PROFILER = _Profiler()
 TILE_NAMES = {0: "128x128", 1: "256x128", 2: "128x128reg", 4: "64x128", 5: "128x128s3", 6: "128x128s4",
               7: "128x128w8s4", 8: "256x128s3", 9: "256x256", 10: "128x128w8", 11: "128x64", 12: "128x128k32s3", 13: "128x128k32s4",
               14: "128x128k32", 15: "256x128k32s3", 16: "128x128w8s3i", 17: "128x128s3i", 18: "256x128s3i", 19: "256x256k32s4i", 20: "256x256k32s4b",
-              21: "256x256k32s3i"}
+              21: "256x256k32s3i", 22: "256x256pp"}
 
 
 def _launch(name, args, tag=None, flops=0.0, nbytes=0.0):
@@ -147,14 +147,15 @@ def pick_tile(M, N, K=0):
 
 
 def pick_conv_tile(M, Cout, K):
-    """Implicit-GEMM conv (tools/conv_tiles.py on MI355X, N-fastest tile order): the 256x256 tile wins on
-    the large maps (192^2: 897 vs 711 TF/s for 128x128; 96^2: 699 vs 630), the 256x128 two-stage kernel on
-    the K = 4*9*C pconv, and small maps want 64x128 tiles + split-K to cover the 256 CUs.
-    Returns (tile_cfg, splits)."""
+    """Implicit-GEMM conv (tools/conv_tiles.py on MI355X, N-fastest tile order): the 256x256 ping-pong
+    kernel wins on the large maps (same box, 192^2: 898 TF/s vs 750 for the two-barrier 256x256 and 702 for
+    128x128; 96^2: 692 vs 556 / 588) because the other wave group's MFMAs hide the per-piece halo/bounds
+    address work; the 256x128 two-stage kernel serves the K = 4*9*C pconv, and small maps want 64x128 tiles +
+    split-K to cover the 256 CUs.  Returns (tile_cfg, splits)."""
     if K >= 18432:
         return 1, 1
     if M >= 8192:
-        return 9, 1
+        return 22, 1
     blocks = -(-M // 64) * -(-Cout // 128)
     splits = max(1, min(8, round(384 / blocks), K // 1024))
     return 4, splits
