@@ -34,6 +34,7 @@ struct AttnArgs {
   float scale;
   int causal;                            // query i sees keys <= i + (Tk - Tq)
   const int* kv_len_dev;                 // optional: Tk = *kv_len_dev + Tq, read on the device (graph-replayed decode)
+  float* lse;                            // optional [B][H][Tq]: log2-domain log-sum-exp of the scaled scores (training)
 };
 
 template <int D>
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p) 
 
   // ---- normalise and store: lane owns query qi, d = db*32 + 8*g + 4*hi + (0..3) ----
   if (qi < p.Tq) {
+    if (p.lse && hi == 0) p.lse[((size_t)b * p.H + h) * p.Tq + qi] = m_run + __log2f(l_run);
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     bf16_t* orow = p.O + (size_t)b * p.o_batch + (size_t)qi * p.o_row + (size_t)h * D;
 #pragma unroll
@@ -254,7 +256,7 @@ extern "C" {
 int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
                             int head_dim, long q_row, long k_row, long v_row, long o_row, long q_batch,
                             long k_batch, long v_batch, long o_batch, float scale, int causal,
-                            const int* kv_len_dev, void* stream) {
+                            const int* kv_len_dev, float* lse, void* stream) {
   G4R_REQUIRE(B > 0 && H > 0 && Tq >= 0 && Tk > 0, "flash_attn: bad shape");
   G4R_REQUIRE(head_dim == 64 || head_dim == 128, "flash_attn: head_dim must be 64 or 128");
   if (Tq == 0) return G4R_OK;
@@ -264,7 +266,7 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
               "flash_attn: strides must keep 16-byte alignment");
   G4R_REQUIRE(!causal || Tk >= Tq, "flash_attn: causal needs Tk >= Tq");
   AttnArgs a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_row, k_row, v_row, o_row,
-                q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal, kv_len_dev};
+                q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal, kv_len_dev, lse};
   // 64 query rows per workgroup (2 waves): ~2x the workgroups of a 128-row block for the short
   // sequences of this path (577 / ~800 tokens) and finer causal load balance
   if (head_dim == 64) {

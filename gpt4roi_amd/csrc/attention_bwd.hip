@@ -1,0 +1,407 @@
+// attention_bwd.hip -- backward of softmax(Q K^T * scale [+ causal mask]) V for gfx950 (bf16 MFMA, fp32
+// accumulation).  Training rows of the path: the reference gets this gradient
+// from autograd through HF LlamaAttention or from flash-attn's backward
+// (llava/train/llama_flash_attn_monkey_patch.py:15-91).
+//
+// Two kernels, each the mirror image of the forward kernel's register layout so that no probability
+// tile ever needs a transpose:
+//   dQ     : "lane owns a query" (exactly the forward orientation).  S^T = K Q^T and dP^T = V dO^T land
+//            with one query per lane, so LSE and Delta are lane scalars; dQ^T += K^T dS^T uses the packed
+//            dS^T registers as the B operand and K staged TRANSPOSED in LDS as the A operand.
+//   dK, dV : "lane owns a key".  S = Q K^T and dP = dO V^T with the key block's K/V fragments resident in
+//            registers and the streamed query tile in LDS; dV^T += dO^T P and dK^T += Q^T dS use Q / dO
+//            staged transposed.  LSE / Delta of the 64 streamed queries sit in LDS (broadcast reads).
+// P is recomputed from the forward's log2-domain LSE: P = 2^(s*scale*log2e - lse).  Delta = rowsum(dO*O)
+// comes from a small pre-pass.  Nothing is atomically accumulated: results are bit-reproducible.
+#include "g4r_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TB = 64;     // rows of the streamed tile (keys for dQ, queries for dK/dV)
+constexpr int T_LD = 68;   // row stride of a transposed tile (136 B: conflict-free 8-byte reads)
+
+struct AttnBwdArgs {
+  const bf16_t *Q, *K, *V, *O, *dO;
+  bf16_t *dQ, *dK, *dV;
+  const float* lse;  // [B][H][Tq], log2 domain (forward)
+  float* delta;      // [B][H][Tq]
+  long q_row, k_row, v_row, o_row, do_row, dq_row, dk_row, dv_row;
+  long q_batch, k_batch, v_batch, o_batch, do_batch, dq_batch, dk_batch, dv_batch;
+  int Tq, Tk, H;
+  float scale;
+  int causal;
+};
+
+template <int D>
+__device__ __forceinline__ int row_swz(int row) {
+  return D == 128 ? (row & 15) : ((row >> 1) & 7);
+}
+
+// 64 rows x D of a [rows, H*D]-strided matrix -> LDS, row-major with the 16-byte slots of a row XOR-swizzled
+template <int D, int NT>
+__device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, long row_stride, int r0, int rmax,
+                                           int tid) {
+  constexpr int SLOTS = D / 8;
+#pragma unroll
+  for (int it = 0; it < TB * SLOTS / NT; ++it) {
+    const int pk = it * NT + tid;
+    const int row = pk / SLOTS, s = pk % SLOTS;
+    int r = r0 + row;
+    if (r > rmax - 1) r = rmax - 1;
+    const uint4v v = *reinterpret_cast<const uint4v*>(src + (size_t)r * row_stride + s * 8);
+    *reinterpret_cast<uint4v*>(reinterpret_cast<char*>(dst) + row * (D * 2) + ((s ^ row_swz<D>(row)) << 4)) = v;
+  }
+}
+
+// the same 64 rows TRANSPOSED: dst[d][row], stride T_LD.  A thread takes 4 consecutive rows x 8 columns and
+// writes, for each column, the 4 rows as one 8-byte store.
+template <int D, int NT>
+__device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src, long row_stride, int r0,
+                                                 int rmax, int tid) {
+  constexpr int SLOTS = D / 8;
+#pragma unroll
+  for (int u = 0; u < 16 * SLOTS / NT; ++u) {
+    const int pu = u * NT + tid;
+    const int rq = pu % 16, vs = pu / 16;
+    unsigned w[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int r = r0 + rq * 4 + j;
+      if (r > rmax - 1) r = rmax - 1;
+      const uint4v v = *reinterpret_cast<const uint4v*>(src + (size_t)r * row_stride + vs * 8);
+      w[j][0] = v.x, w[j][1] = v.y, w[j][2] = v.z, w[j][3] = v.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint2v lo = {(w[0][e] & 0xffffu) | (w[1][e] << 16), (w[2][e] & 0xffffu) | (w[3][e] << 16)};
+      const uint2v hi2 = {(w[0][e] >> 16) | (w[1][e] & 0xffff0000u), (w[2][e] >> 16) | (w[3][e] & 0xffff0000u)};
+      *reinterpret_cast<uint2v*>(dst + (vs * 8 + 2 * e) * T_LD + rq * 4) = lo;
+      *reinterpret_cast<uint2v*>(dst + (vs * 8 + 2 * e + 1) * T_LD + rq * 4) = hi2;
+    }
+  }
+}
+
+template <int D>
+__device__ __forceinline__ bf16x8 frag_rows(const bf16_t* tile, int row, int kk, int hi) {
+  return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(tile) + row * (D * 2) +
+                                          (((kk * 2 + hi) ^ row_swz<D>(row)) << 4));
+}
+
+// A operand from a transposed tile: row (= head-dim index), 8 of the 16 contraction indices of this MFMA
+// step in the permuted order the C-layout registers of the other operand already have.
+__device__ __forceinline__ bf16x8 frag_transposed(const bf16_t* tile, int row, int base) {
+  const bf16_t* r = tile + row * T_LD + base;
+  const uint2v lo = *reinterpret_cast<const uint2v*>(r);
+  const uint2v hi2 = *reinterpret_cast<const uint2v*>(r + 8);
+  const uint4v w = {lo.x, lo.y, hi2.x, hi2.y};
+  return __builtin_bit_cast(bf16x8, w);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  const uint4v w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                    pack_bf16x2(v[6], v[7])};
+  return __builtin_bit_cast(bf16x8, w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Delta[b][h][i] = sum_d dO[b][i][h*D + d] * O[b][i][h*D + d]
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnBwdArgs p, int B) {
+  constexpr int LPR = D / 8;  // lanes per (row, head)
+  const long total = (long)B * p.Tq * p.H * LPR;
+  // LPR divides 64 and total is a multiple of LPR: a shuffle group is either wholly in range or wholly out
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    float acc = 0.f;
+    const int l = (int)(i % LPR);
+    const long rh = i / LPR;
+    const int h = (int)(rh % p.H);
+    const long bi = rh / p.H;
+    const int q = (int)(bi % p.Tq);
+    const int b = (int)(bi / p.Tq);
+    {
+      const uint4v o = *reinterpret_cast<const uint4v*>(p.O + (size_t)b * p.o_batch + (size_t)q * p.o_row + h * D + l * 8);
+      const uint4v g = *reinterpret_cast<const uint4v*>(p.dO + (size_t)b * p.do_batch + (size_t)q * p.do_row + h * D + l * 8);
+      acc = bf16lo(o.x) * bf16lo(g.x) + bf16hi(o.x) * bf16hi(g.x) + bf16lo(o.y) * bf16lo(g.y) +
+            bf16hi(o.y) * bf16hi(g.y) + bf16lo(o.z) * bf16lo(g.z) + bf16hi(o.z) * bf16hi(g.z) +
+            bf16lo(o.w) * bf16lo(g.w) + bf16hi(o.w) * bf16hi(g.w);
+    }
+#pragma unroll
+    for (int s = LPR / 2; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
+    if (l == 0) p.delta[((size_t)b * p.H + h) * p.Tq + q] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dQ: one workgroup = NW waves = 32*NW queries of one (batch, head); streams the K/V tiles.
+// ---------------------------------------------------------------------------------------------
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;
+  constexpr int KSTEPS = D / 16;
+  constexpr int DB = D / 32;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[TB * D];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[TB * D];
+  __shared__ __attribute__((aligned(16))) bf16_t Kt[D * T_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, ql = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qblock = blockIdx.x * QB;
+  const int qi = qblock + wave * 32 + ql;
+  const int off = p.Tk - p.Tq;
+  const bf16_t* Kb = p.K + (size_t)b * p.k_batch + (size_t)h * D;
+  const bf16_t* Vb = p.V + (size_t)b * p.v_batch + (size_t)h * D;
+  const int qr = qi < p.Tq ? qi : p.Tq - 1;
+
+  bf16x8 qf[KSTEPS], dof[KSTEPS];
+  {
+    const bf16_t* qrow = p.Q + (size_t)b * p.q_batch + (size_t)qr * p.q_row + (size_t)h * D + hi * 8;
+    const bf16_t* grow = p.dO + (size_t)b * p.do_batch + (size_t)qr * p.do_row + (size_t)h * D + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
+      dof[kk] = *reinterpret_cast<const bf16x8*>(grow + kk * 16);
+    }
+  }
+  const float lse_i = p.lse[((size_t)b * p.H + h) * p.Tq + qr];
+  const float delta_i = p.delta[((size_t)b * p.H + h) * p.Tq + qr];
+  const float sc2 = p.scale * 1.4426950408889634f;
+
+  float16v oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+
+  int kend = p.Tk;
+  if (p.causal) {
+    const int last = qblock + QB - 1 + off + 1;
+    if (last < kend) kend = last;
+  }
+  for (int j0 = 0; j0 < kend; j0 += TB) {
+    stage_rows<D, NT>(Ks, Kb, p.k_row, j0, p.Tk, tid);
+    stage_rows<D, NT>(Vs, Vb, p.v_row, j0, p.Tk, tid);
+    stage_transposed<D, NT>(Kt, Kb, p.k_row, j0, p.Tk, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float16v sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f, dpacc[r] = 0.f;
+      const int row = kb * 32 + ql;
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Ks, row, kk, hi), qf[kk], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Vs, row, kk, hi), dof[kk], dpacc, 0, 0, 0);
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const bool valid = key < p.Tk && qi < p.Tq && (!p.causal || key <= qi + off);
+        const float pr = valid ? __builtin_amdgcn_exp2f(sacc[r] * sc2 - lse_i) : 0.f;
+        ds[r] = pr * (dpacc[r] - delta_i) * p.scale;
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bf16x8 pf = pack8(ds + hf * 8);
+        const int kbase = kb * 32 + hf * 16 + 4 * hi;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(Kt, d * 32 + ql, kbase), pf, oacc[d], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (qi < p.Tq) {
+    bf16_t* orow = p.dQ + (size_t)b * p.dq_batch + (size_t)qi * p.dq_row + (size_t)h * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint2v w = {pack_bf16x2(oacc[d][g * 4], oacc[d][g * 4 + 1]),
+                          pack_bf16x2(oacc[d][g * 4 + 2], oacc[d][g * 4 + 3])};
+        *reinterpret_cast<uint2v*>(orow + d * 32 + g * 8 + 4 * hi) = w;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dK, dV: one workgroup = NW waves = 32*NW keys of one (batch, head); streams the Q / dO tiles.
+// ---------------------------------------------------------------------------------------------
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
+  constexpr int NT = NW * 64;
+  constexpr int KB = NW * 32;
+  constexpr int KSTEPS = D / 16;
+  constexpr int DB = D / 32;
+  extern __shared__ __attribute__((aligned(16))) char dkv_smem[];  // 67.5 KB at D = 128: dynamic
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(dkv_smem);
+  bf16_t* Gs = Qs + TB * D;        // dO rows
+  bf16_t* Qt = Gs + TB * D;
+  bf16_t* Gt = Qt + D * T_LD;      // dO transposed
+  float* lse_s = reinterpret_cast<float*>(Gt + D * T_LD);
+  float* delta_s = lse_s + TB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, ql = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int kblock = blockIdx.x * KB;
+  const int kj = kblock + wave * 32 + ql;  // this lane's key
+  const int off = p.Tk - p.Tq;
+  const bf16_t* Qb = p.Q + (size_t)b * p.q_batch + (size_t)h * D;
+  const bf16_t* Gb = p.dO + (size_t)b * p.do_batch + (size_t)h * D;
+  const int kr = kj < p.Tk ? kj : p.Tk - 1;
+
+  bf16x8 kf[KSTEPS], vf[KSTEPS];
+  {
+    const bf16_t* krow = p.K + (size_t)b * p.k_batch + (size_t)kr * p.k_row + (size_t)h * D + hi * 8;
+    const bf16_t* vrow = p.V + (size_t)b * p.v_batch + (size_t)kr * p.v_row + (size_t)h * D + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      kf[kk] = *reinterpret_cast<const bf16x8*>(krow + kk * 16);
+      vf[kk] = *reinterpret_cast<const bf16x8*>(vrow + kk * 16);
+    }
+  }
+  const float sc2 = p.scale * 1.4426950408889634f;
+  float16v dkacc[DB], dvacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dkacc[d][r] = 0.f, dvacc[d][r] = 0.f;
+
+  int q_begin = 0;
+  if (p.causal) {
+    q_begin = kblock - off;  // first query that sees the first key of this block
+    if (q_begin < 0) q_begin = 0;
+    q_begin = (q_begin / TB) * TB;
+  }
+  const float* lse_b = p.lse + ((size_t)b * p.H + h) * p.Tq;
+  const float* delta_b = p.delta + ((size_t)b * p.H + h) * p.Tq;
+  for (int i0 = q_begin; i0 < p.Tq; i0 += TB) {
+    stage_rows<D, NT>(Qs, Qb, p.q_row, i0, p.Tq, tid);
+    stage_rows<D, NT>(Gs, Gb, p.do_row, i0, p.Tq, tid);
+    stage_transposed<D, NT>(Qt, Qb, p.q_row, i0, p.Tq, tid);
+    stage_transposed<D, NT>(Gt, Gb, p.do_row, i0, p.Tq, tid);
+    if (tid < TB) {
+      int q = i0 + tid;
+      if (q > p.Tq - 1) q = p.Tq - 1;
+      lse_s[tid] = lse_b[q];
+      delta_s[tid] = delta_b[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float16v sacc, dpacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f, dpacc[r] = 0.f;
+      const int row = qb * 32 + ql;
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Qs, row, kk, hi), kf[kk], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Gs, row, kk, hi), vf[kk], dpacc, 0, 0, 0);
+      }
+      float pr[16], ds[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int il = qb * 32 + 8 * g + 4 * hi;
+        const float4v l4 = *reinterpret_cast<const float4v*>(lse_s + il);
+        const float4v d4 = *reinterpret_cast<const float4v*>(delta_s + il);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = g * 4 + e;
+          const int qi = i0 + il + e;
+          const bool valid = qi < p.Tq && kj < p.Tk && (!p.causal || kj <= qi + off);
+          pr[r] = valid ? __builtin_amdgcn_exp2f(sacc[r] * sc2 - l4[e]) : 0.f;
+          ds[r] = pr[r] * (dpacc[r] - d4[e]) * p.scale;
+        }
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bf16x8 pf = pack8(pr + hf * 8);
+        const bf16x8 sf = pack8(ds + hf * 8);
+        const int ibase = qb * 32 + hf * 16 + 4 * hi;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(Gt, d * 32 + ql, ibase), pf, dvacc[d], 0, 0, 0);
+          dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(Qt, d * 32 + ql, ibase), sf, dkacc[d], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (kj < p.Tk) {
+    bf16_t* krow = p.dK + (size_t)b * p.dk_batch + (size_t)kj * p.dk_row + (size_t)h * D;
+    bf16_t* vrow = p.dV + (size_t)b * p.dv_batch + (size_t)kj * p.dv_row + (size_t)h * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint2v wk = {pack_bf16x2(dkacc[d][g * 4], dkacc[d][g * 4 + 1]),
+                           pack_bf16x2(dkacc[d][g * 4 + 2], dkacc[d][g * 4 + 3])};
+        const uint2v wv = {pack_bf16x2(dvacc[d][g * 4], dvacc[d][g * 4 + 1]),
+                           pack_bf16x2(dvacc[d][g * 4 + 2], dvacc[d][g * 4 + 3])};
+        *reinterpret_cast<uint2v*>(krow + d * 32 + g * 8 + 4 * hi) = wk;
+        *reinterpret_cast<uint2v*>(vrow + d * 32 + g * 8 + 4 * hi) = wv;
+      }
+  }
+}
+
+template <int D>
+int launch_bwd(const AttnBwdArgs& a, int B, hipStream_t stream) {
+  {
+    const long total = (long)B * a.Tq * a.H * (D / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((attn_delta_kernel<D>), dim3(blocks), dim3(256), 0, stream, a, B);
+    G4R_CHECK_LAUNCH("attn_delta");
+  }
+  constexpr int NW = D == 128 ? 4 : 2;  // the staging split needs 16 * D / 8 >= threads
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<D, NW>), dim3(g4r_ceil_div(a.Tq, NW * 32), a.H, B), dim3(NW * 64), 0,
+                     stream, a);
+  G4R_CHECK_LAUNCH("attn_bwd_dq");
+  constexpr int DKV_LDS = (2 * TB * D + 2 * D * T_LD) * 2 + 2 * TB * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    if (e != hipSuccess) return g4r_note_hip_error(e, "attn_bwd_dkv: hipFuncSetAttribute");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, NW>), dim3(g4r_ceil_div(a.Tk, NW * 32), a.H, B), dim3(NW * 64), DKV_LDS,
+                     stream, a);
+  G4R_CHECK_LAUNCH("attn_bwd_dkv");
+  return G4R_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int g4r_flash_attn_bwd_bf16(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                            const float* lse, float* delta, void* dQ, void* dK, void* dV, int B, int H, int Tq,
+                            int Tk, int head_dim, long q_row, long k_row, long v_row, long o_row, long do_row,
+                            long dq_row, long dk_row, long dv_row, long q_batch, long k_batch, long v_batch,
+                            long o_batch, long do_batch, long dq_batch, long dk_batch, long dv_batch,
+                            float scale, int causal, void* stream) {
+  G4R_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "flash_attn_bwd: bad shape");
+  G4R_REQUIRE(head_dim == 64 || head_dim == 128, "flash_attn_bwd: head_dim must be 64 or 128");
+  G4R_REQUIRE(Q && K && V && O && dO && lse && delta && dQ && dK && dV, "flash_attn_bwd: null pointer");
+  G4R_REQUIRE(!causal || Tk >= Tq, "flash_attn_bwd: causal needs Tk >= Tq");
+  const long strides[] = {q_row,   k_row,   v_row,   o_row,   do_row,   dq_row,   dk_row,   dv_row,
+                          q_batch, k_batch, v_batch, o_batch, do_batch, dq_batch, dk_batch, dv_batch};
+  for (long s : strides) G4R_REQUIRE(s % 8 == 0, "flash_attn_bwd: strides must keep 16-byte alignment");
+  AttnBwdArgs a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)O, (const bf16_t*)dO,
+                   (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, lse, delta,
+                   q_row, k_row, v_row, o_row, do_row, dq_row, dk_row, dv_row,
+                   q_batch, k_batch, v_batch, o_batch, do_batch, dq_batch, dk_batch, dv_batch,
+                   Tq, Tk, H, scale, causal};
+  if (head_dim == 64) return launch_bwd<64>(a, B, (hipStream_t)stream);
+  return launch_bwd<128>(a, B, (hipStream_t)stream);
+}
+
+}  // extern "C"

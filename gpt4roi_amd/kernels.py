@@ -18,7 +18,19 @@ _SIGS = {
     "g4r_conv3x3_nhwc_bf16": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_int,
                               c_int, c_int, c_int, P],
     "g4r_flash_attn_fwd_bf16": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long,
-                                c_long, c_long, c_long, c_long, c_float, c_int, P, P],
+                                c_long, c_long, c_long, c_long, c_float, c_int, P, P, P],
+    "g4r_flash_attn_bwd_bf16": [P] * 10 + [c_int] * 5 + [c_long] * 16 + [c_float, c_int, P],
+    "g4r_rmsnorm_bwd_bf16": [P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_long, c_long, c_float, P],
+    "g4r_layernorm_bwd_bf16": [P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_long, c_float, c_int, P],
+    "g4r_swiglu_il_bf16": [P, P, c_int, c_int, P],
+    "g4r_swiglu_il_bwd_bf16": [P, P, P, c_int, c_int, P],
+    "g4r_rope_qkv_bwd_bf16": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, P],
+    "g4r_cross_entropy_f32": [P, P, P, P, P, c_int, c_int, c_long, c_long, c_int, P],
+    "g4r_transpose_bf16": [P, P, c_int, c_int, c_long, c_long, c_int, P],
+    "g4r_colsum_bf16": [P, P, c_int, c_int, c_long, P],
+    "g4r_relu_bwd_bf16": [P, P, P, c_long, P],
+    "g4r_gather_rows_bf16": [P, P, P, c_int, c_int, c_long, c_long, P],
+    "g4r_adamw_f32": [P, P, c_int, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P],
     "g4r_layernorm_bf16": [P, P, P, P, c_int, c_int, c_long, c_long, c_float, c_int, P],
     "g4r_rmsnorm_bf16": [P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "g4r_groupnorm_affine_nhwc_bf16": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
@@ -236,8 +248,9 @@ def prep_conv3x3_weight(ws):
     return torch.cat(parts, 1).reshape(ws[0].size(0), -1).to(torch.bfloat16).contiguous()
 
 
-def flash_attn(q, k, v, heads, scale, causal=False, out=None, kv_len_dev=None):
-    """q [B, Tq, heads*D], k/v [B, Tk, heads*D] (row-strided views allowed) -> [B, Tq, heads*D]."""
+def flash_attn(q, k, v, heads, scale, causal=False, out=None, kv_len_dev=None, lse=None):
+    """q [B, Tq, heads*D], k/v [B, Tk, heads*D] (row-strided views allowed) -> [B, Tq, heads*D].
+    lse (optional fp32 [B, heads, Tq]) receives the log2-domain log-sum-exp for flash_attn_bwd."""
     _bf16(q, k, v)
     B, Tq, HD = q.shape
     Tk = k.size(1)
@@ -248,7 +261,7 @@ def flash_attn(q, k, v, heads, scale, causal=False, out=None, kv_len_dev=None):
     _launch("g4r_flash_attn_fwd_bf16", (
         _p(q), _p(k), _p(v), _p(out), B, heads, Tq, Tk, D, q.stride(1), k.stride(1), v.stride(1), out.stride(1),
         q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), int(bool(causal)), _p(kv_len_dev),
-        _stream(q),),
+        _p(lse), _stream(q),),
         tag=f"flash_attn<{D}>", flops=4.0 * B * heads * Tq * Tk * D * (0.5 if causal and Tq == Tk else 1.0),
         nbytes=2.0 * B * HD * (2 * Tq + 2 * Tk))
     return out
@@ -449,3 +462,168 @@ def roi_align_mlvl(feats, rois, output_size, scales, sampling_ratio=2, aligned=T
                    int(sampling_ratio), int(bool(aligned)), _stream(rois)),
             tag="roi_align_mlvl_nhwc", flops=0.0, nbytes=float(alg))
     return out
+
+
+# ---- training rows (include/g4r_train.h) ------------------------------------------------------------------
+def flash_attn_bwd(q, k, v, o, do, lse, heads, scale, causal=True):
+    """-> dq, dk, dv (bf16, [B, T, heads*D] contiguous)."""
+    _bf16(q, k, v, o, do)
+    _f32(lse)
+    B, Tq, HD = q.shape
+    Tk = k.size(1)
+    D = HD // heads
+    for t in (q, k, v, o, do):
+        assert t.stride(2) == 1
+    dq = torch.empty((B, Tq, HD), dtype=torch.bfloat16, device=q.device)
+    dk = torch.empty((B, Tk, HD), dtype=torch.bfloat16, device=q.device)
+    dv = torch.empty((B, Tk, HD), dtype=torch.bfloat16, device=q.device)
+    delta = torch.empty((B, heads, Tq), dtype=torch.float32, device=q.device)
+    _launch("g4r_flash_attn_bwd_bf16", (
+        _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, heads, Tq, Tk, D,
+        q.stride(1), k.stride(1), v.stride(1), o.stride(1), do.stride(1), dq.stride(1), dk.stride(1), dv.stride(1),
+        q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0),
+        float(scale), int(bool(causal)), _stream(q),),
+        tag=f"flash_attn_bwd<{D}>", flops=14.0 * B * heads * Tq * Tk * D * (0.5 if causal and Tq == Tk else 1.0),
+        nbytes=2.0 * B * HD * (4 * Tq + 4 * Tk))
+    return dq, dk, dv
+
+
+def rmsnorm_bwd(x, gamma, dy, dres=None, dgamma=None, eps=1e-6):
+    """dx = dres + d rmsnorm(x; gamma)/dx . dy; x, dy, dres [rows, cols] bf16 (row-strided ok)."""
+    _bf16(x, dy, dres)
+    _f32(gamma, dgamma)
+    rows, cols = x.shape
+    dx = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    _launch("g4r_rmsnorm_bwd_bf16", (_p(x), _p(gamma), _p(dy), _p(dres), _p(dx), _p(dgamma), rows, cols, x.stride(0),
+                                     dy.stride(0), dres.stride(0) if dres is not None else 0, dx.stride(0),
+                                     float(eps), _stream(x),), tag="g4r_rmsnorm_bwd_bf16")
+    return dx
+
+
+def layernorm_bwd(x, gamma, dy, dgamma=None, dbeta=None, eps=1e-5, relu_in=False, need_dx=True):
+    _bf16(x, dy)
+    _f32(gamma, dgamma, dbeta)
+    rows, cols = x.shape
+    dx = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device) if need_dx else None
+    _launch("g4r_layernorm_bwd_bf16", (_p(x), _p(gamma), _p(dy), _p(dx), _p(dgamma), _p(dbeta), rows, cols,
+                                       x.stride(0), dy.stride(0), dx.stride(0) if need_dx else 0, float(eps),
+                                       int(bool(relu_in)), _stream(x),), tag="g4r_layernorm_bwd_bf16")
+    return dx
+
+
+def swiglu_il(gu):
+    """gu [T, 2F] with interleaved (gate, up) columns -> silu(gate) * up [T, F]."""
+    _bf16(gu)
+    T, F2 = gu.shape
+    out = torch.empty((T, F2 // 2), dtype=torch.bfloat16, device=gu.device)
+    assert gu.is_contiguous()
+    _launch("g4r_swiglu_il_bf16", (_p(gu), _p(out), T, F2 // 2, _stream(gu),), tag="g4r_swiglu_il_bf16")
+    return out
+
+
+def swiglu_il_bwd(gu, dy):
+    _bf16(gu, dy)
+    T, F2 = gu.shape
+    assert gu.is_contiguous() and dy.is_contiguous() and dy.shape == (T, F2 // 2)
+    dgu = torch.empty_like(gu)
+    _launch("g4r_swiglu_il_bwd_bf16", (_p(gu), _p(dy), _p(dgu), T, F2 // 2, _stream(gu),),
+            tag="g4r_swiglu_il_bwd_bf16")
+    return dgu
+
+
+def rope_qkv_bwd(dq, dk, dv, cos, sin, heads, head_dim, pos0=0):
+    """dq, dk, dv [T, heads*D] (row-strided ok) -> d(qkv) [T, 3*heads*D]."""
+    _bf16(dq, dk, dv)
+    T, HD = dq.shape
+    out = torch.empty((T, 3 * HD), dtype=torch.bfloat16, device=dq.device)
+    _launch("g4r_rope_qkv_bwd_bf16", (_p(dq), _p(dk), _p(dv), _p(cos), _p(sin), _p(out), T, heads, head_dim, pos0,
+                                      dq.stride(0), dk.stride(0), dv.stride(0), _stream(dq),),
+            tag="g4r_rope_qkv_bwd_bf16")
+    return out
+
+
+def cross_entropy(logits, labels, loss_sum, grad_scale=None, dlogits=None, n_pad=None):
+    """logits fp32 [R, N] (row-strided), labels int64 [R] (< 0 = ignored).  Adds the summed loss to loss_sum
+    (fp32 [1]); when dlogits (bf16 [R, >= n_pad]) is given it receives (softmax - onehot) * grad_scale[0]."""
+    _f32(logits, loss_sum, grad_scale)
+    R, N = logits.shape
+    assert labels.dtype == torch.int64 and labels.numel() == R and labels.is_contiguous()
+    if dlogits is not None:
+        _bf16(dlogits)
+        n_pad = n_pad or dlogits.size(1)
+    _launch("g4r_cross_entropy_f32", (_p(logits), _p(labels), _p(dlogits), _p(loss_sum), _p(grad_scale), R, N,
+                                      logits.stride(0), dlogits.stride(0) if dlogits is not None else 0,
+                                      n_pad or N, _stream(logits),), tag="g4r_cross_entropy_f32")
+    return dlogits
+
+
+def transpose(x, r_pad=None, out=None):
+    """x [R, C] bf16 (row-strided) -> [C, R_pad] with zero columns R..R_pad."""
+    _bf16(x)
+    R, C = x.shape
+    r_pad = r_pad or R
+    if out is None:
+        out = torch.empty((C, r_pad), dtype=torch.bfloat16, device=x.device)
+    _launch("g4r_transpose_bf16", (_p(x), _p(out), R, C, x.stride(0), out.stride(0), r_pad, _stream(x),),
+            tag="g4r_transpose_bf16", nbytes=2.0 * (R * C + C * r_pad))
+    return out
+
+
+def colsum(x, out=None):
+    _bf16(x)
+    M, N = x.shape
+    if out is None:
+        out = torch.zeros(N, dtype=torch.float32, device=x.device)
+    _launch("g4r_colsum_bf16", (_p(x), _p(out), M, N, x.stride(0), _stream(x),), tag="g4r_colsum_bf16")
+    return out
+
+
+def relu_bwd(y, dy):
+    _bf16(y, dy)
+    assert y.is_contiguous() and dy.is_contiguous() and y.numel() == dy.numel()
+    dx = torch.empty_like(dy)
+    _launch("g4r_relu_bwd_bf16", (_p(y), _p(dy), _p(dx), y.numel(), _stream(y),), tag="g4r_relu_bwd_bf16")
+    return dx
+
+
+def gather_rows(src, idx, out=None):
+    """src [R, C] bf16 (row-strided), idx int32 [n] (negative -> zero row) -> [n, C]."""
+    _bf16(src)
+    assert idx.dtype == torch.int32 and idx.is_contiguous()
+    n, C = idx.numel(), src.size(1)
+    if out is None:
+        out = torch.empty((n, C), dtype=torch.bfloat16, device=src.device)
+    _launch("g4r_gather_rows_bf16", (_p(src), _p(idx), _p(out), n, C, src.stride(0), out.stride(0), _stream(src),),
+            tag="g4r_gather_rows_bf16")
+    return out
+
+
+def adamw(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+          grad_scale=1.0, param_bf16=None):
+    _f32(param, exp_avg, exp_avg_sq)
+    assert grad.dtype in (torch.bfloat16, torch.float32) and grad.numel() == param.numel()
+    assert param.is_contiguous() and grad.is_contiguous() and exp_avg.is_contiguous() and exp_avg_sq.is_contiguous()
+    if param_bf16 is not None:
+        _bf16(param_bf16)
+        assert param_bf16.is_contiguous() and param_bf16.numel() == param.numel()
+    _launch("g4r_adamw_f32", (_p(param), _p(grad), int(grad.dtype == torch.bfloat16), _p(exp_avg), _p(exp_avg_sq),
+                              _p(param_bf16), param.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                              float(weight_decay), int(step), float(grad_scale), _stream(param),),
+            tag="g4r_adamw_f32")
+
+
+def linear_dgrad(dy, w_t, out=None, residual=None):
+    """dx [M, K] = dy [M, N] @ W [N, K], given W^T ([K, N_pad], zero padded to a multiple of 64) as the NT weight."""
+    return gemm(dy, w_t, residual=residual, out=out)
+
+
+def linear_wgrad(dy, x, out_dtype=torch.float32, splits=None):
+    """dW [N, K] = dy^T [N, M] . x [M, K]: one NT GEMM over the (zero-padded) token axis."""
+    M = dy.size(0)
+    m_pad = -(-M // 64) * 64
+    dyt = transpose(dy, m_pad)
+    xt = transpose(x, m_pad)
+    if splits is None:
+        tiles = -(-dyt.size(0) // 128) * -(-xt.size(0) // 128)
+        splits = max(1, min(8, 512 // max(tiles, 1), m_pad // 256))
+    return gemm(dyt, xt, out_dtype=out_dtype, splits=splits)

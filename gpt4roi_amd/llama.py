@@ -95,6 +95,106 @@ class LlamaDecoder:
         logits = K.gemm(xn.reshape(-1, C), self.lm_head, out_dtype=torch.float32)
         return logits.view(B, -1, self.vocab)
 
+    # ---- training rows: forward that keeps what the backward needs ---------
+    def prepare_training(self, train_weights=False):
+        """Materialise W^T for every projection (the input-gradient GEMMs are NT GEMMs against W^T;
+        13 GB for the 7B model, a one-off for frozen weights, refreshed by `refresh_transposes` after an
+        optimizer step when the decoder itself is trained)."""
+        self.train_weights = train_weights
+        self.v_pad = -(-self.vocab // 64) * 64
+        self.refresh_transposes()
+
+    def refresh_transposes(self):
+        for L in self.layers:
+            for nm in ("wqkv", "wo", "wgu", "wd"):
+                L[nm + "_t"] = K.transpose(L[nm])
+        self.lm_head_t = K.transpose(self.lm_head, self.v_pad)
+
+    def forward_train(self, inputs_embeds):
+        """inputs_embeds [B,T,C] bf16 at positions 0..T-1 -> (logits fp32 [B*T, V], ctx).  Same kernels as
+        `forward` except that the gate|up GEMM keeps its pre-activation output for the SwiGLU backward and
+        the attention kernel also returns the log-sum-exp."""
+        B, T, C = inputs_embeds.shape
+        assert T <= self.max_positions and B <= self.kc.size(1)
+        H, D = self.heads, self.head_dim
+        x = inputs_embeds.reshape(B * T, C).contiguous()
+        scale = 1.0 / math.sqrt(D)
+        saved = []
+        for li, L in enumerate(self.layers):
+            h = K.rmsnorm(x, L['n1'], self.eps)
+            qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
+            q = torch.empty((B, T, C), dtype=torch.bfloat16, device=x.device)
+            for b in range(B):
+                K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, 0)
+            lse = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
+            a = K.flash_attn(q, self.kc[li, :B, :T], self.vc[li, :B, :T], H, scale, True, lse=lse)
+            x1 = K.gemm(a.view(B * T, C), L['wo'], residual=x)
+            h2 = K.rmsnorm(x1, L['n2'], self.eps)
+            gu = K.gemm(h2, L['wgu'])
+            f = K.swiglu_il(gu)
+            x2 = K.gemm(f, L['wd'], residual=x1)
+            rec = dict(x=x, q=q, a=a, lse=lse, x1=x1, gu=gu)
+            if self.train_weights:
+                rec.update(h=h, h2=h2, f=f)
+            saved.append(rec)
+            x = x2
+        xn = K.rmsnorm(x, self.norm, self.eps)
+        logits = K.gemm(xn, self.lm_head, out_dtype=torch.float32)
+        self.pos = T
+        return logits, dict(B=B, T=T, saved=saved, x_final=x, xn=xn)
+
+    def backward(self, ctx, dlogits):
+        """dlogits bf16 [B*T, v_pad] (zero in the pad columns) -> d(inputs_embeds) [B*T, C] bf16.
+        With `train_weights`, self.grads[name] receives the fp32 weight gradients (layer weights in the
+        kernel layout: fused qkv, interleaved gate|up)."""
+        B, T = ctx["B"], ctx["T"]
+        C, H, D = self.hidden, self.heads, self.head_dim
+        scale = 1.0 / math.sqrt(D)
+        tw = self.train_weights
+        grads = {}
+        if tw:
+            grads["lm_head"] = K.linear_wgrad(dlogits[:, :self.vocab], ctx["xn"])
+            grads["norm"] = torch.zeros_like(self.norm)
+        dxn = K.gemm(dlogits, self.lm_head_t)
+        dx = K.rmsnorm_bwd(ctx["x_final"], self.norm, dxn, dgamma=grads.get("norm"), eps=self.eps)
+        for li in range(len(self.layers) - 1, -1, -1):
+            L, S = self.layers[li], ctx["saved"][li]
+            df = K.gemm(dx, L['wd_t'])
+            dgu = K.swiglu_il_bwd(S['gu'], df)
+            dh2 = K.gemm(dgu, L['wgu_t'])
+            if tw:
+                grads[f"{li}.wd"] = K.linear_wgrad(dx, S['f'])
+                grads[f"{li}.wgu"] = K.linear_wgrad(dgu, S['h2'])
+                grads[f"{li}.n2"] = torch.zeros_like(L['n2'])
+                grads[f"{li}.n1"] = torch.zeros_like(L['n1'])
+            dx1 = K.rmsnorm_bwd(S['x1'], L['n2'], dh2, dres=dx, dgamma=grads.get(f"{li}.n2"), eps=self.eps)
+            da = K.gemm(dx1, L['wo_t']).view(B, T, C)
+            dq, dk, dv = K.flash_attn_bwd(S['q'], self.kc[li, :B, :T], self.vc[li, :B, :T], S['a'], da, S['lse'], H,
+                                          scale, True)
+            dqkv = torch.cat([K.rope_qkv_bwd(dq[b], dk[b], dv[b], self.cos, self.sin, H, D, 0) for b in range(B)], 0) \
+                if B > 1 else K.rope_qkv_bwd(dq[0], dk[0], dv[0], self.cos, self.sin, H, D, 0)
+            dh = K.gemm(dqkv, L['wqkv_t'])
+            if tw:
+                grads[f"{li}.wo"] = K.linear_wgrad(dx1, S['a'].view(B * T, C))
+                grads[f"{li}.wqkv"] = K.linear_wgrad(dqkv, S['h'])
+            dx = K.rmsnorm_bwd(S['x'], L['n1'], dh, dres=dx1, dgamma=grads.get(f"{li}.n1"), eps=self.eps)
+        self.grads = grads
+        return dx
+
+    def loss_and_dlogits(self, logits, labels):
+        """Shifted-label token cross entropy (llava/model/llava.py:240-252): logits fp32 [B*T, V], labels int64
+        [B, T] with -100 = ignored.  Returns (mean loss fp32 [1] on the device, dlogits bf16 [B*T, v_pad])."""
+        B, T = labels.shape
+        lab = torch.full((B, T), -100, dtype=torch.int64, device=logits.device)
+        lab[:, :-1] = labels[:, 1:]
+        lab = lab.reshape(-1).contiguous()
+        cnt = (lab >= 0).sum().clamp(min=1)
+        gs = (1.0 / cnt.float()).reshape(1).contiguous()
+        loss_sum = torch.zeros(1, dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty((B * T, self.v_pad), dtype=torch.bfloat16, device=logits.device)
+        K.cross_entropy(logits, lab, loss_sum, gs, dlogits, self.v_pad)
+        return loss_sum * gs, dlogits
+
     # ---- device-resident greedy decode, one hipGraph replay per token ----------------------------
     def _decode_state(self, max_new):
         st = getattr(self, "_dstate", None)

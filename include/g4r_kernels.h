@@ -57,11 +57,13 @@ int g4r_conv3x3_nhwc_bf16(const void* X, const void* W, void* Y, const float* bi
  * kv_len_dev (nullable): when set, Tk = *kv_len_dev + Tq is computed on the device (the argument Tk is then
  * only an upper bound): *kv_len_dev = positions already cached before this call, so a decode step can be
  * replayed from a hipGraph while the cache grows.
+ * lse (nullable): fp32 [B, H, Tq], receives the log2-domain log-sum-exp of the scaled scores for the backward
+ * (g4r_train.h).
  */
 int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq,
                             int Tk, int head_dim, long q_row, long k_row, long v_row, long o_row,
                             long q_batch, long k_batch, long v_batch, long o_batch, float scale,
-                            int causal, const int* kv_len_dev, void* stream);
+                            int causal, const int* kv_len_dev, float* lse, void* stream);
 
 /* LayerNorm over the last dim (CLIP pre_layrnorm / layer_norm1,2; pos_embedd LayerNorms
  * gpt4roi/models/layers.py:260-267).  gamma/beta fp32.  relu_in: apply ReLU to x first. */

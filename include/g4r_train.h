@@ -1,0 +1,87 @@
+/*
+ * g4r_train.h -- C ABI of the training rows of the region-feature path (SURVEY.md 8a rows a2, a12, a16, a18;
+ * 8d configs 3 and 4): the backward and optimizer kernels the reference obtains from torch autograd,
+ * flash-attn's backward and torch.optim.AdamW under HF Trainer
+ * (/root/reference/gpt4roi/train/train.py:698-712, train_stage1.sh, train_stage2.sh).
+ *
+ * Same conventions as g4r_kernels.h: raw device pointers + sizes + hipStream_t (as void*), int status
+ * (0 = ok; text via g4r_last_error()), the caller owns every buffer, no allocation, no global state.
+ * bf16 tensors are raw 16-bit patterns.  Matrix gradients use the forward GEMM / implicit-GEMM entry points of
+ * g4r_kernels.h on transposed operands (g4r_transpose_bf16 below).
+ */
+#ifndef G4R_TRAIN_H
+#define G4R_TRAIN_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * Backward of g4r_flash_attn_fwd_bf16 (which now also returns `lse`, the log2-domain log-sum-exp of the scaled
+ * scores, [B, H, Tq] fp32).  Replaces autograd through HF LlamaAttention / flash_attn_unpadded_qkvpacked_func's
+ * backward (llava/train/llama_flash_attn_monkey_patch.py:15-91).  delta [B, H, Tq] fp32 is scratch
+ * (rowsum(dO * O)).  dQ/dK/dV are fully written (no accumulation, no atomics: bit-reproducible).
+ */
+int g4r_flash_attn_bwd_bf16(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                            const float* lse, float* delta, void* dQ, void* dK, void* dV, int B, int H, int Tq,
+                            int Tk, int head_dim, long q_row, long k_row, long v_row, long o_row, long do_row,
+                            long dq_row, long dk_row, long dv_row, long q_batch, long k_batch, long v_batch,
+                            long o_batch, long do_batch, long dq_batch, long dk_batch, long dv_batch,
+                            float scale, int causal, void* stream);
+
+/* HF LlamaRMSNorm backward.  dx = dres + d(rmsnorm)/dx (dres nullable: the residual-stream gradient that
+ * bypasses the norm); dgamma (nullable, fp32 [cols]) is accumulated with atomics. */
+int g4r_rmsnorm_bwd_bf16(const void* x, const float* gamma, const void* dy, const void* dres, void* dx,
+                         float* dgamma, int rows, int cols, long ldx, long lddy, long lddres, long lddx, float eps,
+                         void* stream);
+
+/* nn.LayerNorm backward (pos_embedd, gpt4roi/models/layers.py:260-267); relu_in as in the forward kernel.
+ * dx nullable (first layer); dgamma / dbeta fp32 [cols], accumulated. */
+int g4r_layernorm_bwd_bf16(const void* x, const float* gamma, const void* dy, void* dx, float* dgamma, float* dbeta,
+                           int rows, int cols, long ldx, long lddy, long lddx, float eps, int relu_in, void* stream);
+
+/* SiLU(gate) * up over INTERLEAVED columns (gate_up [T, 2F]: column 2c = gate_c, 2c+1 = up_c, the layout the
+ * fused gate|up GEMM writes); the training forward keeps gate_up for the backward. */
+int g4r_swiglu_il_bf16(const void* gate_up, void* out, int T, int F, void* stream);
+int g4r_swiglu_il_bwd_bf16(const void* gate_up, const void* dy, void* dgate_up, int T, int F, void* stream);
+
+/* Backward of g4r_rope_qkv_bf16: d(qkv)[t] = [R(pos)^-1 dq[t], R(pos)^-1 dk[t], dv[t]], dqkv [T, 3*H*D]. */
+int g4r_rope_qkv_bwd_bf16(const void* dq, const void* dk, const void* dv, const float* cos_tab, const float* sin_tab,
+                          void* dqkv, int T, int heads, int head_dim, int pos0, long ldq, long ldk, long ldv,
+                          void* stream);
+
+/*
+ * Token cross entropy of llava/model/llava.py:240-252 (labels already shifted by the caller; label < 0 =
+ * ignore_index).  logits fp32 [rows, ld]; *loss_sum += sum over valid rows of (lse - logit[label]);
+ * dlogits (nullable) bf16 [rows, ldd] = (softmax - onehot) * *grad_scale, columns N..n_pad zero-filled so the
+ * buffer can feed a GEMM whose reduction length must be a multiple of 64.
+ */
+int g4r_cross_entropy_f32(const float* logits, const long* labels, void* dlogits, float* loss_sum,
+                          const float* grad_scale, int rows, int N, long ld, long ldd, int n_pad, void* stream);
+
+/* out[c][r] = in[r][c] for r < R, zero for R <= r < R_pad (bf16).  Weight gradients are NT GEMMs over the token
+ * / pixel axis: dW[N,K] = dY^T[N, M] . (X^T[K, M])^T. */
+int g4r_transpose_bf16(const void* in, void* out, int R, int C, long ld_in, long ld_out, int R_pad, void* stream);
+
+/* out[c] += sum_r x[r][c]  (bias gradients). */
+int g4r_colsum_bf16(const void* x, float* out, int M, int N, long ld, void* stream);
+
+/* dx = dy * (y > 0). */
+int g4r_relu_bwd_bf16(const void* y, const void* dy, void* dx, long n, void* stream);
+
+/* dst[i] = src[idx[i]] (rows of C bf16 values; idx < 0 -> zeros): gradient of the image-patch / <bbox> splice
+ * (gpt4roi/models/spi_llava.py:99-196) with respect to the projector output and the region embeddings. */
+int g4r_gather_rows_bf16(const void* src, const int* idx, void* dst, int n, int C, long ld_src, long ld_dst,
+                         void* stream);
+
+/* torch.optim.AdamW step on fp32 master weights (decoupled weight decay); grad bf16 or fp32, multiplied by
+ * grad_scale first (gradient averaging / clipping); param_bf16 (nullable) receives the rounded copy the kernels
+ * read.  step >= 1. */
+int g4r_adamw_f32(float* param, const void* grad, int grad_is_bf16, float* exp_avg, float* exp_avg_sq,
+                  void* param_bf16, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G4R_TRAIN_H */
