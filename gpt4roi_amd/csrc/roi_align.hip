@@ -514,6 +514,76 @@ int launch_bwd_nchw(const T* gout, const T* rois, const T* amy, const T* amx, T*
   return G4R_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of the fused multi-level NHWC RoIAlign (training row a12 for the region module): scatters
+// d(roi_feats) into fp32 NHWC gradient maps of the POST GroupNorm+ReLU features (the deferred affine's own
+// backward is g4r_gn_relu_bwd_nhwc_bf16).  Same sample geometry as the forward kernel; 16 corner taps per
+// output bin, fp32 atomics as in the reference's roi_align_backward_cuda_kernel
+// (mmcv-1.4.7/mmcv/ops/csrc/common/cuda/roi_align_cuda_kernel.cuh:111-210).
+// dout element (l, n, ph, pw, c) = dout[l*lvl_stride + ((n*PH + ph)*PW + pw)*pix_stride + c]  (bf16).
+// ---------------------------------------------------------------------------------------------
+struct MlvlGradArgs {
+  float* grad[G4R_MAX_LEVELS];
+  int H[G4R_MAX_LEVELS];
+  int W[G4R_MAX_LEVELS];
+  float scale[G4R_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_bwd_kernel(MlvlGradArgs a, const float* __restrict__ rois,
+                                                                      const bf16_t* __restrict__ dout, long lvl_stride,
+                                                                      long pix_stride, int L, int B, int C, int N,
+                                                                      int PH, int PW, int sr, int aligned) {
+  __shared__ Tap1D<float> xtab[MLVL_MAX_XTAB];
+  __shared__ Tap1D<float> ytab[MLVL_MAX_YTAB];
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int q = bid >> 3;
+  const int ph = q % PH;
+  const int grp = (q / PH) * 8 + xcd;
+  if (grp >= L * N) return;
+  const int l = grp / N, n = grp % N;
+  const int H = a.H[l], W = a.W[l];
+  const RoiGeom<float> g = roi_geometry<float>(rois + (size_t)5 * n, a.scale[l], aligned, PH, PW, sr);
+  const int tid = threadIdx.x;
+  if (tid < sr) ytab[tid] = make_tap1d<float>(sample_coord<float>(g.start_h, g.bin_h, ph, tid, sr), H);
+  for (int i = tid; i < PW * sr; i += 256)
+    xtab[i] = make_tap1d<float>(sample_coord<float>(g.start_w, g.bin_w, i / sr, i % sr, sr), W);
+  __syncthreads();
+  if (g.batch < 0 || g.batch >= B) return;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int nvec = C >> 3;
+  const float inv_count = 1.f / (float)(sr * sr);
+  float* gm = a.grad[l] + (size_t)g.batch * H * W * C;
+  const bf16_t* dbase = dout + (size_t)l * lvl_stride + ((size_t)n * PH + ph) * PW * pix_stride;
+  for (int pw = wave; pw < PW; pw += 4) {
+    for (int v = lane; v < nvec; v += 64) {
+      Vec8 d = load8(dbase + (size_t)pw * pix_stride + v * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d.v[k] *= inv_count;
+      for (int iy = 0; iy < sr; ++iy) {
+        const Tap1D<float> ty = ytab[iy];
+        if (!ty.valid) continue;
+        for (int ix = 0; ix < sr; ++ix) {
+          const Tap1D<float> tx = xtab[pw * sr + ix];
+          if (!tx.valid) continue;
+          const float ly = ty.frac, lx = tx.frac, hy = 1.f - ly, hx = 1.f - lx;
+          float* p1 = gm + ((size_t)ty.lo * W + tx.lo) * C + v * 8;
+          float* p2 = gm + ((size_t)ty.lo * W + tx.hi) * C + v * 8;
+          float* p3 = gm + ((size_t)ty.hi * W + tx.lo) * C + v * 8;
+          float* p4 = gm + ((size_t)ty.hi * W + tx.hi) * C + v * 8;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            unsafeAtomicAdd(p1 + k, d.v[k] * hy * hx);
+            unsafeAtomicAdd(p2 + k, d.v[k] * hy * lx);
+            unsafeAtomicAdd(p3 + k, d.v[k] * ly * hx);
+            unsafeAtomicAdd(p4 + k, d.v[k] * ly * lx);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <typename TI>
 int launch_mlvl(const void* const* feats, const float* const* affines, const int* heights, const int* widths, const float* scales,
                 int levels, const float* rois, void* output, int B, int C, int N, int PH, int PW,
@@ -617,6 +687,37 @@ int g4r_roi_align_mlvl_nhwc_f32(const void* const* feats, const float* const* af
                                 int sampling_ratio, int aligned, void* stream) {
   return launch_mlvl<float>(feats, affines, heights, widths, scales, levels, rois, output, batch, channels,
                             n_rois, pooled_h, pooled_w, sampling_ratio, aligned, stream);
+}
+
+int g4r_roi_align_mlvl_nhwc_bwd_bf16(const void* dout, long lvl_stride, long pix_stride, float* const* grads,
+                                     const int* heights, const int* widths, const float* scales, int levels,
+                                     const float* rois, int batch, int channels, int n_rois, int pooled_h,
+                                     int pooled_w, int sampling_ratio, int aligned, void* stream) {
+  G4R_REQUIRE(levels > 0 && levels <= G4R_MAX_LEVELS, "roi_align_mlvl_bwd: 1..8 levels");
+  G4R_REQUIRE(channels > 0 && (channels % 8) == 0 && pix_stride % 8 == 0 && lvl_stride % 8 == 0,
+              "roi_align_mlvl_bwd: channels / strides must be multiples of 8");
+  G4R_REQUIRE(pooled_h > 0 && pooled_w > 0 && batch > 0 && n_rois >= 0, "roi_align_mlvl_bwd: bad shape");
+  if (sampling_ratio <= 0 || sampling_ratio > MLVL_MAX_YTAB || pooled_w * sampling_ratio > MLVL_MAX_XTAB)
+    return g4r_note_error(G4R_ERR_UNSUPPORTED, "roi_align_mlvl_bwd: needs 0 < sampling_ratio <= 16, PW*sr <= 256");
+  if (n_rois == 0) return G4R_OK;
+  G4R_REQUIRE(dout && grads && heights && widths && scales && rois, "roi_align_mlvl_bwd: null pointer");
+  MlvlGradArgs a;
+  for (int l = 0; l < G4R_MAX_LEVELS; ++l) {
+    const int s = l < levels ? l : 0;
+    a.grad[l] = grads[s];
+    a.H[l] = heights[s];
+    a.W[l] = widths[s];
+    a.scale[l] = scales[s];
+    G4R_REQUIRE(grads[s] && heights[s] > 0 && widths[s] > 0, "roi_align_mlvl_bwd: bad level");
+  }
+  const long groups = (long)levels * n_rois;
+  const long blocks = ((groups + 7) / 8) * 8 * pooled_h;
+  G4R_REQUIRE(blocks < 2147483647L, "roi_align_mlvl_bwd: grid too large");
+  hipLaunchKernelGGL(roi_align_mlvl_nhwc_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, rois,
+                     (const bf16_t*)dout, lvl_stride, pix_stride, levels, batch, channels, n_rois, pooled_h, pooled_w,
+                     sampling_ratio, aligned);
+  G4R_CHECK_LAUNCH("roi_align_mlvl_nhwc_bwd");
+  return G4R_OK;
 }
 
 }  // extern "C"

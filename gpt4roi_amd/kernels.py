@@ -31,6 +31,12 @@ _SIGS = {
     "g4r_relu_bwd_bf16": [P, P, P, c_long, P],
     "g4r_gather_rows_bf16": [P, P, P, c_int, c_int, c_long, c_long, P],
     "g4r_adamw_f32": [P, P, c_int, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P],
+    "g4r_groupnorm_stats_nhwc_bf16": [P, P, P, c_int, c_int, c_int, c_int, c_float, P],
+    "g4r_gn_relu_bwd_nhwc_bf16": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "g4r_fuse_shuffle_bwd_nhwc_bf16": [P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P],
+    "g4r_nhwc_to_cm_padded_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_int, P],
+    "g4r_roi_align_mlvl_nhwc_bwd_bf16": [P, c_long, c_long, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_int, P],
     "g4r_layernorm_bf16": [P, P, P, P, c_int, c_int, c_long, c_long, c_float, c_int, P],
     "g4r_rmsnorm_bf16": [P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "g4r_groupnorm_affine_nhwc_bf16": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
@@ -627,3 +633,113 @@ def linear_wgrad(dy, x, out_dtype=torch.float32, splits=None):
         tiles = -(-dyt.size(0) // 128) * -(-xt.size(0) // 128)
         splits = max(1, min(8, 512 // max(tiles, 1), m_pad // 256))
     return gemm(dyt, xt, out_dtype=out_dtype, splits=splits)
+
+
+# ---- region-module backward ----------------------------------------------------------------------------------
+def groupnorm_stats(z, groups, eps=1e-5):
+    """z [B, H, W, C] bf16 -> (mean, rstd) [B, groups, 2] fp32."""
+    _bf16(z)
+    B, H, W, C = z.shape
+    part = torch.empty((B, 256, groups, 2), dtype=torch.float32, device=z.device)
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=z.device)
+    _launch("g4r_groupnorm_stats_nhwc_bf16", (_p(z), _p(part), _p(stats), B, H * W, C, groups, float(eps), _stream(z),),
+            tag="g4r_groupnorm_stats_nhwc_bf16")
+    return stats
+
+
+def gn_relu_bwd(z, dy, affine, gamma, stats, dgamma, dbeta, groups):
+    """y = relu(GN(z)): dy fp32 [B,H,W,C] -> dz bf16; dgamma / dbeta (fp32 [C]) accumulated."""
+    _bf16(z)
+    _f32(dy, affine, gamma, stats, dgamma, dbeta)
+    B, H, W, C = z.shape
+    assert dy.shape == z.shape and dy.is_contiguous() and z.is_contiguous()
+    gsum = torch.empty((B, groups, 2), dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z)
+    _launch("g4r_gn_relu_bwd_nhwc_bf16", (_p(z), _p(dy), _p(affine), _p(gamma), _p(stats), _p(dgamma), _p(dbeta),
+                                          _p(gsum), _p(dz), B, H * W, C, groups, _stream(z),),
+            tag="g4r_gn_relu_bwd_nhwc_bf16", nbytes=float(z.numel() * (2 * 2 + 2 * 4 + 2)))
+    return dz
+
+
+def fuse_shuffle_bwd(dinp, d_own, d_top, d_down):
+    """dinp bf16 [B,H,W,C]; d_* fp32 NHWC gradient maps (accumulated)."""
+    _bf16(dinp)
+    _f32(d_own, d_top, d_down)
+    B, H, W, C = dinp.shape
+    assert dinp.is_contiguous() and d_own.shape == dinp.shape
+    for d in (d_own, d_top, d_down):
+        assert d.is_contiguous() and d.size(0) == B and d.size(3) == C
+    _launch("g4r_fuse_shuffle_bwd_nhwc_bf16", (_p(dinp), H, W, _p(d_own), _p(d_top), d_top.size(1), d_top.size(2),
+                                               _p(d_down), d_down.size(1), d_down.size(2), B, C, _stream(dinp),),
+            tag="g4r_fuse_shuffle_bwd_nhwc_bf16")
+
+
+def roi_align_mlvl_bwd(dout, lvl_stride, pix_stride, grads, rois, output_size, scales, sampling_ratio=2, aligned=True):
+    """dout bf16 (any layout described by the two strides, see g4r_train.h); grads: list of fp32 NHWC maps."""
+    _bf16(dout)
+    L = len(grads)
+    for g in grads:
+        _f32(g)
+        assert g.is_contiguous() and g.dim() == 4
+    _f32(rois)
+    rois = rois.contiguous()
+    B, _, _, C = grads[0].shape
+    N = rois.size(0)
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    PA = c_void_p * L
+    ga = PA(*[g.data_ptr() for g in grads])
+    ha = (c_int * L)(*[g.size(1) for g in grads])
+    wa = (c_int * L)(*[g.size(2) for g in grads])
+    sa = (c_float * L)(*[float(s) for s in scales])
+    _launch("g4r_roi_align_mlvl_nhwc_bwd_bf16", (_p(dout), int(lvl_stride), int(pix_stride), ctypes.cast(ga, P),
+                                                 ctypes.cast(ha, P), ctypes.cast(wa, P), ctypes.cast(sa, P), L,
+                                                 _p(rois), B, C, N, ph, pw, int(sampling_ratio), int(bool(aligned)),
+                                                 _stream(rois)), tag="roi_align_mlvl_nhwc_bwd")
+
+
+def conv3x3_dgrad_weight(ws):
+    """Conv weights [Cout, Cin, 3, 3] (one per group) -> prepared weight of the transposed convolution
+    dX = conv3x3(dY, W^T rotated by 180 degrees); the groups' input gradients are stacked on the output channels:
+    result [groups*Cin, 9*Cout]."""
+    if isinstance(ws, torch.Tensor):
+        ws = [ws]
+    wt = torch.cat([w.flip(2, 3).permute(1, 0, 2, 3) for w in ws], 0)
+    return prep_conv3x3_weight(wt)
+
+
+class ConvWgradPlan:
+    """Buffers for the 3x3 weight gradient of ONE map geometry [B, H, W]: channel-major zero-bordered copies of
+    the input (3 column shifts) and of the output gradient, reused across steps (the borders stay zero)."""
+
+    def __init__(self, B, H, W, cin, cout, device):
+        self.B, self.H, self.W, self.cin, self.cout = B, H, W, cin, cout
+        self.Wp = -(-(W + 2) // 8) * 8
+        self.seg = (H + 2) * self.Wp
+        self.base = self.Wp + 8
+        self.kp = -(-(B * self.seg) // 64) * 64
+        self.ltot = -(-(self.base + self.kp + self.Wp + 8) // 64) * 64
+        self.xt = torch.zeros((3, cin, self.ltot), dtype=torch.bfloat16, device=device)
+        self.dt = torch.zeros((1, cout, self.ltot), dtype=torch.bfloat16, device=device)
+
+    def _fill(self, src, dst, n_shift):
+        B, H, W, C = src.shape
+        _launch("g4r_nhwc_to_cm_padded_bf16", (_p(src), _p(dst), B, H, W, C, self.Wp, self.seg, self.base, self.ltot,
+                                               n_shift, _stream(src),), tag="g4r_nhwc_to_cm_padded_bf16",
+                nbytes=2.0 * src.numel() * (1 + n_shift))
+
+    def wgrad(self, x, dy):
+        """x [B,H,W,Cin], dy [B,H,W,Cout] bf16 NHWC -> dW [Cout, Cin, 3, 3] fp32 (torch conv layout)."""
+        _bf16(x, dy)
+        assert x.is_contiguous() and dy.is_contiguous()
+        assert x.shape == (self.B, self.H, self.W, self.cin) and dy.shape == (self.B, self.H, self.W, self.cout)
+        self._fill(x, self.xt, 3)
+        self._fill(dy, self.dt, 1)
+        a = self.dt[0][:, self.base:self.base + self.kp]
+        tiles = -(-self.cout // 128) * -(-self.cin // 128)
+        splits = max(1, min(8, 512 // tiles, self.kp // 512))
+        taps = []
+        for ky in range(3):
+            for kx in range(3):
+                o = self.base + (ky - 1) * self.Wp
+                taps.append(gemm(a, self.xt[kx][:, o:o + self.kp], out_dtype=torch.float32, splits=splits))
+        return torch.stack(taps, 2).view(self.cout, self.cin, 3, 3)

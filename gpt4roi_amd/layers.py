@@ -127,6 +127,76 @@ class MLVLFuseModule(nn.Module):
         return maps, affs
 
 
+    # ---- training rows ----------------------------------------------------------------
+    def forward_train(self, tokens, P, sizes):
+        """Same launches as forward(); additionally keeps the 1x1-conv inputs and every round's raw maps and
+        folded GN affines for backward()."""
+        if self._ready is None:
+            self.prepare()
+        r = self._ready
+        B = tokens[0].size(0)
+        xs, maps = [], []
+        for lvl, tok in enumerate(tokens):
+            H = sizes[lvl]
+            x = K.upsample_coord(tok, P, P, H, H, self.cpad)
+            y = K.gemm(x.view(B * H * H, self.cpad), r['w_in'][lvl], bias=r['b_in'][lvl])
+            xs.append(x)
+            maps.append(y.view(B, H, H, self.embed_dims))
+        all_maps, all_affs = [maps], [[None] * self.num_levels]
+        for rnd in range(self.num_fuse):
+            g, bt, groups, eps = r['gn'][rnd]
+            new_maps, new_affs = [], []
+            for tar, top, dow in self.fuse_lvl_list:
+                inp = K.fuse_shuffle(all_maps[-1][tar], all_maps[-1][top], all_maps[-1][dow], all_affs[-1][tar],
+                                     all_affs[-1][top], all_affs[-1][dow])
+                z = K.conv3x3(inp, r['w_f'][rnd])
+                new_maps.append(z)
+                new_affs.append(K.groupnorm_affine(z, g, bt, groups, eps))
+            all_maps.append(new_maps)
+            all_affs.append(new_affs)
+        return all_maps[-1], all_affs[-1], dict(xs=xs, maps=all_maps, affs=all_affs, B=B)
+
+    def backward(self, ctx, d_y):
+        """d_y: list[num_levels] of fp32 NHWC gradients w.r.t. the POST GN+ReLU maps of the last round.
+        Returns {state_dict key: fp32 gradient in the reference layout}.  (No input gradient: the ViT is frozen.)"""
+        r = self._ready
+        C, B = self.embed_dims, ctx['B']
+        dev = d_y[0].device
+        grads = {}
+        if getattr(self, '_wgrad_plans', None) is None or self._wgrad_plans[0].B != B or \
+                [p.H for p in self._wgrad_plans] != [m.size(1) for m in ctx['maps'][0]]:
+            self._wgrad_plans = [K.ConvWgradPlan(B, m.size(1), m.size(2), C, C, dev) for m in ctx['maps'][0]]
+        for rnd in range(self.num_fuse - 1, -1, -1):
+            g, bt, groups, eps = r['gn'][rnd]
+            z_r, aff_r = ctx['maps'][rnd + 1], ctx['affs'][rnd + 1]
+            prev, paff = ctx['maps'][rnd], ctx['affs'][rnd]
+            d_prev = [torch.zeros(m.shape, dtype=torch.float32, device=dev) for m in prev]
+            dgamma = torch.zeros(C, dtype=torch.float32, device=dev)
+            dbeta = torch.zeros(C, dtype=torch.float32, device=dev)
+            wt = K.conv3x3_dgrad_weight(self.fuse_convs[rnd].conv.weight.detach())
+            dW = None
+            for tar, top, dow in self.fuse_lvl_list:
+                stats = K.groupnorm_stats(z_r[tar], groups, eps)
+                dz = K.gn_relu_bwd(z_r[tar], d_y[tar], aff_r[tar], g, stats, dgamma, dbeta, groups)
+                inp = K.fuse_shuffle(prev[tar], prev[top], prev[dow], paff[tar], paff[top], paff[dow])
+                w = self._wgrad_plans[tar].wgrad(inp, dz)
+                dW = w if dW is None else dW + w
+                dinp = K.conv3x3(dz, wt)
+                K.fuse_shuffle_bwd(dinp, d_prev[tar], d_prev[top], d_prev[dow])
+            grads[f'fuse_convs.{rnd}.conv.weight'] = dW
+            grads[f'fuse_convs.{rnd}.gn.weight'] = dgamma
+            grads[f'fuse_convs.{rnd}.gn.bias'] = dbeta
+            d_y = d_prev
+        cin = self.input_dims + 2
+        for lvl in range(self.num_levels):
+            dm = K.cast_bf16(d_y[lvl].view(-1, C))
+            x = ctx['xs'][lvl]
+            dw = K.linear_wgrad(dm, x.view(-1, self.cpad))
+            grads[f'input_conv.{lvl}.weight'] = dw[:, :cin].reshape(C, cin, 1, 1).contiguous()
+            grads[f'input_conv.{lvl}.bias'] = K.colsum(dm)
+        return grads
+
+
 class PreparedBoxes:
     """Host-side preparation of a request's boxes, done ONCE outside the launch sequence so that the
     per-image kernel sequence has no host<->device traffic and can be captured in a hipGraph:
@@ -245,6 +315,80 @@ class MlvlRoIExtractor(BaseRoIExtractor):
         return list(torch.split(x, counts, 0))
 
 
+    # ---- training rows ---------------------------------------------------------------------------------------
+    def forward_train(self, feats, rois, affines=None, image_size=224):
+        """forward() that also returns the intermediates backward() needs."""
+        if self._ready is None:
+            self.prepare()
+        r = self._ready
+        dev = feats[0].device
+        prep = rois if isinstance(rois, PreparedBoxes) else PreparedBoxes(rois, image_size, dev)
+        assert prep.n > 0, "training needs at least one box"
+        h1 = K.gemm(prep.boxes_bf16, r['pe0'][0], bias=r['pe0'][1], act='relu')
+        l2 = K.layernorm(h1, r['ln2'][0], r['ln2'][1], r['ln2'][2])
+        h3 = K.gemm(l2, r['pe3'][0], bias=r['pe3'][1], act='relu')
+        pe = K.layernorm(h3, r['ln5'][0], r['ln5'][1], r['ln5'][2])
+        rl = self.roi_layers[0]
+        roi_feats = K.roi_align_mlvl(feats, prep.rois5, rl.output_size, [l.spatial_scale for l in self.roi_layers],
+                                     sampling_ratio=rl.sampling_ratio, aligned=rl.aligned, affines=affines)
+        fused = K.conv3x3(roi_feats, r['w_p'], bias=r['b_p'], act='relu', groups=self.fuse_level)
+        flat = fused.view(prep.n, -1)
+        x = K.gemm(flat, r['w_fl'], bias=r['b_fl'], splits=64, tile_cfg=4)
+        xs = K.add_rows(x, pe)
+        out = K.gemm(xs, r['up'][0], bias=r['up'][1])
+        ctx = dict(prep=prep, h1=h1, l2=l2, h3=h3, roi_feats=roi_feats, fused=fused, xs=xs,
+                   shapes=[tuple(f.shape) for f in feats])
+        return out, ctx
+
+    def backward(self, ctx, d_out):
+        """d_out bf16 [N, out_dims] -> ({state_dict key: fp32 gradient, reference layout}, list of fp32 NHWC
+        gradients w.r.t. the (post GN+ReLU) feature maps)."""
+        r = self._ready
+        prep = ctx['prep']
+        N, C, L = prep.n, self.embed_dims, self.fuse_level
+        oh, ow = self.roi_layers[0].output_size
+        dev = d_out.device
+        d_out = d_out.contiguous()
+        g = {}
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)  # noqa: E731
+        # updims
+        g['updims.weight'] = K.linear_wgrad(d_out, ctx['xs'])
+        g['updims.bias'] = K.colsum(d_out)
+        d_x = K.gemm(d_out, K.transpose(r['up'][0]))
+        # pos_embedd: Linear -> ReLU -> LN -> Linear -> ReLU -> LN   (layers.py:260-267)
+        g['pos_embedd.5.weight'], g['pos_embedd.5.bias'] = z(1024), z(1024)
+        d_h3 = K.layernorm_bwd(ctx['h3'], r['ln5'][0], d_x, g['pos_embedd.5.weight'], g['pos_embedd.5.bias'], r['ln5'][2])
+        d_p3 = K.relu_bwd(ctx['h3'], d_h3)
+        g['pos_embedd.3.weight'] = K.linear_wgrad(d_p3, ctx['l2'])
+        g['pos_embedd.3.bias'] = K.colsum(d_p3)
+        d_l2 = K.gemm(d_p3, K.transpose(r['pe3'][0]))
+        g['pos_embedd.2.weight'], g['pos_embedd.2.bias'] = z(256), z(256)
+        d_h1 = K.layernorm_bwd(ctx['h1'], r['ln2'][0], d_l2, g['pos_embedd.2.weight'], g['pos_embedd.2.bias'], r['ln2'][2])
+        d_p1 = K.relu_bwd(ctx['h1'], d_h1)
+        g['pos_embedd.0.weight'] = K.linear_wgrad(d_p1, prep.boxes_bf16)
+        g['pos_embedd.0.bias'] = K.colsum(d_p1)
+        # flatten_linear (kernel layout: column pos*C + c; reference: column c*oh*ow + pos)
+        flat = ctx['fused'].view(N, -1)
+        dwf = K.linear_wgrad(d_x, flat)
+        g['flatten_linear.weight'] = dwf.view(-1, oh * ow, C).permute(0, 2, 1).reshape(dwf.size(0), -1).contiguous()
+        g['flatten_linear.bias'] = K.colsum(d_x)
+        d_flat = K.gemm(d_x, K.transpose(r['w_fl']))
+        d_pre = K.relu_bwd(flat, d_flat).view(N, oh, ow, C)
+        # pconvs: sum_l conv_l(roi_feats[l]) + sum_l bias_l
+        db = K.colsum(d_pre.view(-1, C))
+        if getattr(self, '_pplan', None) is None or self._pplan.B != N:
+            self._pplan = K.ConvWgradPlan(N, oh, ow, C, C, dev)
+        for l in range(L):
+            g[f'pconvs.{l}.bias'] = db if l == 0 else db.clone()
+            g[f'pconvs.{l}.weight'] = self._pplan.wgrad(ctx['roi_feats'][l], d_pre)
+        d_roi = K.conv3x3(d_pre, K.conv3x3_dgrad_weight([c.weight.detach() for c in self.pconvs]))  # [N,oh,ow,L*C]
+        d_maps = [torch.zeros(sh, dtype=torch.float32, device=dev) for sh in ctx['shapes']]
+        rl = self.roi_layers[0]
+        K.roi_align_mlvl_bwd(d_roi, C, L * C, d_maps, prep.rois5, rl.output_size,
+                             [l.spatial_scale for l in self.roi_layers], rl.sampling_ratio, rl.aligned)
+        return g, d_maps
+
+
 class MLVLROIQueryModule(nn.Module):
 
     def __init__(self, embed_dims=1024, out_dims=4096, num_levels=3):
@@ -262,11 +406,7 @@ class MLVLROIQueryModule(nn.Module):
         self.mlvl_fuse.prepare()
         self.roi_align.prepare()
 
-    @torch.no_grad()
-    def forward(self, mlvl_feats, bboxes):
-        """mlvl_feats: list[4] of [B, P*P, C] (token form, as spi_llava.py:80-82 passes) or
-        [B, C, P, P]; bboxes: list[B] of [n_i, 4] normalised xyxy.  Returns list[B] of
-        [n_i, out_dims] bf16."""
+    def _tokens(self, mlvl_feats):
         toks = []
         for f in mlvl_feats:
             if f.dim() == 4:                                   # NCHW -> token form
@@ -279,6 +419,33 @@ class MLVLROIQueryModule(nn.Module):
         assert P * P == toks[0].shape[1], "level features must be square token grids"
         n = len(toks)
         sizes = [P * 2 ** l for l in range(n)][::-1]          # level 0 (shallowest ViT layer) is finest
+        return toks, P, sizes
+
+    @torch.no_grad()
+    def forward_train(self, mlvl_feats, bboxes):
+        """Training forward: (region embeddings [N, out_dims] bf16 concatenated over the batch, ctx)."""
+        toks, P, sizes = self._tokens(mlvl_feats)
+        maps, affs, fctx = self.mlvl_fuse.forward_train(toks, P, sizes)
+        out, rctx = self.roi_align.forward_train(maps, bboxes, affines=affs, image_size=14 * P)
+        return out, dict(fuse=fctx, roi=rctx)
+
+    @torch.no_grad()
+    def backward(self, ctx, d_out):
+        """d_out bf16 [N, out_dims] (rows in the order of cat(bboxes)) -> {state_dict key: fp32 gradient in the
+        reference layout} for every parameter of the module (the gradients autograd gives the reference through
+        gpt4roi/models/layers.py:218-236)."""
+        g_roi, d_maps = self.roi_align.backward(ctx['roi'], d_out)
+        g_fuse = self.mlvl_fuse.backward(ctx['fuse'], d_maps)
+        grads = {f'roi_align.{k}': v for k, v in g_roi.items()}
+        grads.update({f'mlvl_fuse.{k}': v for k, v in g_fuse.items()})
+        return grads
+
+    @torch.no_grad()
+    def forward(self, mlvl_feats, bboxes):
+        """mlvl_feats: list[4] of [B, P*P, C] (token form, as spi_llava.py:80-82 passes) or
+        [B, C, P, P]; bboxes: list[B] of [n_i, 4] normalised xyxy.  Returns list[B] of
+        [n_i, out_dims] bf16."""
+        toks, P, sizes = self._tokens(mlvl_feats)
         maps, affs = self.mlvl_fuse(toks, P, sizes)
         if isinstance(bboxes, PreparedBoxes):
             assert bboxes.image_size == 14 * P, "PreparedBoxes built for another image size"

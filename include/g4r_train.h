@@ -81,6 +81,45 @@ int g4r_adamw_f32(float* param, const void* grad, int grad_is_bf16, float* exp_a
                   void* param_bf16, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int step, float grad_scale, void* stream);
 
+/* ---- region module (gpt4roi/models/layers.py:96-335) ------------------------------------------------------ */
+
+/* Per-(image, group) mean and rstd of a raw NHWC conv output: stats [B, G, 2] fp32.  The forward
+ * (g4r_groupnorm_affine_nhwc_bf16) keeps only the folded affine, the backward recomputes the statistics.
+ * partial: scratch, B*256*G*2 floats. */
+int g4r_groupnorm_stats_nhwc_bf16(const void* x, float* partial, float* stats, int B, int HW, int C, int G, float eps,
+                                  void* stream);
+
+/* Backward of ConvModule's GroupNorm + ReLU (mmcv conv_module.py:196-206) applied to the raw conv output z:
+ * y = relu(a*z + s).  dy fp32 [B, HW, C] = gradient w.r.t. y; affine [B, 2, C] from the forward; stats from
+ * g4r_groupnorm_stats_nhwc_bf16; dgamma/dbeta fp32 [C] are accumulated; gsum scratch [B, G, 2]; dz bf16. */
+int g4r_gn_relu_bwd_nhwc_bf16(const void* z, const float* dy, const float* affine, const float* gamma,
+                              const float* stats, float* dgamma, float* dbeta, float* gsum, void* dz, int B, int HW,
+                              int C, int G, void* stream);
+
+/* Transpose of g4r_fuse_shuffle_nhwc_bf16 (MLVLFuseModule._single_shuffle, layers.py:152-180): the gradient of
+ * one level's conv input is scattered (fp32 atomics, bilinear align_corners weights) into the gradient maps of
+ * the level itself (channels [0, C/2)), its coarser neighbour (channels [3C/4, C)) and its finer neighbour
+ * (channels [C/2, 3C/4)). */
+int g4r_fuse_shuffle_bwd_nhwc_bf16(const void* dinp, int H, int W, float* d_own, float* d_top, int Ht, int Wt,
+                                   float* d_down, int Hd, int Wd, int B, int C, void* stream);
+
+/* NHWC bf16 [B, H, W, C] -> channel-major rows with a zero border:
+ *   dst[s][c][base + b*seg + (y+1)*Wp + (x+1) - (s - n_shift/2)] = src[b][y][x][c],   dst [n_shift, C, ltot]
+ * The 3x3 weight gradient is then 9 NT GEMMs over the pixel axis,
+ *   dW[co][ci][ky][kx] = sum_p dY^T[co][p] * X^T_{kx}[ci][p + (ky-1)*Wp],
+ * with every operand row 16-byte aligned (n_shift = 3 for X, 1 for dY).  dst must be zero-initialised once. */
+int g4r_nhwc_to_cm_padded_bf16(const void* src, void* dst, int B, int H, int W, int C, int Wp, long seg, long base,
+                               long ltot, int n_shift, void* stream);
+
+/* Backward of g4r_roi_align_mlvl_nhwc_bf16 (g4r_roi_align.h): dout bf16 with element (l, n, ph, pw, c) at
+ * dout[l*lvl_stride + ((n*PH + ph)*PW + pw)*pix_stride + c]; grads[l] fp32 NHWC [B, H_l, W_l, C] accumulate the
+ * gradient w.r.t. the (post GroupNorm+ReLU) feature maps.  Replaces roi_align_backward
+ * (mmcv-1.4.7/mmcv/ops/csrc/common/cuda/roi_align_cuda_kernel.cuh:111-210) for the fused module. */
+int g4r_roi_align_mlvl_nhwc_bwd_bf16(const void* dout, long lvl_stride, long pix_stride, float* const* grads,
+                                     const int* heights, const int* widths, const float* scales, int levels,
+                                     const float* rois, int batch, int channels, int n_rois, int pooled_h,
+                                     int pooled_w, int sampling_ratio, int aligned, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,8 +53,30 @@ class ConvModuleOracle(nn.Module):
         return F.relu(self.gn(_r(y, emulate)))
 
 
+class _RoIAlignOracleFn(torch.autograd.Function):
+    """The C oracle's forward and backward (oracle/roi_align_oracle.c, both pinned bit-exact to the reference's CPU
+    build) as one autograd node: what mmcv's RoIAlignFunction is for the reference (mmcv/ops/roi_align.py:64-128)."""
+
+    @staticmethod
+    def forward(ctx, x, rois, output_size, spatial_scale, sampling_ratio, pool_mode, aligned):
+        assert pool_mode == 'avg'
+        out, _, _ = roi_oracle.forward(x.detach().float().numpy(), rois.detach().float().numpy(), output_size,
+                                       np.float32(spatial_scale), sampling_ratio, pool_mode, aligned)
+        ctx.save_for_backward(rois)
+        ctx.cfg = (tuple(x.shape), output_size, spatial_scale, sampling_ratio, pool_mode, aligned)
+        return torch.from_numpy(out)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (rois,) = ctx.saved_tensors
+        shape, output_size, spatial_scale, sampling_ratio, pool_mode, aligned = ctx.cfg
+        gin = roi_oracle.backward(grad_out.contiguous().float().numpy(), rois.detach().float().numpy(), shape,
+                                  output_size, np.float32(spatial_scale), sampling_ratio, pool_mode, aligned)
+        return torch.from_numpy(gin), None, None, None, None, None, None
+
+
 class RoIAlignOracle(nn.Module):
-    """mmcv.ops.RoIAlign restated on the C oracle (forward only)."""
+    """mmcv.ops.RoIAlign restated on the C oracle (differentiable w.r.t. the feature map)."""
 
     def __init__(self, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode='avg', aligned=True):
         super().__init__()
@@ -65,6 +87,9 @@ class RoIAlignOracle(nn.Module):
         self.aligned = aligned
 
     def forward(self, x, rois):
+        if x.requires_grad:
+            return _RoIAlignOracleFn.apply(x, rois, self.output_size, self.spatial_scale, self.sampling_ratio,
+                                           self.pool_mode, self.aligned)
         out, _, _ = roi_oracle.forward(x.detach().float().numpy(), rois.detach().float().numpy(),
                                        self.output_size, np.float32(self.spatial_scale), self.sampling_ratio,
                                        self.pool_mode, self.aligned)
