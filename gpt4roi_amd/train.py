@@ -1,0 +1,129 @@
+"""One training step of the region-feature path on the gfx950 kernels.
+
+What the reference runs per step under HF Trainer (/root/reference/gpt4roi/train/train.py:698-712 with
+train_stage1.sh: `ONLY_SPI=1`, bf16, per-device batch 1, AdamW lr 2e-5, weight decay 0, cosine schedule, warm-up
+ratio 0.003, max_grad_norm 1.0 (HF default), DDP over the GPUs of one node):
+
+    forward (ViT frozen -> region module -> projector -> splice -> LLaMA frozen -> lm_head -> shifted CE)
+    backward to the trainable parameters (autograd), gradient all-reduce (DDP), clip, AdamW.
+
+Here the same step is an explicit launch sequence: `forward_train` of every stage keeps what its hand-written
+backward needs, the frozen decoder only propagates the activation gradient (W^T GEMMs, flash-attention backward),
+the region module produces its parameter gradients in the reference's state_dict layout, the exchange step is
+grad_reduce.GradBucketReducer (reduce-scatter + all-gather over xGMI, one process per GPU), and AdamW is one fused
+kernel per tensor on the fp32 master weights (the nn.Parameters themselves, so checkpoints keep the reference's
+keys).  There is no autograd graph and no CPU fallback.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+from .grad_reduce import GradBucketReducer
+from .layers import PreparedBoxes
+
+
+def cosine_lr(step, total_steps, base_lr, warmup_ratio=0.003):
+    """HF `get_cosine_schedule_with_warmup` (lr_scheduler_type "cosine", train_stage1.sh): step counts from 0."""
+    warm = math.ceil(total_steps * warmup_ratio)
+    if step < warm:
+        return base_lr * step / max(1, warm)
+    prog = (step - warm) / max(1, total_steps - warm)
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+
+
+class RegionTrainer:
+    """Stage-1 trainer: `model.spi_module` (and optionally `model.mm_projector`) are updated, the vision tower and
+    the decoder stay frozen.  `step()` returns the mean token loss as a device tensor."""
+
+    def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
+                 train_projector=False, group=None, bucket_bytes=256 << 20):
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.train_projector = train_projector
+        dev = model.llama.device
+        model.spi_module.to(dev)
+        model.mm_projector.to(dev)
+        model.prepare()
+        model.llama.prepare_training(train_weights=False)
+        self.params = {f"spi_module.{k}": p for k, p in model.spi_module.named_parameters()}
+        if train_projector:
+            self.params.update({f"mm_projector.{k}": p for k, p in model.mm_projector.named_parameters()})
+        for p in self.params.values():
+            assert p.dtype == torch.float32 and p.is_contiguous()
+            p.requires_grad_(True)
+        self.state = {k: (torch.zeros_like(p.data), torch.zeros_like(p.data)) for k, p in self.params.items()}
+        self.steps = 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.reducer = GradBucketReducer(list(self.params.values()), bucket_bytes=bucket_bytes, group=group,
+                                         comm_dtype=torch.float32) if self.world > 1 else None
+        self.last_grad_norm = None
+
+    # ---- forward + backward: parameter gradients in the reference layout ------------------------------------
+    @torch.no_grad()
+    def loss_and_grads(self, input_ids, images, bboxes, labels):
+        m = self.model
+        cfg = m.config
+        B, T = input_ids.shape
+        tower = m.vision_tower[0]
+        if isinstance(images, (list, tuple)):
+            images = torch.stack(list(images), 0)
+        keep = tower.forward(images)
+        image_features, mlvl = tower.select(keep)
+        if not isinstance(bboxes, PreparedBoxes):
+            bboxes = PreparedBoxes(bboxes, images.size(-1), images.device)
+        spi, sctx = m.spi_module.forward_train(mlvl, bboxes)
+        n_patch, Cv = image_features.size(1), image_features.size(2)
+        img_tok = torch.empty((B, n_patch, m.llama.hidden), dtype=torch.bfloat16, device=images.device)
+        for b in range(B):
+            K.gemm(image_features[b], m._proj[0], bias=m._proj[1], out=img_tok[b])
+        embeds, status = K.splice_embed(input_ids.contiguous(), m.llama.embed, img_tok, spi, bboxes.offsets, n_patch,
+                                        cfg.im_patch_token, cfg.bbox_token, cfg.im_start_token, cfg.im_end_token)
+        m.last_status = status
+        m.llama.reset(B)
+        logits, lctx = m.llama.forward_train(embeds)
+        loss, dlogits = m.llama.loss_and_dlogits(logits, labels)
+        d_emb = m.llama.backward(lctx, dlogits)                                  # [B*T, C] bf16
+        flat = input_ids.reshape(-1)
+        idx_bbox = (flat == cfg.bbox_token).nonzero().flatten().to(torch.int32)
+        assert idx_bbox.numel() == bboxes.n, "number of <bbox> tokens != number of regions"
+        grads = {f"spi_module.{k}": g for k, g in m.spi_module.backward(sctx, K.gather_rows(d_emb, idx_bbox)).items()}
+        if self.train_projector:
+            idx_patch = (flat == cfg.im_patch_token).nonzero().flatten().to(torch.int32)
+            d_img = K.gather_rows(d_emb, idx_patch)                              # [B*n_patch, C]
+            x = image_features.reshape(B * n_patch, Cv)
+            grads["mm_projector.weight"] = K.linear_wgrad(d_img, x)
+            grads["mm_projector.bias"] = K.colsum(d_img)
+        return loss, grads
+
+    # ---- exchange, clip, AdamW ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def apply(self, grads, lr=None):
+        names = list(self.params)
+        if self.reducer is not None:
+            self.reducer.reset()
+            for k in reversed(names):                      # the order backward produced them (head of the module first)
+                self.reducer.ready(self.params[k], grads[k])
+            red = self.reducer.finish()
+            grads = {k: red[id(self.params[k])] for k in names}
+        scale = 1.0
+        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+            norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(grads[k]) for k in names]))
+            self.last_grad_norm = norm
+            scale = min(1.0, self.max_grad_norm / (float(norm) + 1e-6))      # torch.nn.utils.clip_grad_norm_
+        self.steps += 1
+        lr = self.lr if lr is None else lr
+        for k in names:
+            p = self.params[k]
+            m_, v_ = self.state[k]
+            g = grads[k]
+            K.adamw(p.data, g.contiguous() if g.dtype == torch.float32 else g.float().contiguous(), m_, v_,
+                    self.steps, lr, self.betas, self.eps, self.weight_decay, grad_scale=scale)
+        self.model.prepare()                                # refresh the bf16 kernel copies of the updated weights
+
+    def step(self, input_ids, images, bboxes, labels, lr=None):
+        loss, grads = self.loss_and_grads(input_ids, images, bboxes, labels)
+        self.apply(grads, lr)
+        return loss

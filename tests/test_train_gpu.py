@@ -401,3 +401,84 @@ def test_region_module_parameter_gradients():
     head = [k for k in ref if k.startswith(("roi_align.updims", "roi_align.pos_embedd", "roi_align.flatten_linear"))]
     assert max(worst[k] for k in head) < 1e-2, {k: worst[k] for k in head}
     assert max(worst.values()) < 0.2 and min(coss.values()) > 0.99, (worst, coss)
+
+
+# ------------------------------------------------------------------------------------------ whole step
+def test_stage1_training_step_end_to_end():
+    """forward -> loss -> backward -> clip -> AdamW of train.RegionTrainer on a mini model: loss and every region-
+    module gradient against autograd through the CPU oracles, the update against torch.optim.AdamW fed with the same
+    gradients, and the loss must go down when the step is repeated on the batch."""
+    from gpt4roi_amd.spi_llava import SPILlavaLlamaModel
+    from gpt4roi_amd.train import RegionTrainer, cosine_lr
+    from gpt4roi_amd.vit import ClipVisionTower
+    H, P, image = 512, 8, 112
+    ids = syn.token_ids(vocab_base=990)
+    vsd = syn.vit_state(H, 4 * H, 12, image, seed=8)
+    lsd = syn.llama_state(512, 1408, 2, ids.vocab, seed=9)
+    tower = ClipVisionTower(vsd, heads=8, device=DEV)
+    dec = LlamaDecoder(lsd, heads=4, max_positions=256, device=DEV)
+    model = SPILlavaLlamaModel(tower, dec, ids, embed_dims=H)
+    orc = S.MLVLROIQueryOracle(embed_dims=H, P=P)
+    orc.roi_align.updims = torch.nn.Linear(1024, 512)
+    spi_sd = S.synthetic_state(orc, 10)
+    orc.load_state_dict(spi_sd)
+    model.spi_module.load_state_dict(spi_sd)
+    g = torch.Generator().manual_seed(11)
+    pw, pb = torch.randn(512, H, generator=g) / H ** 0.5, torch.randn(512, generator=g) * 0.05
+    with torch.no_grad():
+        model.mm_projector.weight.copy_(pw)
+        model.mm_projector.bias.copy_(pb)
+    img = torch.randn(1, 3, image, image, generator=g)
+    boxes = [syn.boxes(3, g)]
+    prompt = syn.prompt_ids(ids, P, 3, g, sys_len=6, question_len=9, vocab_base=990)[None]
+    labels = prompt.clone()
+    labels[:, :8 + P * P] = -100                                   # system prompt and image: no loss
+    labels[labels >= 990] = -100                                   # special tokens are never targets
+    tr = RegionTrainer(model, lr=2e-6, max_grad_norm=1.0)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    loss, grads = tr.loss_and_grads(dev(prompt), dev(img), [dev(b) for b in boxes], dev(labels))
+    # ---- oracle pipeline with autograd ----
+    bf = lambda x: x.to(torch.bfloat16).float()  # noqa: E731
+    vb = {k: bf(v) for k, v in vsd.items()}
+    lb = {k: bf(v) for k, v in lsd.items()}
+    with torch.no_grad():
+        hs = T.clip_vit_hidden_states(vb, img, heads=8, n_layers=11, emulate=True)
+        img_feat, lv = T.select_spi_levels(hs + [hs[-1]], -2, 4)
+        proj = bf(bf(img_feat) @ bf(pw).t() + bf(pb))
+        emb = bf(lsd["model.embed_tokens.weight"])[prompt]
+    spi = orc(lv, boxes, emulate=True)
+    spliced = S.splice(prompt, emb, proj, spi, ids.im_start_token, ids.im_end_token, ids.bbox_token)
+    h, _ = T.llama_forward(lb, spliced, heads=4, emulate=True)
+    logits = T.lm_logits(lb, h, emulate=True)
+    ref_loss = F.cross_entropy(logits[:, :-1].reshape(-1, ids.vocab), labels[:, 1:].reshape(-1), ignore_index=-100)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 3e-2 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+    ref = {f"spi_module.{k}": v.grad for k, v in orc.named_parameters()}
+    assert set(grads) == set(ref)
+    coss = {k: cosine(grads[k], ref[k]) for k in ref}
+    errs = {k: relerr(grads[k], ref[k]) for k in ref}
+    print("step gradients (cos, max-norm err):", sorted((round(coss[k], 4), round(errs[k], 3), k) for k in ref)[:6])
+    assert min(coss.values()) > 0.97 and max(errs.values()) < 0.3, (coss, errs)
+    # ---- clip + AdamW against torch on the same gradients ----
+    lr = 2e-6                                                       # keeps the first Adam step in the linear regime
+    names = list(tr.params)
+    before = {k: tr.params[k].detach().cpu().clone() for k in names}
+    cpu_params = [torch.nn.Parameter(before[k].clone()) for k in names]
+    for p, k in zip(cpu_params, names):
+        p.grad = grads[k].float().cpu().clone()
+    torch.nn.utils.clip_grad_norm_(cpu_params, 1.0)
+    opt = torch.optim.AdamW(cpu_params, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    opt.step()
+    tr.apply(grads, lr=lr)
+    predicted = 0.0
+    for p, k in zip(cpu_params, names):
+        assert relerr(tr.params[k].detach(), p.detach()) < 1e-4, k
+        assert not torch.equal(tr.params[k].detach().cpu(), before[k]), k
+        predicted += float(((p.detach() - before[k]).double() * grads[k].double().cpu()).sum())
+    # ---- the update moves the loss by what the gradient predicts (a directional derivative of the whole step) ----
+    l1 = tr.step(dev(prompt), dev(img), [dev(b) for b in boxes], dev(labels), lr=cosine_lr(50, 100, 2 * lr))
+    l2 = tr.step(dev(prompt), dev(img), [dev(b) for b in boxes], dev(labels), lr=lr)
+    print("loss over three steps:", loss.item(), l1.item(), l2.item(), "first-order prediction of step 1:", predicted)
+    assert predicted < -0.02
+    assert 0.5 * predicted > l1.item() - loss.item() > 1.5 * predicted, (l1.item() - loss.item(), predicted)
+    assert l2.item() < l1.item() < loss.item()
