@@ -529,12 +529,21 @@ struct MlvlGradArgs {
   float scale[G4R_MAX_LEVELS];
 };
 
+#define MLVL_BWD_MAX_PW 16
+
+// Narrow RoIs (the bin row touches <= 32 map columns; most RoIs on the coarse levels): the 2x2 samples of
+// neighbouring bins hit the same texels, so the block first folds the horizontal taps of its whole bin row into
+// LDS,  S[x][c] = sum_{pw,ix} (hx or lx) * d[pw][c] / count,  and then issues ONE atomic per (map row, column,
+// channel) instead of one per (bin, sample, corner): 4*ncols instead of 16*PW atomics per channel.
 __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_bwd_kernel(MlvlGradArgs a, const float* __restrict__ rois,
                                                                       const bf16_t* __restrict__ dout, long lvl_stride,
                                                                       long pix_stride, int L, int B, int C, int N,
                                                                       int PH, int PW, int sr, int aligned) {
   __shared__ Tap1D<float> xtab[MLVL_MAX_XTAB];
   __shared__ Tap1D<float> ytab[MLVL_MAX_YTAB];
+  __shared__ __attribute__((aligned(16))) float stage[MLVL_STAGE_COLS * MLVL_STAGE_CH];
+  __shared__ __attribute__((aligned(16))) float dstage[MLVL_BWD_MAX_PW * MLVL_STAGE_CH];
+  __shared__ int xrange[2];
   const int bid = blockIdx.x;
   const int xcd = bid & 7;
   const int q = bid >> 3;
@@ -545,9 +554,20 @@ __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_bwd_kernel(MlvlGradAr
   const int H = a.H[l], W = a.W[l];
   const RoiGeom<float> g = roi_geometry<float>(rois + (size_t)5 * n, a.scale[l], aligned, PH, PW, sr);
   const int tid = threadIdx.x;
+  if (tid == 0) {
+    xrange[0] = 0x7fffffff;
+    xrange[1] = -1;
+  }
   if (tid < sr) ytab[tid] = make_tap1d<float>(sample_coord<float>(g.start_h, g.bin_h, ph, tid, sr), H);
-  for (int i = tid; i < PW * sr; i += 256)
-    xtab[i] = make_tap1d<float>(sample_coord<float>(g.start_w, g.bin_w, i / sr, i % sr, sr), W);
+  __syncthreads();
+  for (int i = tid; i < PW * sr; i += 256) {
+    const Tap1D<float> t = make_tap1d<float>(sample_coord<float>(g.start_w, g.bin_w, i / sr, i % sr, sr), W);
+    xtab[i] = t;
+    if (t.valid) {
+      atomicMin(&xrange[0], t.lo);
+      atomicMax(&xrange[1], t.hi);
+    }
+  }
   __syncthreads();
   if (g.batch < 0 || g.batch >= B) return;
   const int wave = tid >> 6, lane = tid & 63;
@@ -555,6 +575,71 @@ __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_bwd_kernel(MlvlGradAr
   const float inv_count = 1.f / (float)(sr * sr);
   float* gm = a.grad[l] + (size_t)g.batch * H * W * C;
   const bf16_t* dbase = dout + (size_t)l * lvl_stride + ((size_t)n * PH + ph) * PW * pix_stride;
+
+  const int x_first = xrange[0];
+  const int ncols = xrange[1] - xrange[0] + 1;
+  if (ncols >= 1 && ncols <= MLVL_STAGE_COLS && PW <= MLVL_BWD_MAX_PW) {
+    const int vl = tid & 31, sub = tid >> 5;  // 32 vector lanes (256 channels) x 8 column / bin lanes
+    for (int c0 = 0; c0 < C; c0 += MLVL_STAGE_CH) {
+      const int cv = c0 + vl * 8;
+      const bool ch_ok = cv < C;
+      // phase 0: this bin row's output gradient (already divided by the sample count) into LDS
+      for (int pw = sub; pw < PW; pw += 8) {
+        Vec8 d;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d.v[k] = 0.f;
+        if (ch_ok) d = load8(dbase + (size_t)pw * pix_stride + cv);
+        float* dp = dstage + pw * MLVL_STAGE_CH + vl * 8;
+        *reinterpret_cast<float4v*>(dp) = float4v{d.v[0] * inv_count, d.v[1] * inv_count, d.v[2] * inv_count, d.v[3] * inv_count};
+        *reinterpret_cast<float4v*>(dp + 4) = float4v{d.v[4] * inv_count, d.v[5] * inv_count, d.v[6] * inv_count, d.v[7] * inv_count};
+      }
+      __syncthreads();
+      // phase 1: horizontal taps folded per map column
+      for (int col = sub; col < ncols; col += 8) {
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int t = 0; t < PW * sr; ++t) {
+          const Tap1D<float> tx = xtab[t];
+          if (!tx.valid) continue;
+          const float lx = tx.frac, hx = 1.f - lx;
+          const float w = (tx.lo - x_first == col ? hx : 0.f) + (tx.hi - x_first == col ? lx : 0.f);
+          if (w == 0.f) continue;
+          const float* dp = dstage + (t / sr) * MLVL_STAGE_CH + vl * 8;
+          const float4v d0 = *reinterpret_cast<const float4v*>(dp), d1 = *reinterpret_cast<const float4v*>(dp + 4);
+          acc[0] += w * d0.x; acc[1] += w * d0.y; acc[2] += w * d0.z; acc[3] += w * d0.w;
+          acc[4] += w * d1.x; acc[5] += w * d1.y; acc[6] += w * d1.z; acc[7] += w * d1.w;
+        }
+        float* sp = stage + col * MLVL_STAGE_CH + vl * 8;
+        *reinterpret_cast<float4v*>(sp) = float4v{acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<float4v*>(sp + 4) = float4v{acc[4], acc[5], acc[6], acc[7]};
+      }
+      __syncthreads();
+      // phase 2: vertical taps, one atomic per (map row, column, channel)
+      if (ch_ok) {
+        for (int col = sub; col < ncols; col += 8) {
+          const float* sp = stage + col * MLVL_STAGE_CH + vl * 8;
+          const float4v s0 = *reinterpret_cast<const float4v*>(sp), s1 = *reinterpret_cast<const float4v*>(sp + 4);
+          const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+          for (int iy = 0; iy < sr; ++iy) {
+            const Tap1D<float> ty = ytab[iy];
+            if (!ty.valid) continue;
+            const float ly = ty.frac, hy = 1.f - ly;
+            float* p1 = gm + ((size_t)ty.lo * W + x_first + col) * C + cv;
+            float* p3 = gm + ((size_t)ty.hi * W + x_first + col) * C + cv;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              unsafeAtomicAdd(p1 + k, hy * sv[k]);
+              unsafeAtomicAdd(p3 + k, ly * sv[k]);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
   for (int pw = wave; pw < PW; pw += 4) {
     for (int v = lane; v < nvec; v += 64) {
       Vec8 d = load8(dbase + (size_t)pw * pix_stride + v * 8);

@@ -274,6 +274,92 @@ __global__ __launch_bounds__(256) void fuse_shuffle_bwd_kernel(const bf16_t* __r
   }
 }
 
+// ---- the same transpose as a GATHER, one launch per SOURCE level: every gradient element is written once --------
+// (no zero-fill, no atomics; ~5x faster than the scatter on MI355X where 10^8 fp32 atomics per round dominate).
+//   channels [0, R)      <- d_inp of the level itself
+//   channels [R, R+S)    <- channel c+S of the COARSER target (which read this level as `down`) and, for level 0,
+//                           of the level itself (identity resize)
+//   channels [R+S, C)    <- channel c-S of the FINER target (which read this level as `top`) and, for the last
+//                           level, of the level itself
+// For a resampled target the candidate target rows/columns around src/scale are re-tested with the forward's own
+// lerp_ac(), so the weights are exactly the forward's.
+struct GatherTgt {
+  const bf16_t* g;  // bf16 [B, H, W, C] or null
+  int H, W;
+};
+
+__device__ __forceinline__ void cand_range(int j, int in_size, int out_size, int& lo, int& hi) {
+  if (out_size <= 1 || in_size <= 1) {
+    lo = 0;
+    hi = out_size - 1;
+    return;
+  }
+  const float inv = (float)(out_size - 1) / (float)(in_size - 1);
+  lo = (int)floorf((float)(j - 1) * inv) - 1;
+  hi = (int)ceilf((float)(j + 1) * inv) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out_size - 1) hi = out_size - 1;
+}
+
+__device__ __forceinline__ void gather_tgt(const GatherTgt& t, int b, int ys, int xs, int Hs, int Ws, int C, int ch,
+                                           F8& acc) {
+  int ylo, yhi, xlo, xhi;
+  cand_range(ys, Hs, t.H, ylo, yhi);
+  cand_range(xs, Ws, t.W, xlo, xhi);
+  const bf16_t* base = t.g + (size_t)b * t.H * t.W * C + ch;
+  for (int i = ylo; i <= yhi; ++i) {
+    const Lerp ly = lerp_ac(i, Hs, t.H);
+    const float wy = (ly.i0 == ys ? 1.f - ly.w1 : 0.f) + (ly.i1 == ys ? ly.w1 : 0.f);
+    if (wy == 0.f) continue;
+    for (int j = xlo; j <= xhi; ++j) {
+      const Lerp lx = lerp_ac(j, Ws, t.W);
+      const float wx = (lx.i0 == xs ? 1.f - lx.w1 : 0.f) + (lx.i1 == xs ? lx.w1 : 0.f);
+      if (wx == 0.f) continue;
+      const F8 d = ld8(base + ((size_t)i * t.W + j) * C);
+      const float w = wy * wx;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc.v[k] += w * d.v[k];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void fuse_shuffle_bwd_gather_kernel(float* __restrict__ dsrc, const bf16_t* __restrict__ own,
+                                                                      GatherTgt fine, GatherTgt coarse, int self_top,
+                                                                      int self_down, int B, int H, int W, int C) {
+  const int nvec = C >> 3;
+  const int R = C >> 1, S = C >> 2;
+  const long total = (long)B * H * W * nvec;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    const long pix = i / nvec;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long)W * H));
+    const int c = v * 8;
+    F8 acc;
+    if (c < R) {
+      acc = ld8(own + (size_t)pix * C + c);
+    } else if (c < R + S) {
+      if (self_down) acc = ld8(own + (size_t)pix * C + c + S);
+      else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc.v[k] = 0.f;
+      }
+      if (coarse.g) gather_tgt(coarse, b, y, x, H, W, C, c + S, acc);
+    } else {
+      if (self_top) acc = ld8(own + (size_t)pix * C + c - S);
+      else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc.v[k] = 0.f;
+      }
+      if (fine.g) gather_tgt(fine, b, y, x, H, W, C, c - S, acc);
+    }
+    float* o = dsrc + (size_t)pix * C + c;
+    *reinterpret_cast<float4v*>(o) = float4v{acc.v[0], acc.v[1], acc.v[2], acc.v[3]};
+    *reinterpret_cast<float4v*>(o + 4) = float4v{acc.v[4], acc.v[5], acc.v[6], acc.v[7]};
+  }
+}
+
 // ---- NHWC [B, H, W, C] -> channel-major padded rows ------------------------------------------------------------
 // dst[s][c][base + b*seg + (y+1)*Wp + (x+1) - dx_s] = src[b][y][x][c],  dx_s = s - (n_shift >> 1)
 // (n_shift = 1: the plain copy; n_shift = 3: copies pre-shifted by -1, 0, +1 columns so that every tap's operand
@@ -360,6 +446,18 @@ int g4r_fuse_shuffle_bwd_nhwc_bf16(const void* dinp, int H, int W, float* d_own,
   hipLaunchKernelGGL(fuse_shuffle_bwd_kernel, dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0,
                      (hipStream_t)stream, (const bf16_t*)dinp, own, top, down, B, C);
   G4R_CHECK_LAUNCH("fuse_shuffle_bwd");
+  return G4R_OK;
+}
+
+int g4r_fuse_shuffle_bwd_gather_nhwc_bf16(float* d_src, const void* dinp_own, int H, int W, const void* dinp_fine,
+                                          int Hf, int Wf, const void* dinp_coarse, int Hc, int Wc, int self_top,
+                                          int self_down, int B, int C, void* stream) {
+  G4R_REQUIRE(B > 0 && H > 0 && W > 0 && C % 32 == 0, "fuse_shuffle_bwd_gather: bad shape");
+  G4R_REQUIRE(d_src && dinp_own, "fuse_shuffle_bwd_gather: null pointer");
+  GatherTgt fine = {(const bf16_t*)dinp_fine, Hf, Wf}, coarse = {(const bf16_t*)dinp_coarse, Hc, Wc};
+  hipLaunchKernelGGL(fuse_shuffle_bwd_gather_kernel, dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0,
+                     (hipStream_t)stream, d_src, (const bf16_t*)dinp_own, fine, coarse, self_top, self_down, B, H, W, C);
+  G4R_CHECK_LAUNCH("fuse_shuffle_bwd_gather");
   return G4R_OK;
 }
 

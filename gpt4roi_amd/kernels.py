@@ -34,6 +34,8 @@ _SIGS = {
     "g4r_groupnorm_stats_nhwc_bf16": [P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     "g4r_gn_relu_bwd_nhwc_bf16": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "g4r_fuse_shuffle_bwd_nhwc_bf16": [P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P],
+    "g4r_fuse_shuffle_bwd_gather_nhwc_bf16": [P, P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int,
+                                              c_int, P],
     "g4r_nhwc_to_cm_padded_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_int, P],
     "g4r_roi_align_mlvl_nhwc_bwd_bf16": [P, c_long, c_long, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_int, P],
@@ -674,6 +676,26 @@ def fuse_shuffle_bwd(dinp, d_own, d_top, d_down):
             tag="g4r_fuse_shuffle_bwd_nhwc_bf16")
 
 
+def fuse_shuffle_bwd_gather(level, dinps):
+    """Gradient w.r.t. the (post GN+ReLU) map of source level `level` from the conv-input gradients `dinps` (list over
+    levels, bf16 NHWC) of one fuse round -> fp32 [B, H, W, C], every element written once (no atomics)."""
+    L = len(dinps)
+    own = dinps[level]
+    _bf16(*dinps)
+    B, H, W, C = own.shape
+    fine = dinps[level - 1] if level >= 1 else None          # target level-1 read this level as `top`
+    coarse = dinps[level + 1] if level + 1 < L else None     # target level+1 read this level as `down`
+    for d in dinps:
+        assert d.is_contiguous()
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=own.device)
+    _launch("g4r_fuse_shuffle_bwd_gather_nhwc_bf16", (
+        _p(out), _p(own), H, W, _p(fine), fine.size(1) if fine is not None else 0,
+        fine.size(2) if fine is not None else 0, _p(coarse), coarse.size(1) if coarse is not None else 0,
+        coarse.size(2) if coarse is not None else 0, int(level == L - 1), int(level == 0), B, C, _stream(own),),
+        tag="g4r_fuse_shuffle_bwd_gather", nbytes=float(own.numel() * (4 + 2 * 2)))
+    return out
+
+
 def roi_align_mlvl_bwd(dout, lvl_stride, pix_stride, grads, rois, output_size, scales, sampling_ratio=2, aligned=True):
     """dout bf16 (any layout described by the two strides, see g4r_train.h); grads: list of fp32 NHWC maps."""
     _bf16(dout)
@@ -735,11 +757,20 @@ class ConvWgradPlan:
         self._fill(x, self.xt, 3)
         self._fill(dy, self.dt, 1)
         a = self.dt[0][:, self.base:self.base + self.kp]
+        # [Cout x Cin x pixels] GEMMs: few output tiles, very long K -> split-K over the pixel axis.  MI355X,
+        # 1024 x 1024 (tools/wgrad_tiles.py): K = 38.8k: 256x256 ping-pong x16 splits 707 TF/s (64x128 x8: 451);
+        # K = 9.9k: 128x128 x8 413; K <= 2.6k: 128x128 x4.
         tiles = -(-self.cout // 128) * -(-self.cin // 128)
-        splits = max(1, min(8, 512 // tiles, self.kp // 512))
+        if self.kp >= 16384 and self.cout >= 512 and self.cin >= 512:
+            tile, splits = 22, 16
+        elif self.kp >= 4096:
+            tile, splits = 0, max(1, min(8, 512 // tiles))
+        else:
+            tile, splits = 0, max(1, min(4, 512 // tiles, self.kp // 256))
         taps = []
         for ky in range(3):
             for kx in range(3):
                 o = self.base + (ky - 1) * self.Wp
-                taps.append(gemm(a, self.xt[kx][:, o:o + self.kp], out_dtype=torch.float32, splits=splits))
+                taps.append(gemm(a, self.xt[kx][:, o:o + self.kp], out_dtype=torch.float32, splits=splits,
+                                 tile_cfg=tile))
         return torch.stack(taps, 2).view(self.cout, self.cin, 3, 3)

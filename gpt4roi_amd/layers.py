@@ -170,23 +170,23 @@ class MLVLFuseModule(nn.Module):
             g, bt, groups, eps = r['gn'][rnd]
             z_r, aff_r = ctx['maps'][rnd + 1], ctx['affs'][rnd + 1]
             prev, paff = ctx['maps'][rnd], ctx['affs'][rnd]
-            d_prev = [torch.zeros(m.shape, dtype=torch.float32, device=dev) for m in prev]
             dgamma = torch.zeros(C, dtype=torch.float32, device=dev)
             dbeta = torch.zeros(C, dtype=torch.float32, device=dev)
             wt = K.conv3x3_dgrad_weight(self.fuse_convs[rnd].conv.weight.detach())
-            dW = None
+            dW, dinps = None, []
             for tar, top, dow in self.fuse_lvl_list:
                 stats = K.groupnorm_stats(z_r[tar], groups, eps)
                 dz = K.gn_relu_bwd(z_r[tar], d_y[tar], aff_r[tar], g, stats, dgamma, dbeta, groups)
                 inp = K.fuse_shuffle(prev[tar], prev[top], prev[dow], paff[tar], paff[top], paff[dow])
                 w = self._wgrad_plans[tar].wgrad(inp, dz)
                 dW = w if dW is None else dW + w
-                dinp = K.conv3x3(dz, wt)
-                K.fuse_shuffle_bwd(dinp, d_prev[tar], d_prev[top], d_prev[dow])
+                dinps.append(K.conv3x3(dz, wt))
             grads[f'fuse_convs.{rnd}.conv.weight'] = dW
             grads[f'fuse_convs.{rnd}.gn.weight'] = dgamma
             grads[f'fuse_convs.{rnd}.gn.bias'] = dbeta
-            d_y = d_prev
+            # transpose of the channel shuffle + resampling, gathered per source level (fuse_lvl_list is
+            # (l, min(l+1, L-1), max(l-1, 0)) as in layers.py:108-112)
+            d_y = [K.fuse_shuffle_bwd_gather(l, dinps) for l in range(self.num_levels)]
         cin = self.input_dims + 2
         for lvl in range(self.num_levels):
             dm = K.cast_bf16(d_y[lvl].view(-1, C))

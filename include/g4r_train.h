@@ -103,6 +103,15 @@ int g4r_gn_relu_bwd_nhwc_bf16(const void* z, const float* dy, const float* affin
 int g4r_fuse_shuffle_bwd_nhwc_bf16(const void* dinp, int H, int W, float* d_own, float* d_top, int Ht, int Wt,
                                    float* d_down, int Hd, int Wd, int B, int C, void* stream);
 
+/* The same transpose as a gather, one call per SOURCE level (what the region module's backward uses): d_src fp32
+ * [B, H, W, C] is fully written from the conv-input gradients of the level itself (dinp_own), of the finer target
+ * that read this level as its coarser neighbour (dinp_fine, nullable) and of the coarser target that read it as its
+ * finer neighbour (dinp_coarse, nullable); self_top / self_down: the level is its own neighbour (last / first
+ * level, layers.py:108-112).  No atomics, bit-reproducible. */
+int g4r_fuse_shuffle_bwd_gather_nhwc_bf16(float* d_src, const void* dinp_own, int H, int W, const void* dinp_fine,
+                                          int Hf, int Wf, const void* dinp_coarse, int Hc, int Wc, int self_top,
+                                          int self_down, int B, int C, void* stream);
+
 /* NHWC bf16 [B, H, W, C] -> channel-major rows with a zero border:
  *   dst[s][c][base + b*seg + (y+1)*Wp + (x+1) - (s - n_shift/2)] = src[b][y][x][c],   dst [n_shift, C, ltot]
  * The 3x3 weight gradient is then 9 NT GEMMs over the pixel axis,

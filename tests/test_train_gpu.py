@@ -298,6 +298,19 @@ def test_fuse_shuffle_backward_is_the_transpose():
         assert relerr(d[k], leaves[k].grad) < 1e-4, k
 
 
+def test_fuse_shuffle_backward_gather_equals_scatter():
+    """The per-source-level gather (used by MLVLFuseModule.backward) against the atomic scatter transpose above,
+    over a whole 4-level round with the reference's neighbour table (l, min(l+1, 3), max(l-1, 0))."""
+    B, C, sizes = 2, 64, [24, 12, 6, 3]
+    dinps = [rnd(B, n, n, C, seed=100 + i) for i, n in enumerate(sizes)]
+    want = [torch.zeros((B, n, n, C), dtype=torch.float32, device=DEV) for n in sizes]
+    for tar in range(4):
+        K.fuse_shuffle_bwd(dinps[tar], want[tar], want[min(tar + 1, 3)], want[max(tar - 1, 0)])
+    for l in range(4):
+        got = K.fuse_shuffle_bwd_gather(l, dinps)
+        assert relerr(got, want[l]) < 1e-5, l
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout", [(1, 14, 14, 64, 128), (2, 20, 12, 128, 64)])
 def test_conv3x3_weight_and_input_gradients(B, H, W, cin, cout):
     x, dy = rnd(B, H, W, cin, seed=80), rnd(B, H, W, cout, seed=81)
@@ -315,8 +328,8 @@ def test_conv3x3_weight_and_input_gradients(B, H, W, cin, cout):
 
 def test_roi_align_mlvl_backward():
     B, C, N, L = 2, 64, 5, 2
-    sizes, scales = [24, 12], [0.5, 0.25]
-    rois = torch.tensor([[0, 3.3, 4.1, 30.2, 25.7], [1, 10.0, 2.0, 44.0, 40.0], [0, -3.0, -2.0, 9.0, 12.0],
+    sizes, scales = [80, 12], [1.0, 0.15]          # level 0: wide RoIs (direct path); level 1: narrow (LDS-staged path)
+    rois = torch.tensor([[0, 3.3, 4.1, 30.2, 25.7], [1, 10.0, 2.0, 75.0, 70.0], [0, -3.0, -2.0, 9.0, 12.0],
                          [1, 20.5, 20.5, 21.0, 23.0], [0, 0.0, 0.0, 47.9, 47.9]], dtype=torch.float32)
     dout = rnd(N, 7, 7, L * C, seed=83)
     grads = [torch.zeros((B, s, s, C), dtype=torch.float32, device=DEV) for s in sizes]
