@@ -13,8 +13,8 @@ per-sample host splice loop is ONE gather kernel (g4r_splice_embed_bf16).
 
 What is intentionally not reproduced: HF PreTrainedModel plumbing (from_pretrained, generate's
 sampling modes -- `generate()` here is the greedy path used for parity), the dummy projector
-call the reference makes for text-only samples (:94-97, a zero contribution), training-time
-labels/loss (the forward/inference row is the scope of this round).
+call the reference makes for text-only samples (:94-97, a zero contribution).  `forward(labels=...)`
+returns the shifted-label loss; the training STEP (backward, exchange, AdamW) is gpt4roi_amd/train.py.
 """
 import itertools
 from dataclasses import dataclass
@@ -154,11 +154,21 @@ class SPILlavaMPTForCausalLM(nn.Module):
     def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, images=None, return_dict=None,
                 *, img_metas=None, bboxes=None):
-        if labels is not None:
-            raise NotImplementedError("training loss is outside this round's forward/inference scope")
         logits = self.model(input_ids=input_ids, attention_mask=attention_mask, img_metas=img_metas, bboxes=bboxes,
                             past_key_values=past_key_values, inputs_embeds=inputs_embeds, images=images)
-        return CausalLMOutputWithPast(logits=logits, past_key_values=self.model.llama)
+        loss = None
+        if labels is not None:
+            # shifted-label token cross entropy, llava/model/llava.py:240-252 (evaluation of the loss only; the
+            # training step with its hand-written backward is gpt4roi_amd/train.py::RegionTrainer)
+            B, T, V = logits.shape
+            lab = torch.full((B, T), -100, dtype=torch.int64, device=logits.device)
+            lab[:, :-1] = labels[:, 1:]
+            lab = lab.reshape(-1).contiguous()
+            cnt = (lab >= 0).sum().clamp(min=1).float()
+            loss_sum = torch.zeros(1, dtype=torch.float32, device=logits.device)
+            K.cross_entropy(logits.view(B * T, V), lab, loss_sum)
+            loss = (loss_sum / cnt).reshape(())
+        return CausalLMOutputWithPast(logits=logits, past_key_values=self.model.llama, loss=loss)
 
     @torch.no_grad()
     def generate(self, input_ids, images=None, bboxes=None, max_new_tokens=64, do_sample=False, stop_ids=(), **_):

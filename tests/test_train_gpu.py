@@ -450,6 +450,10 @@ def test_stage1_training_step_end_to_end():
     tr = RegionTrainer(model, lr=2e-6, max_grad_norm=1.0)
     dev = lambda t: t.to(DEV)  # noqa: E731
     loss, grads = tr.loss_and_grads(dev(prompt), dev(img), [dev(b) for b in boxes], dev(labels))
+    from gpt4roi_amd.spi_llava import SPILlavaMPTForCausalLM
+    ev = SPILlavaMPTForCausalLM(model)(input_ids=dev(prompt), images=dev(img), bboxes=[dev(b) for b in boxes],
+                                       labels=dev(labels))          # the reference's forward(labels=...) call shape
+    assert abs(ev.loss.item() - loss.item()) < 2e-2 * abs(loss.item()), (ev.loss.item(), loss.item())
     # ---- oracle pipeline with autograd ----
     bf = lambda x: x.to(torch.bfloat16).float()  # noqa: E731
     vb = {k: bf(v) for k, v in vsd.items()}

@@ -14,3 +14,9 @@ for (B, H, D, T, c) in [(1, 16, 64, 577, False), (1, 32, 128, 767, True), (1, 32
     q, k, v = R(B, T, H * D), R(B, T, H * D), R(B, T, H * D)
     t = timeit(lambda: K.flash_attn(q, k, v, H, 1 / math.sqrt(D), c))
     print(f"attn B{B} H{H} D{D} T{T} causal{int(c)}: {t:.1f} us, {4.0*B*H*T*T*D/(2 if c else 1)/t/1e6:.1f} TF/s")
+    if D == 128:
+        lse = torch.empty((B, H, T), dtype=torch.float32, device="cuda")
+        o = K.flash_attn(q, k, v, H, 1 / math.sqrt(D), c, lse=lse)
+        do = R(B, T, H * D)
+        t = timeit(lambda: K.flash_attn_bwd(q, k, v, o, do, lse, H, 1 / math.sqrt(D), c))
+        print(f"attn bwd B{B} H{H} D{D} T{T} causal{int(c)}: {t:.1f} us, {10.0*B*H*T*T*D/(2 if c else 1)/t/1e6:.1f} TF/s")
