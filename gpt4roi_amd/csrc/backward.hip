@@ -387,6 +387,24 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restri
   }
 }
 
+// ---- out[idx[r]] += src[r] (fp32 accumulation of bf16 rows; idx < 0 = skip): embedding-table gradient -------------
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx,
+                                                               float* __restrict__ out, int n, int C, long ld_src,
+                                                               long ld_out) {
+  const int nvec = C >> 3;
+  const long total = (long)n * nvec;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    const int r = (int)(i / nvec);
+    const int d = idx[r];
+    if (d < 0) continue;
+    const F8 a = ld8(src + (size_t)r * ld_src + v * 8);
+    float* o = out + (size_t)d * ld_out + v * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) unsafeAtomicAdd(o + k, a.v[k]);
+  }
+}
+
 // ---- AdamW (decoupled weight decay, torch.optim.AdamW semantics) ----------------------------------------
 template <typename G>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m,
@@ -524,6 +542,17 @@ int g4r_gather_rows_bf16(const void* src, const int* idx, void* dst, int n, int 
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)n * (C / 8))), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)src, idx, (bf16_t*)dst, n, C, ld_src, ld_dst);
   G4R_CHECK_LAUNCH("gather_rows");
+  return G4R_OK;
+}
+
+int g4r_scatter_add_rows_f32(const void* src, const int* idx, float* out, int n, int C, long ld_src, long ld_out,
+                             void* stream) {
+  G4R_REQUIRE(n >= 0 && C > 0 && C % 8 == 0 && ld_src % 8 == 0, "scatter_add_rows: bad shape");
+  if (n == 0) return G4R_OK;
+  G4R_REQUIRE(src && idx && out, "scatter_add_rows: null pointer");
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for((long)n * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, idx, out, n, C, ld_src, ld_out);
+  G4R_CHECK_LAUNCH("scatter_add_rows");
   return G4R_OK;
 }
 

@@ -44,12 +44,14 @@ class GradBucketReducer:
     """reducer = GradBucketReducer(params); per step: reducer.reset(); reducer.ready(p, grad) for every
     parameter as its gradient is produced (any order); reducer.finish() -> {param: averaged grad view}."""
 
-    def __init__(self, params, bucket_bytes=256 << 20, group=None, comm_dtype=None, average=True):
+    def __init__(self, params, bucket_bytes=256 << 20, group=None, comm_dtype=None, average=True,
+                 trainable_only=True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
         self.average = average
-        params = [p for p in params if p.requires_grad]
+        if trainable_only:                      # nn.Parameters; plain tensors (kernel-layout masters) pass False
+            params = [p for p in params if p.requires_grad]
         assert params, "no trainable parameters"
         self.device = params[0].device
         self.dtype = comm_dtype or params[0].dtype

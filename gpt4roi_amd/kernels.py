@@ -30,6 +30,7 @@ _SIGS = {
     "g4r_colsum_bf16": [P, P, c_int, c_int, c_long, P],
     "g4r_relu_bwd_bf16": [P, P, P, c_long, P],
     "g4r_gather_rows_bf16": [P, P, P, c_int, c_int, c_long, c_long, P],
+    "g4r_scatter_add_rows_f32": [P, P, P, c_int, c_int, c_long, c_long, P],
     "g4r_adamw_f32": [P, P, c_int, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P],
     "g4r_groupnorm_stats_nhwc_bf16": [P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     "g4r_gn_relu_bwd_nhwc_bf16": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
@@ -603,6 +604,17 @@ def gather_rows(src, idx, out=None):
         out = torch.empty((n, C), dtype=torch.bfloat16, device=src.device)
     _launch("g4r_gather_rows_bf16", (_p(src), _p(idx), _p(out), n, C, src.stride(0), out.stride(0), _stream(src),),
             tag="g4r_gather_rows_bf16")
+    return out
+
+
+def scatter_add_rows(src, idx, out):
+    """out[idx[r]] += src[r] (src bf16 [n, C], idx int32 [n] with -1 = skip, out fp32 [V, C])."""
+    _bf16(src)
+    _f32(out)
+    assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == src.size(0)
+    assert out.stride(1) == 1 and src.stride(1) == 1 and out.size(1) == src.size(1)
+    _launch("g4r_scatter_add_rows_f32", (_p(src), _p(idx), _p(out), src.size(0), src.size(1), src.stride(0),
+                                         out.stride(0), _stream(src),), tag="g4r_scatter_add_rows_f32")
     return out
 
 

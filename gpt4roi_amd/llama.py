@@ -110,6 +110,29 @@ class LlamaDecoder:
                 L[nm + "_t"] = K.transpose(L[nm])
         self.lm_head_t = K.transpose(self.lm_head, self.v_pad)
 
+    def trainable_tensors(self):
+        """name -> tensor the kernels read, for stage-2 training (kernel layouts: fused q|k|v rows, interleaved
+        gate/up rows; norm weights are fp32 already)."""
+        out = {"embed_tokens": self.embed, "norm": self.norm, "lm_head": self.lm_head}
+        for i, L in enumerate(self.layers):
+            for nm in ("wqkv", "wo", "wgu", "wd", "n1", "n2"):
+                out[f"{i}.{nm}"] = L[nm]
+        return out
+
+    def export_hf_state_dict(self):
+        """The HF-named state dict of the current weights (undoes the q|k|v fusion and the gate/up interleave)."""
+        C = self.hidden
+        sd = {"model.embed_tokens.weight": self.embed, "model.norm.weight": self.norm, "lm_head.weight": self.lm_head}
+        for i, L in enumerate(self.layers):
+            p = f"model.layers.{i}."
+            sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"] = \
+                L['wqkv'][:C], L['wqkv'][C:2 * C], L['wqkv'][2 * C:]
+            sd[p + "self_attn.o_proj.weight"] = L['wo']
+            sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = L['wgu'][0::2], L['wgu'][1::2]
+            sd[p + "mlp.down_proj.weight"] = L['wd']
+            sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = L['n1'], L['n2']
+        return {k: v.detach().clone() for k, v in sd.items()}
+
     def forward_train(self, inputs_embeds):
         """inputs_embeds [B,T,C] bf16 at positions 0..T-1 -> (logits fp32 [B*T, V], ctx).  Same kernels as
         `forward` except that the gate|up GEMM keeps its pre-activation output for the SwiGLU backward and

@@ -86,6 +86,7 @@ class RegionTrainer:
         logits, lctx = m.llama.forward_train(embeds)
         loss, dlogits = m.llama.loss_and_dlogits(logits, labels)
         d_emb = m.llama.backward(lctx, dlogits)                                  # [B*T, C] bf16
+        self._d_emb = d_emb
         flat = input_ids.reshape(-1)
         idx_bbox = (flat == cfg.bbox_token).nonzero().flatten().to(torch.int32)
         assert idx_bbox.numel() == bboxes.n, "number of <bbox> tokens != number of regions"
@@ -127,3 +128,75 @@ class RegionTrainer:
         loss, grads = self.loss_and_grads(input_ids, images, bboxes, labels)
         self.apply(grads, lr)
         return loss
+
+
+class FullTrainer(RegionTrainer):
+    """Stage 2 (train_stage2.sh: everything but the vision tower is trained): on top of the
+    stage-1 step the decoder produces every weight gradient (NT GEMMs over the token axis), the embedding table
+    gets a scatter-add of d(inputs_embeds), and AdamW runs on fp32 masters of the decoder's kernel-layout tensors
+    (fused q|k|v, interleaved gate/up; `LlamaDecoder.export_hf_state_dict()` gives the HF layout back) writing the
+    bf16 copy the kernels read in the same pass.  Memory for the 7B model: 13.5 GB bf16 weights + 13.5 GB W^T +
+    27 GB masters + 54 GB Adam moments + 27 GB fp32 gradients -- a replica per GPU fits the 288 GB of an MI355X,
+    which is why the exchange is a plain gradient all-reduce rather than the reference's FSDP sharding
+    (train_stage2.sh:51-52)."""
+
+    def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
+                 bucket_bytes=256 << 20):
+        super().__init__(model, lr, betas, eps, weight_decay, max_grad_norm, train_projector=True, group=None,
+                         bucket_bytes=bucket_bytes)
+        dec = model.llama
+        dec.prepare_training(train_weights=True)
+        self.dec_live = {f"llama.{k}": v for k, v in dec.trainable_tensors().items()}
+        # fp32 masters (norm weights are fp32 already and are their own master)
+        self.dec_master = {k: (v if v.dtype == torch.float32 else v.float()) for k, v in self.dec_live.items()}
+        for k, v in self.dec_master.items():
+            self.state[k] = (torch.zeros_like(v), torch.zeros_like(v))
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.reducer = None
+        if self.world > 1:
+            tensors = list(self.params.values()) + list(self.dec_master.values())
+            self.reducer = GradBucketReducer(tensors, bucket_bytes=bucket_bytes, group=group, comm_dtype=torch.float32,
+                                             trainable_only=False)
+
+    @torch.no_grad()
+    def loss_and_grads(self, input_ids, images, bboxes, labels):
+        loss, grads = super().loss_and_grads(input_ids, images, bboxes, labels)
+        m = self.model
+        dec, cfg = m.llama, m.config
+        for k, g in dec.grads.items():
+            grads[f"llama.{k}"] = g
+        # embedding rows: every position that took embed[id] in the splice (not <im_patch>, not <bbox>)
+        flat = input_ids.reshape(-1)
+        idx = torch.where((flat == cfg.im_patch_token) | (flat == cfg.bbox_token), torch.full_like(flat, -1), flat)
+        ge = torch.zeros(dec.embed.shape, dtype=torch.float32, device=dec.embed.device)
+        K.scatter_add_rows(self._d_emb, idx.to(torch.int32).contiguous(), ge)
+        grads["llama.embed_tokens"] = ge
+        return loss, grads
+
+    @torch.no_grad()
+    def apply(self, grads, lr=None):
+        names = list(self.params) + list(self.dec_master)
+        tensors = {**{k: p.data for k, p in self.params.items()}, **self.dec_master}
+        if self.reducer is not None:
+            self.reducer.reset()
+            for k in reversed(names):
+                self.reducer.ready(self.params[k] if k in self.params else self.dec_master[k], grads[k])
+            red = self.reducer.finish()
+            grads = {k: red[id(self.params[k] if k in self.params else self.dec_master[k])] for k in names}
+        scale = 1.0
+        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+            norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(grads[k].float()) for k in names]))
+            self.last_grad_norm = norm
+            scale = min(1.0, self.max_grad_norm / (float(norm) + 1e-6))
+        self.steps += 1
+        lr = self.lr if lr is None else lr
+        for k in names:
+            p = tensors[k]
+            m_, v_ = self.state[k]
+            g = grads[k].reshape(p.shape)
+            live = self.dec_live.get(k)
+            K.adamw(p, g.contiguous() if g.dtype == torch.float32 else g.float().contiguous(), m_, v_, self.steps, lr,
+                    self.betas, self.eps, self.weight_decay, grad_scale=scale,
+                    param_bf16=live if (live is not None and live.dtype == torch.bfloat16) else None)
+        self.model.prepare()
+        self.model.llama.refresh_transposes()

@@ -74,6 +74,11 @@ int g4r_relu_bwd_bf16(const void* y, const void* dy, void* dx, long n, void* str
 int g4r_gather_rows_bf16(const void* src, const int* idx, void* dst, int n, int C, long ld_src, long ld_dst,
                          void* stream);
 
+/* out[idx[r]][:] += src[r][:] (src bf16 rows, out fp32, idx < 0 = skip; fp32 atomics): gradient of the token
+ * embedding lookup inside the splice (rows that took an embedding, spi_llava.py:99-196 / HF embed_tokens). */
+int g4r_scatter_add_rows_f32(const void* src, const int* idx, float* out, int n, int C, long ld_src, long ld_out,
+                             void* stream);
+
 /* torch.optim.AdamW step on fp32 master weights (decoupled weight decay); grad bf16 or fp32, multiplied by
  * grad_scale first (gradient averaging / clipping); param_bf16 (nullable) receives the rounded copy the kernels
  * read.  step >= 1. */

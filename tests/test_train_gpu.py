@@ -499,3 +499,84 @@ def test_stage1_training_step_end_to_end():
     assert predicted < -0.02
     assert 0.5 * predicted > l1.item() - loss.item() > 1.5 * predicted, (l1.item() - loss.item(), predicted)
     assert l2.item() < l1.item() < loss.item()
+
+
+def test_stage2_training_step_end_to_end():
+    """train.FullTrainer (everything but the ViT trainable): decoder / embedding / projector gradients against autograd
+    through the chained oracles, master -> bf16 -> W^T refresh after the update, and the loss follows <grad, dw>."""
+    from gpt4roi_amd.spi_llava import SPILlavaLlamaModel
+    from gpt4roi_amd.train import FullTrainer
+    from gpt4roi_amd.vit import ClipVisionTower
+    H, P, image = 512, 8, 112
+    ids = syn.token_ids(vocab_base=990)
+    vsd = syn.vit_state(H, 4 * H, 12, image, seed=8)
+    lsd = syn.llama_state(512, 1408, 2, ids.vocab, seed=9)
+    tower = ClipVisionTower(vsd, heads=8, device=DEV)
+    dec = LlamaDecoder(lsd, heads=4, max_positions=256, device=DEV)
+    hf = dec.export_hf_state_dict()
+    for k, v in lsd.items():                                        # the kernel layouts round-trip to the HF names
+        assert torch.equal(hf[k].float().cpu(), v.to(torch.bfloat16).float() if v.dim() > 1 else v.float()), k
+    model = SPILlavaLlamaModel(tower, dec, ids, embed_dims=H)
+    orc = S.MLVLROIQueryOracle(embed_dims=H, P=P)
+    orc.roi_align.updims = torch.nn.Linear(1024, 512)
+    spi_sd = S.synthetic_state(orc, 10)
+    orc.load_state_dict(spi_sd)
+    model.spi_module.load_state_dict(spi_sd)
+    g = torch.Generator().manual_seed(11)
+    pw, pb = torch.randn(512, H, generator=g) / H ** 0.5, torch.randn(512, generator=g) * 0.05
+    with torch.no_grad():
+        model.mm_projector.weight.copy_(pw)
+        model.mm_projector.bias.copy_(pb)
+    img = torch.randn(1, 3, image, image, generator=g)
+    boxes = [syn.boxes(3, g)]
+    prompt = syn.prompt_ids(ids, P, 3, g, sys_len=6, question_len=9, vocab_base=990)[None]
+    labels = prompt.clone()
+    labels[:, :8 + P * P] = -100
+    labels[labels >= 990] = -100
+    lr = 2e-6
+    tr = FullTrainer(model, lr=lr, max_grad_norm=1.0)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    args = (dev(prompt), dev(img), [dev(b) for b in boxes], dev(labels))
+    loss, grads = tr.loss_and_grads(*args)
+    # ---- oracle: decoder, embedding and projector as autograd leaves ----
+    bf = lambda x: x.to(torch.bfloat16).float()  # noqa: E731
+    vb = {k: bf(v) for k, v in vsd.items()}
+    lb = {k: bf(v).requires_grad_(True) for k, v in lsd.items()}
+    pwr, pbr = bf(pw).requires_grad_(True), bf(pb).requires_grad_(True)
+    with torch.no_grad():
+        hs = T.clip_vit_hidden_states(vb, img, heads=8, n_layers=11, emulate=True)
+        img_feat, lv = T.select_spi_levels(hs + [hs[-1]], -2, 4)
+    proj = S._r(S._r(img_feat, True) @ pwr.t() + pbr, True)
+    emb = lb["model.embed_tokens.weight"][prompt]
+    spi = orc(lv, boxes, emulate=True)
+    spliced = S.splice(prompt, emb, proj, spi, ids.im_start_token, ids.im_end_token, ids.bbox_token)
+    h, _ = T.llama_forward(lb, spliced, heads=4, emulate=True)
+    logits = T.lm_logits(lb, h, emulate=True)
+    ref_loss = F.cross_entropy(logits[:, :-1].reshape(-1, ids.vocab), labels[:, 1:].reshape(-1), ignore_index=-100)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 3e-2 * abs(ref_loss.item())
+    p0 = "model.layers.0."
+    ref = {"llama.embed_tokens": lb["model.embed_tokens.weight"].grad, "llama.lm_head": lb["lm_head.weight"].grad,
+           "llama.norm": lb["model.norm.weight"].grad,
+           "llama.0.wqkv": torch.cat([lb[p0 + f"self_attn.{n}_proj.weight"].grad for n in "qkv"], 0),
+           "llama.0.wo": lb[p0 + "self_attn.o_proj.weight"].grad,
+           "llama.0.wgu": torch.stack([lb[p0 + "mlp.gate_proj.weight"].grad, lb[p0 + "mlp.up_proj.weight"].grad], 1).reshape(-1, 512),
+           "llama.1.wd": lb["model.layers.1.mlp.down_proj.weight"].grad,
+           "llama.1.n1": lb["model.layers.1.input_layernorm.weight"].grad,
+           "mm_projector.weight": pwr.grad, "mm_projector.bias": pbr.grad}
+    coss = {k: round(cosine(grads[k], v), 4) for k, v in ref.items()}
+    print("stage-2 gradient cosines:", coss)
+    assert min(coss.values()) > 0.97, coss
+    assert set(grads) == set(tr.params) | set(tr.dec_master)
+    # ---- update: masters, bf16 copies and transposes stay consistent; the loss follows the gradient ----
+    before = {k: v.clone() for k, v in tr.dec_master.items()}
+    tr.apply(grads, lr=lr)
+    predicted = sum(float(((tr.dec_master[k] - before[k]).double() * grads[k].reshape(before[k].shape).double()).sum())
+                    for k in before)
+    L0 = dec.layers[0]
+    assert torch.equal(L0["wo"], tr.dec_master["llama.0.wo"].to(torch.bfloat16))
+    assert torch.equal(L0["wo_t"], L0["wo"].t().contiguous())
+    assert not torch.equal(tr.dec_master["llama.0.wo"], before["llama.0.wo"])
+    l1 = tr.step(*args, lr=lr)
+    print("stage-2 loss:", loss.item(), l1.item(), "predicted change from the decoder part alone:", predicted)
+    assert predicted < 0 and l1.item() < loss.item()
