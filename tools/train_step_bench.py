@@ -16,13 +16,14 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from gpt4roi_amd import kernels as K  # noqa: E402
 from gpt4roi_amd import synthetic as syn  # noqa: E402
-from gpt4roi_amd.train import RegionTrainer  # noqa: E402
+from gpt4roi_amd.train import FullTrainer, RegionTrainer  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--rois", type=int, default=32)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--llama-layers", type=int, default=32)
+ap.add_argument("--stage", type=int, default=1, help="1: region module trainable; 2: everything but the ViT")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 margs = SimpleNamespace(image_size=336, llama_layers=a.llama_layers)
@@ -37,7 +38,7 @@ labels = prompt.clone()
 labels[:, :42 + P * P] = -100
 labels[labels >= 32000] = -100
 t0 = time.time()
-tr = RegionTrainer(model, lr=2e-5)
+tr = (FullTrainer if a.stage == 2 else RegionTrainer)(model, lr=2e-5)
 torch.cuda.synchronize()
 print(f"trainer ready in {time.time()-t0:.1f}s; mem {torch.cuda.memory_allocated()/2**30:.1f} GiB", flush=True)
 losses = [tr.step(prompt, img, boxes, labels).item()]          # warm-up (allocations, plans)
@@ -51,7 +52,8 @@ K.PROFILER.start()
 tr.step(prompt, img, boxes, labels)
 agg = K.PROFILER.stop()
 top = sorted(((v["ms"], k, v["calls"]) for k, v in agg.items()), reverse=True)[:14]
-print(json.dumps(dict(metric="stage-1 training step (ViT-L/14@336 frozen, region module trainable, LLaMA-7B frozen)",
+print(json.dumps(dict(metric=("stage-2 training step (ViT-L/14@336 frozen; region module, projector and LLaMA-7B trainable)" if a.stage == 2 else
+                              "stage-1 training step (ViT-L/14@336 frozen, region module trainable, LLaMA-7B frozen)"),
                       batch=a.batch, rois=a.rois, tokens=int(prompt.size(1)), ms_per_step=round(ms, 2),
                       region_tokens_per_s=round(a.batch * a.rois / ms * 1e3, 1), losses=[round(x, 4) for x in losses],
                       peak_mem_GiB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
