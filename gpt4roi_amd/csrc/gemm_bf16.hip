@@ -784,6 +784,238 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   gemm_epilogue<TM, TN>(p, acc, m0 + wm * 128 + em, n0 + wn * 64 + en, split);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ping-pong kernel, second form: K tiles of 32 in a RING OF FOUR (4 x 32 KB of LDS), one phase per K tile.
+// The probe of the first form (tools/pp_probe.py) showed that the LDS-DMA address path is the co-limiter: a CU
+// accepts one 1 KiB piece every ~26 cycles, i.e. 1664 cycles of issue per 64 of K against 2048 cycles of MFMA,
+// and a wave that is issuing pieces cannot issue MFMAs.  So here ONLY the group that is reading fragments issues
+// pieces (its 4 per K tile, for the tile three ahead: 16 pieces = ~416 cycles per phase, under the other group's
+// 16 MFMAs), never the group on the matrix pipe, and every wave has five phases of slack for its pieces to land:
+//        phase:     2t              2t+1            2t+2
+//   waves 0-3:   read(t)+DMA(t+3)   MFMA(t)      read(t+1)+DMA(t+4)
+//   waves 4-7:   MFMA(t-1)          read(t)+DMA(t+3)   MFMA(t)
+// ---------------------------------------------------------------------------------------------
+template <int AMODE, bool PROBE = false>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, NW = 8, NT = 512, BKT = 32, RING = 4;
+  constexpr int ROWB = 64, SPR = 4;
+  constexpr int TM = 4, TN = 2;
+  constexpr int NA = BM * SPR / NT, NB = BN * SPR / NT;  // 2 + 2 pieces per wave per K tile
+  constexpr int A_BYTES = BM * BKT * 2, STAGE_BYTES = (BM + BN) * BKT * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // RING * STAGE_BYTES = 128 KB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int grp = wm;
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = p.n_fastest ? wg / p.tiles_n : wg % p.tiles_m;
+  const int tile_n = p.n_fastest ? wg % p.tiles_n : wg / p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int split = blockIdx.y;
+  const int t_begin = split * p.tiles_per_split;
+  int t_end = t_begin + p.tiles_per_split;
+  const int nt_total = p.K / BKT;
+  if (t_end > nt_total) t_end = nt_total;
+
+  const bf16_t* a_src[NA];
+  int a_y[NA], a_x[NA];
+  const bf16_t* b_src[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int pslot = (j * NW + wave) * 64 + lane;
+    const int row = pslot / SPR, ps = pslot % SPR;
+    const int kslot = ps ^ ((row >> 2) & 3);
+    int gm = m0 + row;
+    if (gm > p.M - 1) gm = p.M - 1;
+    a_src[j] = p.A + (size_t)gm * p.lda + kslot * 8;
+    a_y[j] = a_x[j] = 0;
+    if (AMODE == 1) {
+      const int hw = p.H * p.Wd;
+      const int b = gm / hw, rem = gm - b * hw;
+      a_y[j] = rem / p.Wd;
+      a_x[j] = rem - a_y[j] * p.Wd;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int pslot = (j * NW + wave) * 64 + lane;
+    const int row = pslot / SPR, ps = pslot % SPR;
+    const int kslot = ps ^ ((row >> 2) & 3);
+    int gn = n0 + row;
+    if (gn > p.N - 1) gn = p.N - 1;
+    b_src[j] = p.W + (size_t)gn * p.ldw + kslot * 8;
+  }
+  struct TileSrc { long a_off; int k0, dy, dx; };
+  auto tile_src = [&](int t) {
+    TileSrc ts;
+    ts.k0 = t * BKT;
+    ts.a_off = ts.k0;
+    ts.dy = ts.dx = 0;
+    if (AMODE == 1) {
+      const int per_tap = p.Cin / BKT;
+      const int tap_lin = t / per_tap;
+      const int c0 = (t - tap_lin * per_tap) * BKT;
+      const int g = tap_lin / 9, tap = tap_lin - g * 9;
+      ts.dy = tap / 3 - 1;
+      ts.dx = tap - (tap / 3) * 3 - 1;
+      ts.a_off = (long)g * p.a_group_stride + ((long)ts.dy * p.Wd + ts.dx) * p.lda + c0;
+    }
+    return ts;
+  };
+  // piece j of a K tile for this wave: j < NA -> rows of A, else rows of W (1 KiB each)
+  auto piece = [&](int j, const TileSrc& ts, int buf) {
+    char* sa = smem + buf * STAGE_BYTES;
+    if (j < NA) {
+      const bf16_t* src = a_src[j] + ts.a_off;
+      if (AMODE == 1) {
+        const int yy = a_y[j] + ts.dy, xx = a_x[j] + ts.dx;
+        if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.Wd) src = p.zeros + (lane & 3) * 8;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sa + (j * NW + wave) * 1024), 16, 0, 0);
+    } else {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[j - NA] + ts.k0),
+                                       (__attribute__((address_space(3))) void*)(sa + A_BYTES + ((j - NA) * NW + wave) * 1024), 16, 0, 0);
+    }
+  };
+  auto stage = [&](int t, int buf) {
+    const TileSrc ts = tile_src(t);
+#pragma unroll
+    for (int j = 0; j < NA + NB; ++j) piece(j, ts, buf);
+  };
+  float16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frow = lane & 31, fsw = (frow >> 2) & 3, fhi = lane >> 5;
+  const int a_row_off = (wm * 128 + frow) * ROWB;
+  const int b_row_off = (wn * 64 + frow) * ROWB;
+  bf16x8 af[2][TM], wf[2][TN];
+  // the 12 fragment reads of a K tile (three chunks of four)
+  auto ldchunk = [&](int buf, int c) {
+    const char* sa = smem + buf * STAGE_BYTES;
+    const char* sb = sa + A_BYTES;
+    const int s0 = ((0 * 2 + fhi) ^ fsw) << 4, s1 = ((1 * 2 + fhi) ^ fsw) << 4;
+    if (c == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + s0);
+    } else if (c == 1) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[0][j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + s0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[1][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + s1);
+    } else {
+#pragma unroll
+      for (int i = 2; i < TM; ++i) af[1][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + s1);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[1][j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + s1);
+    }
+  };
+  auto mma = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  const int nt = t_end - t_begin;
+  if (nt > 0) {
+#pragma unroll
+    for (int t = 0; t < RING - 1; ++t)
+      if (t < nt) stage(t_begin + t, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (grp == 1) G4R_PP_BARRIER();
+    long long* stamps = reinterpret_cast<long long*>(p.ws) + grp * 8;
+    const bool probing = PROBE && blockIdx.x == 0 && blockIdx.y == 0 && (wave & 3) == 0 && lane == 0;
+#define G4R_PP32_STAMP(slot) \
+  if (PROBE) { if (probing && (i == 16 || (slot) >= 6)) stamps[slot] = __builtin_amdgcn_s_memtime(); }
+    {
+      const int i = 0;
+      G4R_PP32_STAMP(6);
+    }
+    for (int i = 0; i < nt; ++i) {
+      const int buf = i & (RING - 1);
+      G4R_PP32_STAMP(0);
+      // read phase of K tile i: fragments, then this wave's 4 pieces of tile i+3 into the buffer that tile i-1
+      // left (both groups finished reading it: group 1 one phase ago, group 0 two)
+      // fragments first, pieces after.  Alternating them inside the wave is much slower (2150-2220 vs 1490 cycles
+      // per K tile, with the builtin AND with raw-ISA pieces the compiler cannot see): a ds_read behind an LDS-DMA
+      // piece of the same wave waits for it in hardware.
+      ldchunk(buf, 0);
+      ldchunk(buf, 1);
+      ldchunk(buf, 2);
+      G4R_PP32_STAMP(1);
+      if (i + RING - 1 < nt) {
+        stage(t_begin + i + RING - 1, (i + RING - 1) & (RING - 1));
+        G4R_PP32_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile i+1's pieces (issued two read phases ago) have landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      G4R_PP32_STAMP(3);
+      G4R_PP_BARRIER();
+      G4R_PP32_STAMP(4);
+      mma();
+      G4R_PP_BARRIER();
+      G4R_PP32_STAMP(5);
+    }
+    {
+      const int i = 0;
+      G4R_PP32_STAMP(7);
+    }
+    if (grp == 0) G4R_PP_BARRIER();
+  }
+  const int em = lane & 31, en = 4 * (lane >> 5);
+  gemm_epilogue<TM, TN>(p, acc, m0 + wm * 128 + em, n0 + wn * 64 + en, split);
+}
+
+template <int AMODE, bool PROBE = false>
+int launch_pp32(GemmArgs& p, hipStream_t stream) {
+  {
+    const int nt = p.K / 32;
+    int splits = p.splits < 1 ? 1 : p.splits;
+    if (splits > nt) splits = nt;
+    p.tiles_per_split = g4r_ceil_div(nt, splits);
+    p.splits = g4r_ceil_div(nt, p.tiles_per_split);
+  }
+  p.tiles_m = g4r_ceil_div(p.M, 256);
+  p.tiles_n = g4r_ceil_div(p.N, 256);
+  const size_t lds = 4 * (256 + 256) * 32 * 2;
+  auto kern = gemm_bf16_pp32_kernel<AMODE, PROBE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_pp32: hipFuncSetAttribute");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(512), lds, stream, p);
+  G4R_CHECK_LAUNCH("gemm_bf16_pp32");
+  if (p.splits > 1) {
+    long total = (long)p.M * p.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    G4R_CHECK_LAUNCH("splitk_reduce");
+  }
+  return G4R_OK;
+}
+
 template <int AMODE, bool PROBE = false>
 int launch_pp(GemmArgs& p, hipStream_t stream) {
   {
@@ -874,6 +1106,8 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 20: return launch_tile<256, 256, 2, 4, AMODE, true, 4, 32, 2>(p, stream);  // same, burst reads
     case 21: return launch_tile<256, 256, 2, 4, AMODE, true, 3, 32, 1>(p, stream);  // 256x256, BK 32 ring x3 (96 KB)
     case 22: return launch_pp<AMODE>(p, stream);                                 // 256x256 ping-pong (4 barriers / K tile)
+    case 24: return launch_pp32<AMODE>(p, stream);                               // 256x256 ping-pong, K 32 ring of 4
+    case 25: return launch_pp32<AMODE, true>(p, stream);                         // same + s_memtime stamps (tools only)
     case 23: return launch_pp<AMODE, true>(p, stream);                           // same + s_memtime stamps into ws (tools only)
     default: return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");
   }

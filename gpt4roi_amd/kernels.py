@@ -106,7 +106,7 @@ PROFILER = _Profiler()
 TILE_NAMES = {0: "128x128", 1: "256x128", 2: "128x128reg", 4: "64x128", 5: "128x128s3", 6: "128x128s4",
               7: "128x128w8s4", 8: "256x128s3", 9: "256x256", 10: "128x128w8", 11: "128x64", 12: "128x128k32s3", 13: "128x128k32s4",
               14: "128x128k32", 15: "256x128k32s3", 16: "128x128w8s3i", 17: "128x128s3i", 18: "256x128s3i", 19: "256x256k32s4i", 20: "256x256k32s4b",
-              21: "256x256k32s3i", 22: "256x256pp"}
+              21: "256x256k32s3i", 22: "256x256pp", 24: "256x256pp32"}
 
 
 def _launch(name, args, tag=None, flops=0.0, nbytes=0.0):
@@ -161,6 +161,15 @@ def pick_tile(M, N, K=0):
     """Tile heuristic for a 256-CU part, from tools/microbench.py on MI355X: 128x128 two-stage when
     the grid fills the chip; 64x128 (more workgroups) when it would not; for long-K / narrow-N shapes
     (LLaMA down_proj 767x4096x11008) the 8-wave ring variant."""
+    # 256x256 ring ping-pong (tile 24, ~1.0 PF/s on full waves): when its tiles fill >= 55 % of one wave of the 256
+    # CUs (LLaMA fused qkv 767x12288: 144 tiles, 92 us vs 108 us for 128x128) or >= 85 % of several, and the M
+    # padding costs < 10 %.  768x22016 (258 tiles = one wave + 2) and the N = 4096 projections (48 tiles) stay on
+    # the 128-wide tiles.
+    t256 = -(-M // 256) * -(-N // 256)
+    if K >= 2048 and K % 64 == 0 and (-(-M // 256) * 256) <= 1.1 * M:
+        eff = t256 / (-(-t256 // 256) * 256)
+        if (t256 <= 256 and eff >= 0.55) or eff >= 0.85:
+            return 24
     t128 = -(-M // 128) * -(-N // 128)
     if t128 >= 192:
         return 7 if (K >= 8192 and t128 < 512) else 0
@@ -176,7 +185,7 @@ def pick_conv_tile(M, Cout, K):
     if K >= 18432:
         return 1, 1
     if M >= 8192:
-        return 22, 1
+        return 24, 1
     blocks = -(-M // 64) * -(-Cout // 128)
     splits = max(1, min(8, round(384 / blocks), K // 1024))
     return 4, splits
@@ -774,7 +783,7 @@ class ConvWgradPlan:
         # K = 9.9k: 128x128 x8 413; K <= 2.6k: 128x128 x4.
         tiles = -(-self.cout // 128) * -(-self.cin // 128)
         if self.kp >= 16384 and self.cout >= 512 and self.cin >= 512:
-            tile, splits = 22, 16
+            tile, splits = 24, 16
         elif self.kp >= 4096:
             tile, splits = 0, max(1, min(8, 512 // tiles))
         else:
