@@ -437,6 +437,23 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
 // split-K combine + epilogue: C = act(sum_s ws[s] + bias) + residual
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
   const long total = (long)p.M * p.N;
+  if (p.act == 4) {  // SwiGLU over interleaved (gate, up) column pairs: C has N/2 columns (bf16)
+    const int half = p.N >> 1;
+    const long pairs = (long)p.M * half;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (long)gridDim.x * 256) {
+      const int c = (int)(i % half);
+      const long m = i / half;
+      float g = 0.f, u = 0.f;
+      for (int s = 0; s < p.splits; ++s) {
+        const float2 v = *reinterpret_cast<const float2*>(p.ws + (size_t)s * total + m * p.N + 2 * c);
+        g += v.x;
+        u += v.y;
+      }
+      const float sg = bf16lo(pack_bf16x2(g / (1.f + __expf(-g)), 0.f));
+      reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + c] = f32_to_bf16(sg * u);
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int n = (int)(i % p.N);
     const long m = i / p.N;
@@ -1130,8 +1147,8 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
   if (M == 0 || N == 0) return G4R_OK;
   G4R_REQUIRE(A && W && C, "gemm: null pointer");
   G4R_REQUIRE(act >= 0 && act <= 4, "gemm: act must be 0..4");
-  G4R_REQUIRE(act != 4 || (N % 4 == 0 && ldc % 2 == 0 && splits == 1 && !residual && !bias && !out_f32 && K % BK == 0),
-              "gemm: swiglu epilogue needs N % 4 == 0, bf16 output, no bias/residual/split-K");
+  G4R_REQUIRE(act != 4 || (N % 4 == 0 && ldc % 2 == 0 && !residual && !bias && !out_f32 && K % BK == 0),
+              "gemm: swiglu epilogue needs N % 4 == 0, bf16 output, no bias/residual");
   if (M == 1 && K % 8 == 0 && (ldw % 8) == 0 && splits == 1 && K >= 512 && (act != 4 || N % 4 == 0)) {
     // single-token decode: weight-streaming GEMV
     const int waves = g4r_ceil_div(N, 4);

@@ -191,6 +191,24 @@ def pick_conv_tile(M, Cout, K):
     return 4, splits
 
 
+def wave_split(M, N, K):
+    """Columns [0, N_main) that fill WHOLE waves of 256x256 tiles on the 256 CUs, when the full problem does not
+    (LLaMA gate|up 767x22016: 3 x 86 = 258 tiles = one wave + 2; lm_head 767x32006: 378 tiles).  The main part
+    then runs on the ring ping-pong kernel (tile 24) with one tile per CU per wave and the remaining columns as a
+    second, small GEMM.  Returns N_main or None."""
+    if not (K >= 2048 and K % 64 == 0 and M > 1 and (-(-M // 256) * 256) <= 1.1 * M):
+        return None
+    mt, nt = -(-M // 256), -(-N // 256)
+    t256 = mt * nt
+    waves, rem = divmod(t256, 256)
+    if waves < 1 or rem == 0:
+        return None
+    n_main = (waves * 256 // mt) * 256
+    if n_main <= 0 or n_main >= N:
+        return None
+    return n_main
+
+
 def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfloat16, splits=1,
          tile_cfg=None, workspace=None):
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + residual.  a may be row-strided (last dim dense)."""
@@ -206,6 +224,15 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
     assert out.stride(1) == 1 and out.shape == (M, n_out)
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
+    if tile_cfg is None and splits == 1 and pick_tile(M, N, K) != 24:
+        n_main = wave_split(M, N, K)
+        if n_main is not None:
+            o_main = n_main // 2 if act == "swiglu" else n_main
+            gemm(a, w[:n_main], bias[:n_main] if bias is not None else None,
+                 residual[:, :n_main] if residual is not None else None, act, out[:, :o_main], tile_cfg=24)
+            gemm(a, w[n_main:], bias[n_main:] if bias is not None else None,
+                 residual[:, n_main:] if residual is not None else None, act, out[:, o_main:])
+            return out
     if tile_cfg is None:
         tile_cfg = pick_tile(M, N, K)
         if splits == 1 and tile_cfg == 4 and K >= 2048 and K % 64 == 0 and M > 1:

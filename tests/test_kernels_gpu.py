@@ -297,6 +297,27 @@ def test_flash_attention_strided_qkv_and_peaked_rows():
     close(got, _attn_ref(q, k, v, H, 0.125, False), 3e-2, 3e-2, "attn strided")
 
 
+def test_gemm_wave_split_path():
+    """Column split into whole waves of 256x256 tiles + a tail GEMM (kernels.wave_split), with every epilogue the
+    split has to slice: bias, residual, swiglu's interleaved columns, fp32 output."""
+    M, K_ = 700, 2048
+    N = 256 * 130                                            # 3 x 130 = 390 tiles: one wave of 255 + a tail
+    assert K.wave_split(M, N, K_) == 85 * 256
+    a, w = rnd(M, K_, scale=0.5, seed=200), rnd(N, K_, scale=0.05, seed=201)
+    bias = rnd(N, seed=202, dtype=torch.float32)
+    ref = a.float() @ w.float().t() + bias
+    close(K.gemm(a, w, bias=bias, out_dtype=torch.float32), ref, 2e-2, 2e-2, "wave split fp32")
+    res = rnd(M, N, seed=203)
+    close(K.gemm(a, w, bias=bias, residual=res), ref + res.float(), 6e-2, 2e-2, "wave split residual")
+    g = a.float() @ w.float()[0::2].t()
+    u = a.float() @ w.float()[1::2].t()
+    close(K.gemm(a, w, act="swiglu"), F.silu(g) * u, 6e-2, 3e-2, "wave split swiglu")
+    # a narrow tail (the LLaMA gate|up case: 256 of 22016 columns) must not pick split-K under the swiglu epilogue
+    n2 = 256 * 86
+    assert K.wave_split(M, n2, K_) == 85 * 256
+    close(K.gemm(a, w[:n2], act="swiglu"), (F.silu(g) * u)[:, :n2 // 2], 6e-2, 3e-2, "wave split swiglu, narrow tail")
+
+
 # ------------------------------------------------------------------------------------------ norms
 def test_layernorm_rmsnorm():
     x = rnd(77, 1024, scale=3.0, seed=60)
