@@ -1112,16 +1112,7 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 9: return launch_tile<256, 256, 2, 4, AMODE, true, 2>(p, stream);   // 128 KB, wave tile 128x64
     case 10: return launch_tile<128, 128, 2, 4, AMODE, true, 2>(p, stream);  // 8 waves x (64x32), 2 wg/CU
     case 11: return launch_tile<128, 64, 2, 2, AMODE, true, 2>(p, stream);   // 48 KB: 3 wg/CU
-    case 12: return launch_tile<128, 128, 2, 2, AMODE, true, 3, 32>(p, stream);  // BK 32 ring: 48 KB, 3 wg/CU
-    case 13: return launch_tile<128, 128, 2, 2, AMODE, true, 4, 32>(p, stream);  // BK 32 ring: 64 KB, 2 wg/CU
-    case 14: return launch_tile<128, 128, 2, 2, AMODE, true, 2, 32>(p, stream);  // BK 32 2-stage: 32 KB, 4 wg/CU
-    case 15: return launch_tile<256, 128, 4, 2, AMODE, true, 3, 32>(p, stream);  // BK 32 ring: 72 KB, 2 wg/CU x 8 waves
-    case 16: return launch_tile<128, 128, 2, 4, AMODE, true, 3, 64, 1>(p, stream);  // 8-wave ring, interleaved reads
-    case 17: return launch_tile<128, 128, 2, 2, AMODE, true, 3, 64, 1>(p, stream);  // 4-wave ring, interleaved reads
-    case 18: return launch_tile<256, 128, 4, 2, AMODE, true, 3, 64, 1>(p, stream);  // 256x128 ring, interleaved reads
-    case 19: return launch_tile<256, 256, 2, 4, AMODE, true, 4, 32, 1>(p, stream);  // 256x256, BK 32 ring x4 (128 KB), interleaved
-    case 20: return launch_tile<256, 256, 2, 4, AMODE, true, 4, 32, 2>(p, stream);  // same, burst reads
-    case 21: return launch_tile<256, 256, 2, 4, AMODE, true, 3, 32, 1>(p, stream);  // 256x256, BK 32 ring x3 (96 KB)
+    // (12-21 were the BK = 32 / interleaved-read ring experiments of DESIGN.md section 3; they lost and were removed)
     case 22: return launch_pp<AMODE>(p, stream);                                 // 256x256 ping-pong (4 barriers / K tile)
     case 24: return launch_pp32<AMODE>(p, stream);                               // 256x256 ping-pong, K 32 ring of 4
     case 25: return launch_pp32<AMODE, true>(p, stream);                         // same + s_memtime stamps (tools only)

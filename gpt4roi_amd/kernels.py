@@ -104,9 +104,8 @@ class _Profiler:
 
 PROFILER = _Profiler()
 TILE_NAMES = {0: "128x128", 1: "256x128", 2: "128x128reg", 4: "64x128", 5: "128x128s3", 6: "128x128s4",
-              7: "128x128w8s4", 8: "256x128s3", 9: "256x256", 10: "128x128w8", 11: "128x64", 12: "128x128k32s3", 13: "128x128k32s4",
-              14: "128x128k32", 15: "256x128k32s3", 16: "128x128w8s3i", 17: "128x128s3i", 18: "256x128s3i", 19: "256x256k32s4i", 20: "256x256k32s4b",
-              21: "256x256k32s3i", 22: "256x256pp", 24: "256x256pp32"}
+              7: "128x128w8s4", 8: "256x128s3", 9: "256x256", 10: "128x128w8", 11: "128x64", 22: "256x256pp",
+              24: "256x256pp32"}
 
 
 def _launch(name, args, tag=None, flops=0.0, nbytes=0.0):

@@ -23,9 +23,9 @@ def lib():
 
 def test_library_exports_every_declared_symbol(lib):
     names = set()
-    for h in ("g4r_roi_align.h", "g4r_kernels.h"):
+    for h in ("g4r_roi_align.h", "g4r_kernels.h", "g4r_train.h"):
         names |= set(re.findall(r"\b(g4r_\w+)\s*\(", open(os.path.join(ROOT, "include", h)).read()))
-    assert len(names) >= 25
+    assert len(names) >= 45
     for n in sorted(names):
         assert hasattr(lib, n), n
     assert lib.g4r_abi_version() == 3

@@ -1,0 +1,105 @@
+"""CPU: host logic of the training rows -- the learning-rate schedule against HF's own scheduler, the tile /
+wave-split planners of the GEMM front, argument validation of the training C ABI without a GPU, and the oracle's
+differentiable RoIAlign node (forward and backward are the pinned C oracle)."""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "gpt4roi_amd", "lib", "libgpt4roi_hip.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        from gpt4roi_amd import build
+        build.build()
+    l = ctypes.CDLL(LIB)
+    l.g4r_last_error.restype = ctypes.c_char_p
+    return l
+
+
+def test_cosine_schedule_matches_hf_trainer():
+    # train_stage1.sh: --lr_scheduler_type cosine --warmup_ratio 0.003 --learning_rate 2e-5
+    from transformers import get_cosine_schedule_with_warmup
+    from gpt4roi_amd.train import cosine_lr
+    total, base, ratio = 5000, 2e-5, 0.003
+    warm = math.ceil(total * ratio)                       # HF TrainingArguments.get_warmup_steps
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=base)
+    sch = get_cosine_schedule_with_warmup(opt, warm, total)
+    for step in range(total):
+        if step in (0, 1, warm - 1, warm, warm + 1, 777, 2500, 4998, 4999):
+            assert abs(sch.get_last_lr()[0] - cosine_lr(step, total, base, ratio)) < 1e-12, step
+        opt.step()
+        sch.step()
+
+
+def test_tile_planners():
+    from gpt4roi_amd import kernels as K
+    # the ring ping-pong tile only where whole waves of 256x256 tiles come out; never for skinny or short-K problems
+    assert K.pick_tile(767, 12288, 4096) == 24 and K.pick_tile(4096, 4096, 4096) == 24
+    assert K.pick_tile(767, 22016, 4096) != 24 and K.pick_tile(577, 4096, 1024) != 24 and K.pick_tile(1, 4096, 4096) != 24
+    assert K.wave_split(767, 22016, 4096) == 85 * 256      # 3 x 85 = 255 tiles = one wave; tail of 256 columns
+    assert K.wave_split(767, 32006, 4096) == 85 * 256
+    assert K.wave_split(767, 12288, 4096) is None          # fewer than one wave: no main part
+    assert K.wave_split(4096, 4096, 4096) is None          # exactly one wave: nothing to split
+    for (M, N, Kd) in [(767, 22016, 4096), (1534, 22016, 4096), (700, 33280, 2048), (3000, 9000, 8192)]:
+        n = K.wave_split(M, N, Kd)
+        if n is not None:
+            assert 0 < n < N and n % 256 == 0 and (-(-M // 256) * (n // 256)) % 256 <= -(-M // 256) * 256 - 1
+            assert (-(-M // 256) * (n // 256)) <= (-(-M // 256) * -(-N // 256))
+    tile, splits = K.pick_conv_tile(192 * 192, 1024, 9216)
+    assert (tile, splits) == (24, 1)
+    tile, splits = K.pick_conv_tile(24 * 24, 1024, 9216)
+    assert tile == 4 and splits > 1
+
+
+def test_training_abi_validates_arguments_without_a_gpu(lib):
+    f = ctypes.c_float
+    assert lib.g4r_flash_attn_bwd_bf16(*([None] * 10), 1, 2, 8, 8, 96, *([ctypes.c_long(128)] * 16), f(1.0), 1, None) == 1
+    assert b"head_dim" in lib.g4r_last_error()
+    assert lib.g4r_rmsnorm_bwd_bf16(None, None, None, None, None, None, 4, 100, ctypes.c_long(104), ctypes.c_long(104),
+                                    ctypes.c_long(0), ctypes.c_long(104), f(1e-6), None) == 1     # cols % 8
+    assert lib.g4r_rmsnorm_bwd_bf16(None, None, None, None, None, None, 0, 128, ctypes.c_long(128), ctypes.c_long(128),
+                                    ctypes.c_long(0), ctypes.c_long(128), f(1e-6), None) == 0     # zero rows: no-op
+    assert lib.g4r_cross_entropy_f32(None, None, None, None, None, 3, 10, ctypes.c_long(10), ctypes.c_long(0), 8, None) == 1
+    assert lib.g4r_adamw_f32(None, None, 0, None, None, None, ctypes.c_long(16), f(1e-3), f(0.9), f(0.999), f(1e-8), f(0.0),
+                             0, f(1.0), None) == 1
+    assert b"step" in lib.g4r_last_error()
+    assert lib.g4r_nhwc_to_cm_padded_bf16(None, None, 1, 4, 4, 8, 5, ctypes.c_long(30), ctypes.c_long(8), ctypes.c_long(64),
+                                          1, None) == 1                                          # Wp < W + 2
+    assert lib.g4r_gather_rows_bf16(None, None, None, 0, 64, ctypes.c_long(64), ctypes.c_long(64), None) == 0
+
+
+def test_oracle_roi_align_autograd_node():
+    """oracle/spi_oracle._RoIAlignOracleFn: backward is the C oracle's backward, which is the transpose of its forward."""
+    from oracle import spi_oracle as S
+    layer = S.RoIAlignOracle(7, spatial_scale=0.5, sampling_ratio=2)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 12, 10, generator=g, requires_grad=True)
+    rois = torch.tensor([[0, 1.5, 2.0, 14.0, 17.5], [1, 0.0, 0.0, 19.0, 23.0], [0, 6.2, 3.3, 9.9, 8.1]])
+    y = layer(x, rois)
+    w = torch.randn(y.shape, generator=g)
+    (y * w).sum().backward()
+    # <A x, w> = <x, A^T w> for the linear map A = roi_align(., rois)
+    x2 = torch.randn(x.shape, generator=g)
+    y2 = layer(x2, rois)
+    lhs = float((y2 * w).sum())
+    rhs = float((x2 * x.grad).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+    assert np.isfinite(x.grad.numpy()).all() and float(x.grad.abs().sum()) > 0
+
+
+def test_trainer_refuses_cpu():
+    # no CPU fallback anywhere in the product path: kernels.* raise on CPU tensors
+    from gpt4roi_amd import kernels as K
+    from gpt4roi_amd._lib import HipKernelError
+    with pytest.raises(HipKernelError):
+        K.rmsnorm_bwd(torch.zeros(2, 64, dtype=torch.bfloat16), torch.ones(64), torch.zeros(2, 64, dtype=torch.bfloat16))
+    with pytest.raises(HipKernelError):
+        K.cross_entropy(torch.zeros(2, 8), torch.zeros(2, dtype=torch.int64), torch.zeros(1))
