@@ -498,6 +498,45 @@ inline int grid_for(long work_items) {
   return (int)b;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Image front end: uint8 HWC image -> normalised, bilinearly resized fp32 CHW tensor, the
+// step right before the ViT.  Replaces, on the device, `image_processor.preprocess` + F.interpolate(size,
+// mode='bilinear', align_corners=False) of gpt4roi/app.py:125-136 and the Resize/Normalize stages of the dataset
+// pipelines (gpt4roi/datasets/refcoco.py:69-85).  Normalisation is affine and interpolation linear, so doing
+// them in one pass equals normalise-then-resize.  PyTorch's half-pixel convention:
+//   src = max(0, (dst + 0.5) * in/out - 0.5), i0 = floor(src), i1 = min(i0 + 1, in - 1).
+// ---------------------------------------------------------------------------------------------
+struct NormParams {
+  float mean[3], inv_std[3];
+};
+
+__global__ __launch_bounds__(256) void image_preprocess_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                               int H, int W, long row_bytes, int bgr, int OH, int OW,
+                                                               NormParams np) {
+  const long total = (long)OH * OW;
+  const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ox = (int)(i % OW), oy = (int)(i / OW);
+    float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+    if (fy < 0.f) fy = 0.f;
+    if (fx < 0.f) fx = 0.f;
+    int y0 = (int)fy, x0 = (int)fx;
+    if (y0 > H - 1) y0 = H - 1;
+    if (x0 > W - 1) x0 = W - 1;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const uint8_t* r0 = src + (size_t)y0 * row_bytes;
+    const uint8_t* r1 = src + (size_t)y1 * row_bytes;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int sc = bgr ? 2 - c : c;
+      const float p00 = r0[x0 * 3 + sc], p01 = r0[x1 * 3 + sc], p10 = r1[x0 * 3 + sc], p11 = r1[x1 * 3 + sc];
+      const float v = (1.f - ly) * ((1.f - lx) * p00 + lx * p01) + ly * ((1.f - lx) * p10 + lx * p11);
+      dst[(size_t)c * total + i] = (v * (1.f / 255.f) - np.mean[c]) * np.inv_std[c];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -628,6 +667,19 @@ int g4r_cast_f32_to_bf16(const float* x, void* y, long n, void* stream) {
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x,
                      (bf16_t*)y, n);
   G4R_CHECK_LAUNCH("cast_f32_bf16");
+  return G4R_OK;
+}
+
+int g4r_image_preprocess_u8_f32(const void* image, int height, int width, long row_bytes, int bgr, float* out,
+                                int out_h, int out_w, float mean_r, float mean_g, float mean_b, float std_r,
+                                float std_g, float std_b, void* stream) {
+  G4R_REQUIRE(height > 0 && width > 0 && out_h > 0 && out_w > 0 && row_bytes >= 3L * width, "image_preprocess: bad shape");
+  G4R_REQUIRE(image && out, "image_preprocess: null pointer");
+  G4R_REQUIRE(std_r > 0.f && std_g > 0.f && std_b > 0.f, "image_preprocess: std must be positive");
+  NormParams np = {{mean_r, mean_g, mean_b}, {1.f / std_r, 1.f / std_g, 1.f / std_b}};
+  hipLaunchKernelGGL(image_preprocess_kernel, dim3(grid_for((long)out_h * out_w)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)image, out, height, width, row_bytes, bgr, out_h, out_w, np);
+  G4R_CHECK_LAUNCH("image_preprocess");
   return G4R_OK;
 }
 

@@ -56,6 +56,8 @@ _SIGS = {
     "g4r_argmax_rows_f32": [P, c_long, c_int, c_int, P, P],
     "g4r_add_rows_bf16": [P, P, P, c_long, c_int, c_long, P],
     "g4r_cast_f32_to_bf16": [P, P, c_long, P],
+    "g4r_image_preprocess_u8_f32": [P, c_int, c_int, c_long, c_int, P, c_int, c_int, c_float, c_float, c_float, c_float,
+                                    c_float, c_float, P],
     "g4r_roi_align_mlvl_nhwc_bf16": [P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, P],
     "g4r_roi_align_mlvl_nhwc_f32": [P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -475,6 +477,25 @@ def cast_bf16(x):
     _launch("g4r_cast_f32_to_bf16", (
         _p(x), _p(y), x.numel(), _stream(x),))
     return y
+
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)      # openai/clip-vit-large-patch14 image processor;
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)       # refcoco.py:69-72 uses the same numbers * 255
+
+
+def image_preprocess(image, size, mean=CLIP_MEAN, std=CLIP_STD, bgr=False, out=None):
+    """image uint8 [H, W, 3] on the GPU (row-strided ok) -> fp32 [3, size, size] normalised and bilinearly resized
+    (align_corners=False), ready for ClipVisionTower.forward (stack several for a batch)."""
+    _lib.require_gpu(image)
+    assert image.dtype == torch.uint8 and image.dim() == 3 and image.size(2) == 3 and image.stride(2) == 1 \
+        and image.stride(1) == 3
+    oh, ow = (size, size) if isinstance(size, int) else size
+    if out is None:
+        out = torch.empty((3, oh, ow), dtype=torch.float32, device=image.device)
+    _launch("g4r_image_preprocess_u8_f32", (_p(image), image.size(0), image.size(1), image.stride(0), int(bool(bgr)),
+                                            _p(out), oh, ow, *[float(m) for m in mean], *[float(s) for s in std],
+                                            _stream(image),), tag="g4r_image_preprocess_u8_f32")
+    return out
 
 
 def roi_align_mlvl(feats, rois, output_size, scales, sampling_ratio=2, aligned=True, affines=None, out=None):

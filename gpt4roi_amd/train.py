@@ -33,6 +33,20 @@ def cosine_lr(step, total_steps, base_lr, warmup_ratio=0.003):
     return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
 
 
+def exchange_gradients(reducer, tensors, grads):
+    """Average `grads` (name -> tensor) over the ranks with a GradBucketReducer built over `tensors` (name -> the
+    parameter tensor each gradient belongs to).  Gradients are reported in reverse registration order -- the order
+    the backward produces them (head of the model first) -- so that the first buckets are on the wire while the
+    rest is still being computed.  Returns name -> averaged gradient (views into the reducer's flat buckets).
+    Backend agnostic: RCCL on the node, gloo in tests/test_train_exchange_gloo.py."""
+    names = list(tensors)
+    reducer.reset()
+    for k in reversed(names):
+        reducer.ready(tensors[k], grads[k])
+    red = reducer.finish()
+    return {k: red[id(tensors[k])] for k in names}
+
+
 class RegionTrainer:
     """Stage-1 trainer: `model.spi_module` (and optionally `model.mm_projector`) are updated, the vision tower and
     the decoder stay frozen.  `step()` returns the mean token loss as a device tensor."""
@@ -104,11 +118,7 @@ class RegionTrainer:
     def apply(self, grads, lr=None):
         names = list(self.params)
         if self.reducer is not None:
-            self.reducer.reset()
-            for k in reversed(names):                      # the order backward produced them (head of the module first)
-                self.reducer.ready(self.params[k], grads[k])
-            red = self.reducer.finish()
-            grads = {k: red[id(self.params[k])] for k in names}
+            grads = exchange_gradients(self.reducer, self.params, grads)
         scale = 1.0
         if self.max_grad_norm is not None and self.max_grad_norm > 0:
             norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(grads[k]) for k in names]))
@@ -178,11 +188,7 @@ class FullTrainer(RegionTrainer):
         names = list(self.params) + list(self.dec_master)
         tensors = {**{k: p.data for k, p in self.params.items()}, **self.dec_master}
         if self.reducer is not None:
-            self.reducer.reset()
-            for k in reversed(names):
-                self.reducer.ready(self.params[k] if k in self.params else self.dec_master[k], grads[k])
-            red = self.reducer.finish()
-            grads = {k: red[id(self.params[k] if k in self.params else self.dec_master[k])] for k in names}
+            grads = exchange_gradients(self.reducer, {**self.params, **self.dec_master}, grads)
         scale = 1.0
         if self.max_grad_norm is not None and self.max_grad_norm > 0:
             norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(grads[k].float()) for k in names]))

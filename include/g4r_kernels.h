@@ -144,6 +144,16 @@ int g4r_argmax_rows_f32(const float* logits, long ld, int rows, int N, long* out
 int g4r_add_rows_bf16(const void* a, const void* b, void* y, long rows, int C, long brows, void* stream);
 int g4r_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
 
+/*
+ * Image front end: uint8 HWC (RGB, or BGR with bgr = 1) -> fp32 CHW [3, out_h, out_w],
+ * (pixel/255 - mean) / std, bilinear resize with align_corners = False -- `image_processor.preprocess` followed by
+ * F.interpolate of gpt4roi/app.py:125-136; the Resize + Normalize stages of the dataset pipelines
+ * (gpt4roi/datasets/refcoco.py:69-85).  row_bytes = bytes between image rows (>= 3 * width).
+ */
+int g4r_image_preprocess_u8_f32(const void* image, int height, int width, long row_bytes, int bgr, float* out,
+                                int out_h, int out_w, float mean_r, float mean_g, float mean_b, float std_r,
+                                float std_g, float std_b, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

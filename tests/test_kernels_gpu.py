@@ -318,6 +318,20 @@ def test_gemm_wave_split_path():
     close(K.gemm(a, w[:n2], act="swiglu"), (F.silu(g) * u)[:, :n2 // 2], 6e-2, 3e-2, "wave split swiglu, narrow tail")
 
 
+def test_image_preprocess_matches_normalise_then_interpolate():
+    # app.py:125-136: processor (rescale 1/255, normalise) then F.interpolate(bilinear, align_corners=False)
+    g = torch.Generator().manual_seed(77)
+    for (H, W, S) in [(480, 640, 336), (100, 37, 224), (224, 224, 224), (30, 50, 112)]:
+        img = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)
+        mean, std = torch.tensor(K.CLIP_MEAN), torch.tensor(K.CLIP_STD)
+        ref = ((img.permute(2, 0, 1).float() / 255.0) - mean[:, None, None]) / std[:, None, None]
+        ref = F.interpolate(ref[None], size=(S, S), mode="bilinear", align_corners=False)[0]
+        got = K.image_preprocess(img.to(DEV), S)
+        close(got, ref, 2e-5, 2e-5, f"image preprocess {H}x{W}->{S}")
+        got_bgr = K.image_preprocess(img.flip(2).contiguous().to(DEV), S, bgr=True)
+        close(got_bgr, ref, 2e-5, 2e-5, "image preprocess bgr")
+
+
 # ------------------------------------------------------------------------------------------ norms
 def test_layernorm_rmsnorm():
     x = rnd(77, 1024, scale=3.0, seed=60)

@@ -103,3 +103,26 @@ def test_trainer_refuses_cpu():
         K.rmsnorm_bwd(torch.zeros(2, 64, dtype=torch.bfloat16), torch.ones(64), torch.zeros(2, 64, dtype=torch.bfloat16))
     with pytest.raises(HipKernelError):
         K.cross_entropy(torch.zeros(2, 8), torch.zeros(2, dtype=torch.int64), torch.zeros(1))
+
+
+def test_collator_contract():
+    # gpt4roi/datasets/data_modules.py:22-56
+    from types import SimpleNamespace
+    from gpt4roi_amd.data import IGNORE_INDEX, DataCollatorForDetDataset, expand_image_tokens, to_device
+    coll = DataCollatorForDetDataset(pad_token_id=0)
+    inst = [dict(input_ids=torch.tensor([1, 5, 6, 7]), labels=torch.tensor([-100, -100, 6, 7]), image=torch.zeros(3, 28, 28),
+                 img_metas=dict(i=0), bboxes=torch.tensor([[0.1, 0.2, 0.5, 0.6]])),
+            dict(input_ids=torch.tensor([1, 9]), labels=torch.tensor([-100, 9]), image=torch.ones(3, 28, 28),
+                 img_metas=dict(i=1), bboxes=torch.zeros(0, 4))]
+    b = coll(inst)
+    assert b['input_ids'].tolist() == [[1, 5, 6, 7], [1, 9, 0, 0]]
+    assert b['labels'].tolist() == [[-100, -100, 6, 7], [-100, 9, IGNORE_INDEX, IGNORE_INDEX]]
+    assert b['attention_mask'].tolist() == [[True] * 4, [True, True, False, False]]
+    assert b['images'].shape == (2, 3, 28, 28) and len(b['bboxes']) == 2 and b['img_metas'][1]['i'] == 1
+    inst[1]['image'] = torch.ones(3, 14, 14)                         # ragged images stay a list
+    assert isinstance(coll(inst)['images'], list)
+    ids = SimpleNamespace(im_patch_token=100, im_start_token=103, im_end_token=104)
+    assert expand_image_tokens(torch.tensor([1, 50, 2]), 50, ids, 3).tolist() == [1, 103, 100, 100, 100, 104, 2]
+    dev = to_device(b, "cpu")
+    assert dev['bboxes'].counts == [1, 0] and dev['bboxes'].n == 1 and dev['bboxes'].offsets.tolist() == [0, 1, 1]
+    assert torch.allclose(dev['bboxes'].rois5, torch.tensor([[0.0, 2.8, 5.6, 14.0, 16.8]]))
