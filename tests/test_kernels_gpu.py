@@ -325,7 +325,7 @@ def test_image_preprocess_matches_normalise_then_interpolate():
         img = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)
         mean, std = torch.tensor(K.CLIP_MEAN), torch.tensor(K.CLIP_STD)
         ref = ((img.permute(2, 0, 1).float() / 255.0) - mean[:, None, None]) / std[:, None, None]
-        ref = F.interpolate(ref[None], size=(S, S), mode="bilinear", align_corners=False)[0]
+        ref = F.interpolate(ref[None], size=(S, S), mode="bilinear", align_corners=False)[0].to(DEV)
         got = K.image_preprocess(img.to(DEV), S)
         close(got, ref, 2e-5, 2e-5, f"image preprocess {H}x{W}->{S}")
         got_bgr = K.image_preprocess(img.flip(2).contiguous().to(DEV), S, bgr=True)
