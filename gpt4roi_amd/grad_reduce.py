@@ -19,7 +19,7 @@ DDP's defaults:
     flat buffers (averaged), no extra copy.
 
 Backend agnostic: RCCL ("nccl" on ROCm) on the node, gloo in the CPU tests
-(tests/test_grad_reduce_gloo.py).  The backward kernels that feed it are the next row.
+(tests/test_grad_reduce_gloo.py, tests/test_train_exchange_gloo.py).  Fed by gpt4roi_amd/train.py.
 """
 import torch
 import torch.distributed as dist

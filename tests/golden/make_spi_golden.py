@@ -14,6 +14,8 @@ and per-stage statistics.
 
   spi_module_ref_c64.npz   embed_dims 64,  B 2, rois (3, 2)   -> CPU pin of the restatement
   spi_module_ref_c512.npz  embed_dims 512, B 1, rois (5,)     -> GPU parity fixture (224^2, P 16)
+  spi_module_ref_grads_c64.npz  digests of every parameter GRADIENT of the reference module (loss = sum(out^2)/2)
+                           -> CPU pin of the oracle's backward (the reference the training rows are checked against)
 """
 import importlib.util
 import os
@@ -83,9 +85,36 @@ def run(ref, embed_dims, B, n_rois, wseed, iseed, name):
     print(name, out.shape, "mean", out.mean(), "std", out.std(), "absmax", np.abs(out).max())
 
 
+def grad_digest(g):
+    """Small, order-sensitive digest of a gradient tensor: norms + 64 leading + 64 strided elements."""
+    f = g.detach().double().flatten()
+    n = f.numel()
+    idx = (torch.arange(64) * max(1, n // 64)).clamp(max=n - 1)
+    return np.concatenate([[float(f.norm()), float(f.sum()), float(f.abs().max()), float(n)],
+                           f[:64].numpy() if n >= 64 else np.pad(f.numpy(), (0, 64 - n)), f[idx].numpy()])
+
+
+def run_grads(ref, embed_dims, B, n_rois, wseed, iseed, name):
+    """Parameter gradients of the REFERENCE'S module code under autograd (training rows): loss = sum(out^2)/2.
+    The RoIAlign leaf is oracle.spi_oracle.RoIAlignOracle, whose autograd node is the C oracle's forward and
+    backward -- both bit-exact against the reference's compiled CPU op (tests/test_oracle_roi_align.py)."""
+    torch.manual_seed(0)
+    m = ref.MLVLROIQueryModule(embed_dims=embed_dims, out_dims=4096, num_levels=4)
+    m.load_state_dict(S.synthetic_state(m, wseed))
+    m.train()
+    feats, boxes = S.synthetic_inputs(iseed, B, 16, embed_dims, n_rois)
+    out = torch.cat(m([f.clone() for f in feats], boxes), 0)
+    (0.5 * out.pow(2).sum()).backward()
+    digests = {k.replace(".", "__"): grad_digest(p.grad) for k, p in m.named_parameters()}
+    np.savez_compressed(os.path.join(HERE, name), embed_dims=embed_dims, B=B, n_rois=np.array(n_rois), wseed=wseed,
+                        iseed=iseed, P=16, loss=float(0.5 * out.detach().pow(2).sum()), **digests)
+    print(name, len(digests), "parameter gradients; loss", float(0.5 * out.detach().pow(2).sum()))
+
+
 if __name__ == "__main__":
     ref = import_reference_layers()
     torch.set_num_threads(os.cpu_count())
     run(ref, 64, 2, (3, 2), 11, 12, "spi_module_ref_c64.npz")
+    run_grads(ref, 64, 2, (3, 2), 11, 12, "spi_module_ref_grads_c64.npz")
     if "--small" not in sys.argv:
         run(ref, 512, 1, (5,), 21, 22, "spi_module_ref_c512.npz")

@@ -59,3 +59,32 @@ def test_splice_restatement():
     bad[0, 5] = 3
     with pytest.raises(ValueError):
         S.splice(bad, emb, img, spi, IMS, IME, BBOX)
+
+
+def test_restated_module_backward_matches_reference_code(golden_dir):
+    """Training rows: every parameter gradient of the restated module (autograd, RoIAlign = the C oracle's forward +
+    backward) against digests of the gradients the REFERENCE'S own layers.py produces on the same seeds
+    (tests/golden/make_spi_golden.py::run_grads).  This is what makes the oracle a pinned reference for
+    MLVLROIQueryModule.backward (tests/test_train_gpu.py)."""
+    z = np.load(os.path.join(golden_dir, "spi_module_ref_grads_c64.npz"))
+    C, B, P = int(z["embed_dims"]), int(z["B"]), int(z["P"])
+    m = S.MLVLROIQueryOracle(embed_dims=C, P=P)
+    m.load_state_dict(S.synthetic_state(m, int(z["wseed"])))
+    feats, boxes = S.synthetic_inputs(int(z["iseed"]), B, P, C, [int(n) for n in z["n_rois"]])
+    out = torch.cat(m(feats, boxes), 0)
+    loss = 0.5 * out.pow(2).sum()
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) < 1e-4 * float(z["loss"])
+    names = [k for k, _ in m.named_parameters()]
+    assert len(names) == 43
+    for k, p in m.named_parameters():
+        d = z[k.replace(".", "__")]
+        f = p.grad.detach().double().flatten()
+        n = f.numel()
+        assert n == int(d[3]), k
+        scale = max(d[2], 1e-12)                                          # largest |gradient| of this tensor
+        assert abs(float(f.norm()) - d[0]) < 2e-4 * d[0] + 1e-9, (k, float(f.norm()), d[0])
+        head = f[:64].numpy() if n >= 64 else np.pad(f.numpy(), (0, 64 - n))
+        idx = (torch.arange(64) * max(1, n // 64)).clamp(max=n - 1)
+        np.testing.assert_allclose(head, d[4:68], atol=2e-4 * scale, err_msg=k)
+        np.testing.assert_allclose(f[idx].numpy(), d[68:132], atol=2e-4 * scale, err_msg=k)
