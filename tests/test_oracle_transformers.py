@@ -70,3 +70,32 @@ def test_greedy_decode_matches_hf_generate():
                           max_new_tokens=6, min_new_tokens=6, pad_token_id=0)
     got, _ = T.greedy_decode(w, emb, m.get_input_embeddings(), heads=4, n_new=6)
     assert got == want[0].tolist()[-6:]
+
+
+def test_llama_loss_and_gradients_match_hf_autograd():
+    """Training rows: loss (HF's shifted-label CE, labels = -100 ignored) and the gradients w.r.t. inputs_embeds and
+    weights from autograd through the restated decoder equal those of HF LlamaForCausalLM(inputs_embeds=, labels=)
+    -- the reference's training forward (llava/model/llava.py:203-261 delegates exactly there)."""
+    import torch.nn.functional as F
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(3)
+    cfg = LlamaConfig(vocab_size=97, hidden_size=64, intermediate_size=176, num_hidden_layers=2,
+                      num_attention_heads=4, num_key_value_heads=4, rms_norm_eps=1e-6, max_position_embeddings=64,
+                      attention_bias=False, tie_word_embeddings=False)
+    m = LlamaForCausalLM(cfg).train()
+    emb = torch.randn(2, 11, 64, requires_grad=True)
+    labels = torch.randint(0, 97, (2, 11))
+    labels[:, :4] = -100
+    out = m(inputs_embeds=emb, labels=labels)
+    out.loss.backward()
+    w = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    emb2 = emb.detach().clone().requires_grad_(True)
+    h, _ = T.llama_forward(w, emb2, heads=4)
+    logits = T.lm_logits(w, h)
+    loss = F.cross_entropy(logits[:, :-1].reshape(-1, 97), labels[:, 1:].reshape(-1), ignore_index=-100)
+    loss.backward()
+    assert abs(float(loss) - float(out.loss)) < 1e-5
+    assert torch.allclose(emb2.grad, emb.grad, atol=1e-6)
+    for k in ("model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight",
+              "model.layers.0.input_layernorm.weight", "model.norm.weight", "lm_head.weight"):
+        assert torch.allclose(w[k].grad, dict(m.named_parameters())[k].grad, atol=1e-6), k
