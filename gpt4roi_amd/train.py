@@ -52,7 +52,7 @@ class RegionTrainer:
     the decoder stay frozen.  `step()` returns the mean token loss as a device tensor."""
 
     def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
-                 train_projector=False, group=None, bucket_bytes=256 << 20):
+                 train_projector=False, group=None, bucket_bytes=256 << 20, _build_reducer=True):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -72,7 +72,7 @@ class RegionTrainer:
         self.steps = 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.reducer = GradBucketReducer(list(self.params.values()), bucket_bytes=bucket_bytes, group=group,
-                                         comm_dtype=torch.float32) if self.world > 1 else None
+                                         comm_dtype=torch.float32) if (self.world > 1 and _build_reducer) else None
         self.last_grad_norm = None
 
     # ---- forward + backward: parameter gradients in the reference layout ------------------------------------
@@ -152,8 +152,8 @@ class FullTrainer(RegionTrainer):
 
     def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
                  bucket_bytes=256 << 20):
-        super().__init__(model, lr, betas, eps, weight_decay, max_grad_norm, train_projector=True, group=None,
-                         bucket_bytes=bucket_bytes)
+        super().__init__(model, lr, betas, eps, weight_decay, max_grad_norm, train_projector=True, group=group,
+                         bucket_bytes=bucket_bytes, _build_reducer=False)   # one reducer over ALL tensors, below
         dec = model.llama
         dec.prepare_training(train_weights=True)
         self.dec_live = {f"llama.{k}": v for k, v in dec.trainable_tensors().items()}
