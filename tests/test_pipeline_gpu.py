@@ -226,6 +226,39 @@ def test_end_to_end_embeds_logits_and_greedy_ids():
     assert len(gen) == 4
 
 
+def test_baseline_config0_full_size_vit_region_module_projector():
+    """BASELINE.json configs[0]: ONE 336x336 image, 4 random boxes, full-width CLIP ViT-L/14 (23 blocks) + region module
+    (C = 1024, P = 24) + projector, no LLaMA -- the HIP path against the CPU oracles at the real sizes."""
+    H, P, image, heads = 1024, 24, 336, 16
+    vsd = syn.vit_state(H, 4 * H, 24, image, seed=31)
+    tower = ClipVisionTower(vsd, heads=heads, device=DEV)
+    m = MLVLROIQueryModule(embed_dims=H, out_dims=4096, num_levels=4)
+    orc = S.MLVLROIQueryOracle(embed_dims=H, P=P)
+    sd = S.synthetic_state(orc, 32)
+    orc.load_state_dict(sd)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    g = torch.Generator().manual_seed(33)
+    img = torch.randn(1, 3, image, image, generator=g)
+    boxes = [syn.boxes(4, g)]
+    pw, pb = torch.randn(4096, H, generator=g) / H ** 0.5, torch.randn(4096, generator=g) * 0.05
+    keep = tower.forward(img.to(DEV))
+    feat, lv = tower.select(keep)
+    got_spi = torch.cat(m(lv, [b.to(DEV) for b in boxes]), 0)
+    got_proj = K.gemm(feat[0], pw.to(DEV).to(torch.bfloat16), bias=bf(pb).to(DEV))
+    vb = {k: bf(v) for k, v in vsd.items()}
+    with torch.no_grad():
+        hs = T.clip_vit_hidden_states(vb, img, heads=heads, n_layers=23, emulate=True)
+        img_feat, olv = T.select_spi_levels(hs + [hs[-1]], -2, 4)
+        want_spi = torch.cat(orc(olv, boxes, emulate=True), 0)
+        want_proj = bf(bf(img_feat[0]) @ bf(pw).t() + bf(pb))
+    e_lv = max(relerr(a[0], b[0]) for a, b in zip(lv, olv))
+    e_spi, e_proj = relerr(got_spi, want_spi), relerr(got_proj, want_proj)
+    print("configs[0] at full size: ViT levels", e_lv, "region tokens", e_spi, "patch tokens", e_proj)
+    assert got_spi.shape == (4, 4096) and got_proj.shape == (P * P, 4096)
+    assert e_lv < 3e-2 and e_spi < 3e-2 and e_proj < 3e-2
+
+
 def test_end_to_end_batch_of_two_ragged_regions():
     """B = 2 images with different numbers of regions (one has none): the batched call must equal
     the two single-image calls (every stage of the path is per-image)."""
