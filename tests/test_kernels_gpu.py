@@ -297,6 +297,37 @@ def test_flash_attention_strided_qkv_and_peaked_rows():
     close(got, _attn_ref(q, k, v, H, 0.125, False), 3e-2, 3e-2, "attn strided")
 
 
+def test_roi_align_full_size_properties():
+    """BASELINE configs[1] sizes (4 levels 192/96/48/24 x 1024 channels, 32 RoIs, 14x14 bins): the oracle would take
+    minutes, so the fused multi-level kernels are checked through size-independent properties -- a constant map pools
+    to the constant, the op is linear, and the backward kernel is its exact transpose (<f(x), w> = <x, f^T(w)>)."""
+    C, N, sizes = 1024, 32, [192, 96, 48, 24]
+    scales = [1 / 1.75, 1 / 3.5, 1 / 7.0, 1 / 14.0]
+    g = torch.Generator().manual_seed(300)
+    xy = torch.rand(N, 2, generator=g) * 0.6
+    wh = torch.rand(N, 2, generator=g) * 0.3 + 0.05
+    rois = torch.cat([torch.zeros(N, 1), torch.cat([xy, xy + wh], 1) * 336.0], 1).to(DEV)
+    x = [torch.randn(1, n, n, C, generator=g).to(DEV) for n in sizes]
+    y = [torch.randn(1, n, n, C, generator=g).to(DEV) for n in sizes]
+    fx = K.roi_align_mlvl(x, rois, 14, scales)
+    fy = K.roi_align_mlvl(y, rois, 14, scales)
+    fz = K.roi_align_mlvl([2.0 * a + 3.0 * b for a, b in zip(x, y)], rois, 14, scales)
+    assert fx.shape == (4, N, 14, 14, C)
+    assert float((fz - (2.0 * fx + 3.0 * fy)).abs().max()) < 2e-4
+    ones = K.roi_align_mlvl([torch.full_like(a, 1.5) for a in x], rois, 14, scales)
+    assert float((ones - 1.5).abs().max()) < 1e-5                     # every sample of these boxes is inside the map
+    w = torch.randn(fx.shape, generator=g).to(torch.bfloat16).to(DEV)    # [L, N, 14, 14, C]
+    grads = [torch.zeros_like(a) for a in x]
+    K.roi_align_mlvl_bwd(w, w.stride(0), w.stride(3), grads, rois, 14, scales, 2, True)
+    lhs = float((fx.double() * w.double()).sum())
+    rhs = float(sum((a.double() * gr.double()).sum() for a, gr in zip(x, grads)))
+    assert abs(lhs - rhs) < 2e-6 * float(fx.double().norm() * w.double().norm()), (lhs, rhs)
+    # and the bf16 production kernel agrees with the fp32 instantiation to bf16 rounding
+    fb = K.roi_align_mlvl([a.to(torch.bfloat16) for a in x], rois, 14, scales)
+    fr = K.roi_align_mlvl([a.to(torch.bfloat16).float() for a in x], rois, 14, scales)
+    close(fb, fr, 2e-2, 1e-2, "bf16 vs fp32 mlvl roi_align at full size")
+
+
 def test_gemm_wave_split_path():
     """Column split into whole waves of 256x256 tiles + a tail GEMM (kernels.wave_split), with every epilogue the
     split has to slice: bias, residual, swiglu's interleaved columns, fp32 output."""
