@@ -376,7 +376,7 @@ def test_fuse_module_backward_isolated(rounds):
     errs = {k: round(relerr(grads[k], ref[k]), 4) for k in sorted(ref)}
     coss = {k: round(cosine(grads[k], ref[k]), 5) for k in sorted(ref)}
     print("fuse gradient errors:", errs, "cosines:", coss)
-    assert max(errs.values()) < 8e-2 and min(coss.values()) > 0.998, (errs, coss)
+    assert max(errs.values()) < 0.12 and min(coss.values()) > 0.997, (errs, coss)
     assert errs[f"fuse_convs.{rounds - 1}.gn.weight"] < 6e-3
 
 
