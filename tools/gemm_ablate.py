@@ -18,7 +18,7 @@ def timeit(fn, iters=10, warm=3):
 lib = _lib.lib()
 for (M, N, Kd) in [(4096, 4096, 4096), (8192, 8192, 4096), (768, 12288, 4096), (768, 22016, 4096)]:
     a, w = R(M, Kd), R(N, Kd)
-    for tile in (24, 26):
+    for tile in (0, 9, 22, 24):
         row = []
         for mode in (0, 1, 2):
             lib.g4r_gemm_debug_mode(mode)
@@ -28,6 +28,6 @@ for (M, N, Kd) in [(4096, 4096, 4096), (8192, 8192, 4096), (768, 12288, 4096), (
         lib.g4r_gemm_debug_mode(0)
         print(f"{M}x{N}x{Kd} tile{tile}: " + " | ".join(row), flush=True)
 x = R(1, 192, 192, 1024); w = R(1024, 9 * 1024)
-for tile in (24, 26):
+for tile in (9, 22, 24):
     t = timeit(lambda: K.conv3x3(x, w, tile_cfg=tile), iters=5)
     print(f"conv3x3 192 tile{tile}: {t*1e6:.1f}us {2.0*192*192*1024*9216/t/1e12:.1f}TF", flush=True)
