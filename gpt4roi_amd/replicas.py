@@ -4,8 +4,8 @@ image, splice per sample, decoder per sequence).  The only communi
 benchmark bookkeeping below (a barrier and a MAX/SUM all-reduce of two scalars), which is backend
 agnostic: RCCL ("nccl" on ROCm) on the GPU box, gloo in the CPU tests.
 
-Training (stage 1/2) adds a real exchange step -- the gradient all-reduce -- and is the next row
-(SURVEY.md 8f); nothing here pretends to be that.
+Training (stage 1/2) adds a real exchange step -- the gradient all-reduce; that lives in grad_reduce.py and
+train.py, not here.
 """
 import time
 
