@@ -295,6 +295,30 @@ class LlamaDecoder:
         return st["out"][:done].tolist()
 
     @torch.no_grad()
+    def greedy_batch(self, inputs_embeds, max_new_tokens, stop_ids=()):
+        """generate(do_sample=False) for B sequences with prompts of EQUAL length (the reference stacks its samples,
+        spi_llava.py:196, so a batch always has one T): one decoder pass per step for the whole batch, i.e. the
+        13.5 GB weight stream of a decode step is shared by B sequences.  Sequences that hit a
+        stop id keep running (their later tokens are cut from the result).  Returns a list of B id lists."""
+        B = inputs_embeds.size(0)
+        self.reset(B)
+        logits = self.forward(inputs_embeds, all_logits=False)
+        assert self.pos + max_new_tokens <= self.max_positions
+        out = torch.empty((B, max_new_tokens), dtype=torch.int64, device=inputs_embeds.device)
+        for s in range(max_new_tokens):
+            nxt = K.argmax_rows(logits.view(B, -1))
+            out[:, s] = nxt
+            if s + 1 == max_new_tokens:
+                break
+            emb = K.gather_rows(self.embed, nxt.to(torch.int32))
+            logits = self.forward(emb.view(B, 1, -1), all_logits=False)
+        res = []
+        for row in out.tolist():
+            hit = [i for i, t in enumerate(row) if t in stop_ids]
+            res.append(row[:hit[0] + 1] if hit else row)
+        return res
+
+    @torch.no_grad()
     def greedy(self, inputs_embeds, max_new_tokens, stop_ids=()):
         """generate(do_sample=False) for batch 1: prefill, then one token per step from the KV cache
         (llava/model/llava.py:263-283 feeds only the last token after step 0)."""

@@ -158,6 +158,33 @@ def test_device_resident_greedy_decode_matches_host_loop():
     assert dec.greedy_graph(emb, 20, stop_ids=(stop,), check_every=4) == want[:first + 1]
 
 
+def test_llama_batched_greedy_decode():
+    """greedy_batch (one decoder pass per step for B sequences): every token it emits must be the argmax -- up to
+    bf16 summation-order noise -- of the single-sequence logits for the same prefix (teacher-forced check, robust
+    against near-tie flips between the M = 1 and M = B kernels), and stop ids cut the rows."""
+    sd, dec = _mini_llama(layers=2)
+    B, T0, n_new = 3, 19, 6
+    g = torch.Generator().manual_seed(70)
+    emb_w = bf(sd["model.embed_tokens.weight"])
+    prompts = emb_w[torch.randint(0, 1000, (B, T0), generator=g)].to(DEV).to(torch.bfloat16)
+    got = dec.greedy_batch(prompts, n_new)
+    assert len(got) == B and all(len(r) == n_new for r in got)
+    same = 0
+    for b in range(B):
+        toks = torch.tensor(got[b][:-1], dtype=torch.int64)
+        prefix = torch.cat([prompts[b:b + 1], emb_w[toks][None].to(DEV).to(torch.bfloat16)], 1)
+        dec.reset(1)
+        logits = dec.forward(prefix)[0, T0 - 1:]                       # predictions for the n_new generated positions
+        top = logits.max(-1).values
+        chosen = logits[torch.arange(n_new, device=DEV), torch.tensor(got[b], device=DEV)]
+        assert float((top - chosen).max()) <= 2e-2 * float(logits.abs().max()), (b, (top - chosen).tolist())
+        same += int((logits.argmax(-1).cpu() == torch.tensor(got[b])).sum())
+    assert same >= int(0.8 * B * n_new)
+    stop = got[1][2]
+    cut = dec.greedy_batch(prompts, n_new, stop_ids=(stop,))
+    assert cut[1] == got[1][:got[1].index(stop) + 1] and all(len(r) <= n_new for r in cut)
+
+
 def test_llama_batch2_matches_batch1():
     sd, dec = _mini_llama(layers=2)
     dec.reset(2)
