@@ -83,3 +83,36 @@ def test_ref_build_agrees_when_present():
     a = O.forward(x, r, 14, 0.25, 2)[0]
     b = O.ref_forward(x, r, 14, 0.25, 2)[0]
     assert np.array_equal(a, b)
+
+
+def test_random_configurations_against_the_compiled_reference_and_adjoint():
+    """Hypothesis sweep over shapes / scales / sampling ratios / aligned / pool modes: the C restatement equals the
+    reference's own compiled CPU op bit for bit (when oracle/_ref is built) and its backward is the exact transpose of
+    its forward in fp64 (avg mode): <f(x), w> = <x, f^T(w)>."""
+    from hypothesis import given, settings, strategies as st
+    ref = O.load_ref()
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 2), st.integers(1, 5), st.integers(3, 17), st.integers(3, 17), st.integers(1, 4),
+           st.integers(1, 5), st.integers(1, 5), st.sampled_from([0.25, 0.5, 1.0 / 7.0, 1.0]), st.integers(0, 3),
+           st.booleans(), st.sampled_from(["avg", "max"]), st.integers(0, 2 ** 31 - 1))
+    def check(B, C, H, W, n, ph, pw, scale, sr, aligned, mode, seed):
+        rng = np.random.default_rng(seed)
+        x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        lo = rng.uniform(-2, 0.7 * max(H, W) / scale, (n, 2))
+        rois = np.concatenate([rng.integers(0, B, (n, 1)).astype(np.float64), lo,
+                               lo + rng.uniform(0.0 if not aligned else 0.0, 0.6 * max(H, W) / scale, (n, 2))], 1).astype(np.float32)
+        out, amy, amx = O.forward(x, rois, (ph, pw), np.float32(scale), sr, mode, aligned)
+        assert out.shape == (n, C, ph, pw) and np.isfinite(out).all()
+        if ref is not None:
+            r_out = O.ref_forward(x, rois, (ph, pw), np.float32(scale), sr, mode, aligned)[0]
+            assert np.array_equal(out, r_out)
+        if mode == "avg":
+            x64, r64 = x.astype(np.float64), rois.astype(np.float64)
+            w = rng.standard_normal(out.shape)
+            f = O.forward(x64, r64, (ph, pw), scale, sr, mode, aligned)[0]
+            gt = O.backward(w, r64, x64.shape, (ph, pw), scale, sr, mode, aligned)
+            lhs, rhs = float((f * w).sum()), float((x64 * gt).sum())
+            assert abs(lhs - rhs) <= 1e-9 * (1.0 + abs(lhs))
+
+    check()
