@@ -88,3 +88,42 @@ def test_restated_module_backward_matches_reference_code(golden_dir):
         idx = (torch.arange(64) * max(1, n // 64)).clamp(max=n - 1)
         np.testing.assert_allclose(head, d[4:68], atol=2e-4 * scale, err_msg=k)
         np.testing.assert_allclose(f[idx].numpy(), d[68:132], atol=2e-4 * scale, err_msg=k)
+
+
+def _splice_case():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_splice_golden",
+                                                  os.path.join(os.path.dirname(__file__), "golden", "make_splice_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_splice_and_level_selection_match_reference_code(golden_dir):
+    """Rows a5 + a15: the restated level selection and splice against the output of the reference's own
+    SPILlavaLlamaModel.forward (tests/golden/make_splice_golden.py: the decoder parent is stubbed to return the
+    spliced inputs_embeds).  Pins oracle.spi_oracle.splice, which the GPU splice kernel is tested against."""
+    from oracle import transformer_oracle as T
+    z = np.load(os.path.join(golden_dir, "splice_ref.npz"))
+    G = _splice_case()
+    case = G.build_case(int(z["seed"]))
+    ids = case["input_ids"]
+    assert np.array_equal(ids.numpy(), z["input_ids"])
+    img_feat, levels = T.select_spi_levels(case["hidden"], -2, 4)
+    assert [int(round(float(t.mean()))) for t in levels] == z["levels"].tolist() == [14, 17, 20, 23]
+    assert [tuple(t.shape) for t in levels] == [tuple(s) for s in z["level_shapes"].tolist()]
+    proj = torch.nn.functional.linear(img_feat, case["proj_w"], case["proj_b"])      # as nn.Linear does in the reference
+    emb = case["embed"][ids]
+    got = S.splice(ids, emb, proj, case["spi"], G.IDS["im_start"], G.IDS["im_end"], G.IDS["bbox"])
+    np.testing.assert_allclose(got.numpy(), z["out"], rtol=1e-5, atol=1e-3)   # projector rows are O(1e3) in fp32
+    # the two malformed prompts the reference rejects (spi_llava.py:115-128) are rejected with the same messages
+    end = 3 + case["n_patch"] + 1
+    bad = ids.clone()
+    bad[0, end] = 55
+    with pytest.raises(ValueError, match="should be the same"):
+        S.splice(bad, emb, proj, case["spi"], G.IDS["im_start"], G.IDS["im_end"], G.IDS["bbox"])
+    bad = ids.clone()
+    bad[0, end], bad[0, end + 1] = bad[0, end + 1].item(), G.IDS["im_end"]
+    with pytest.raises(ValueError, match="should follow"):
+        S.splice(bad, emb, proj, case["spi"], G.IDS["im_start"], G.IDS["im_end"], G.IDS["bbox"])
+    assert "should be the same" in str(z["malformed_error"]) and "should follow" in str(z["malformed_error"])
