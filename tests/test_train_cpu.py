@@ -126,3 +126,23 @@ def test_collator_contract():
     dev = to_device(b, "cpu")
     assert dev['bboxes'].counts == [1, 0] and dev['bboxes'].n == 1 and dev['bboxes'].offsets.tolist() == [0, 1, 1]
     assert torch.allclose(dev['bboxes'].rois5, torch.tensor([[0.0, 2.8, 5.6, 14.0, 16.8]]))
+
+
+def test_collator_matches_reference_code(golden_dir):
+    """gpt4roi_amd.data.DataCollatorForDetDataset against the batch the reference's own collator builds from the same
+    seeded instances (tests/golden/make_collator_golden.py imports data_modules.py:22-56 unmodified)."""
+    import importlib.util
+    from gpt4roi_amd.data import DataCollatorForDetDataset
+    spec = importlib.util.spec_from_file_location("make_collator_golden", os.path.join(golden_dir, "make_collator_golden.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    z = np.load(os.path.join(golden_dir, "collator_ref.npz"))
+    b = DataCollatorForDetDataset(pad_token_id=0)(G.instances())
+    assert sorted(b.keys()) == z["keys"].tolist()
+    for k in ("input_ids", "labels", "attention_mask", "images"):
+        assert np.array_equal(b[k].numpy(), z[k]), k
+    assert [x.shape[0] for x in b["bboxes"]] == z["n_boxes"].tolist()
+    assert [m["idx"] for m in b["img_metas"]] == z["metas"].tolist()
+    ragged = G.instances()
+    ragged[1]["image"] = torch.zeros(3, 4, 4)
+    assert isinstance(DataCollatorForDetDataset(0)(ragged)["images"], list) == bool(z["ragged_images_is_list"])
