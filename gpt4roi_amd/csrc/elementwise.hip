@@ -373,6 +373,10 @@ __global__ __launch_bounds__(256) void splice_embed_kernel(const long* __restric
   }
   const int nvec = C >> 3;
   const int so = spi_offset ? spi_offset[b] : 0;
+  // rows of `spi` this sample owns: a prompt with MORE <bbox> tokens than regions must not read the next sample's
+  // rows (or past the allocation); the surplus tokens take their embedding row and status bit 2 reports the
+  // mismatch (the reference raises on the host instead, spi_llava.py:149-157)
+  const int n_region = spi_offset ? spi_offset[b + 1] - so : 0;
   const int t0 = blockIdx.x * tok_per_block;
   const int t1 = min(T, t0 + tok_per_block);
   for (int i = t0 * nvec + tid; i < t1 * nvec; i += 256) {
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(256) void splice_embed_kernel(const long* __restric
     const bf16_t* src;
     if (prank[t] >= 0 && prank[t] < n_patch)
       src = img + ((size_t)b * n_patch + prank[t]) * C;
-    else if (brank[t] >= 0 && spi)
+    else if (brank[t] >= 0 && brank[t] < n_region && spi)
       src = spi + ((size_t)so + brank[t]) * C;
     else {
       long id = row[t];

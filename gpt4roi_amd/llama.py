@@ -211,7 +211,7 @@ class LlamaDecoder:
         lab = torch.full((B, T), -100, dtype=torch.int64, device=logits.device)
         lab[:, :-1] = labels[:, 1:]
         lab = lab.reshape(-1).contiguous()
-        cnt = (lab >= 0).sum().clamp(min=1)
+        cnt = ((lab >= 0) & (lab < self.vocab)).sum().clamp(min=1)     # the kernel ignores labels outside [0, V)
         gs = (1.0 / cnt.float()).reshape(1).contiguous()
         loss_sum = torch.zeros(1, dtype=torch.float32, device=logits.device)
         dlogits = torch.empty((B * T, self.v_pad), dtype=torch.bfloat16, device=logits.device)

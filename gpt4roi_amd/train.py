@@ -96,6 +96,7 @@ class RegionTrainer:
         embeds, status = K.splice_embed(input_ids.contiguous(), m.llama.embed, img_tok, spi, bboxes.offsets, n_patch,
                                         cfg.im_patch_token, cfg.bbox_token, cfg.im_start_token, cfg.im_end_token)
         m.last_status = status
+        m.check_status()        # per-sample <bbox>/region or <im_start>/<im_end> mismatch raises, as spi_llava.py:115-157 does
         m.llama.reset(B)
         logits, lctx = m.llama.forward_train(embeds)
         loss, dlogits = m.llama.loss_and_dlogits(logits, labels)
