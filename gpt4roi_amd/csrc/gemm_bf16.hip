@@ -21,6 +21,8 @@
 //     (16-B slot ^= (row>>1)&7) is applied on the per-lane SOURCE address and again on the
 //     ds_read_b128 address (rule "both sides or neither");
 //   * XCD-aware, bijective workgroup -> tile map so neighbouring tiles share panels in one L2.
+#include <type_traits>
+
 #include "g4r_common.h"
 
 namespace {
@@ -69,7 +71,10 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // Shared epilogue.  acc[i][j] is the 32x32 accumulator of rows mw + 32*i.. and columns nw + 32*j..,
 // in the swapped-operand layout D[n][m]: this lane holds m = mw + 32*i and, per register quad q,
 // the 4 consecutive columns nw + 32*j + 8*q .. +3 (mw / nw already include the lane offsets).
-template <int TM, int TN>
+// J0 / JN: the accumulator columns this call handles (a 4 x 4 wave tile is emitted as two calls of 4 x 2: the fully
+// unrolled 16-accumulator nest exceeds the compiler's unroll budget, and a rolled nest would index `acc` dynamically,
+// i.e. put the accumulators in scratch).
+template <int TM, int TN, int J0 = 0, int JN = TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float16v (&acc)[TM][TN], int mw, int nw,
                                               int split) {
   const bool vec_ok = (p.N & 3) == 0;  // then every in-range quad is a full, aligned quad
@@ -77,7 +82,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float16v (&acc)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = J0; j < J0 + JN; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int m = mw + i * 32, n = nw + j * 32 + q * 8;
@@ -102,7 +107,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float16v (&acc)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+    for (int j = J0; j < J0 + JN; ++j) {
       float16v c = acc[i][j];
       const int m = mw + i * 32;
       if (p.bias) {
@@ -1001,6 +1006,260 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   gemm_epilogue<TM, TN>(p, acc, m0 + wm * 128 + em, n0 + wn * 64 + en, split);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// One-wave-per-SIMD kernel: 256 x 256 tile, FOUR waves (2 x 2), wave tile 128 x 128 = 16 accumulators of 32x32
+// (all 256 AGPRs of the 512-register budget a lone wave per SIMD has), K tiles of 32 in a ring of four.
+// Rationale: the ping-pong kernels above spend two waves per SIMD to overlap one
+// wave's operand reads with the other's MFMAs, and pay for it with 24 ds_read_b128 per wave per 64 of K and two
+// barriers per phase.  A wave that owns 128 x 128 needs 16 + 16 reads per 64 of K for TWICE the flops (192 KB ->
+// 128 KB of LDS reads per CU per 64 of K), keeps next k-step's fragments in flight under its own MFMAs (8 issue
+// slots per 32-cycle MFMA, <= 2 of them used), and synchronises once per K tile of 32 (4 waves, not 8).
+//   per K tile i (two k-steps of 16, F0/F1 = the two fragment register sets):
+//     k-step 0: 16 MFMA on F0 | 8 reads F1 <- (buf i, k1)         | pieces 4-7 of tile i+3
+//     k-step 1:  4 MFMA on F1 | lgkmcnt(0), vmcnt(<=16), barrier(i)                            (tile i+1 has landed,
+//               12 MFMA on F1 | 8 reads F0 <- (buf i+1, k0)       | pieces 0-3 of tile i+4      buf i is free)
+// ---------------------------------------------------------------------------------------------
+template <int AMODE>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, NW = 4, NT = 256, BKT = 32, RING = 4;
+  constexpr int ROWB = 64, SPR = 4;
+  constexpr int TM = 4, TN = 4;
+  constexpr int NA = BM * SPR / NT, NB = BN * SPR / NT;  // 4 + 4 pieces per wave per K tile
+  constexpr int A_BYTES = BM * BKT * 2, STAGE_BYTES = (BM + BN) * BKT * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // RING * STAGE_BYTES = 128 KB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = p.n_fastest ? wg / p.tiles_n : wg % p.tiles_m;
+  const int tile_n = p.n_fastest ? wg % p.tiles_n : wg / p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int split = blockIdx.y;
+  const int t_begin = split * p.tiles_per_split;
+  int t_end = t_begin + p.tiles_per_split;
+  const int nt_total = p.K / BKT;
+  if (t_end > nt_total) t_end = nt_total;
+
+  const bf16_t* a_src[NA];
+  int a_yx[NA];
+  const bf16_t* b_src[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int pslot = (j * NW + wave) * 64 + lane;
+    const int row = pslot / SPR, ps = pslot % SPR;
+    const int kslot = ps ^ ((row >> 2) & 3);
+    int gm = m0 + row;
+    if (gm > p.M - 1) gm = p.M - 1;
+    a_src[j] = p.A + (size_t)gm * p.lda + kslot * 8;
+    a_yx[j] = 0;
+    if (AMODE == 1) {
+      const int hw = p.H * p.Wd;
+      const int b = gm / hw, rem = gm - b * hw;
+      const int y = rem / p.Wd;
+      a_yx[j] = (y << 16) | (rem - y * p.Wd);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int pslot = (j * NW + wave) * 64 + lane;
+    const int row = pslot / SPR, ps = pslot % SPR;
+    const int kslot = ps ^ ((row >> 2) & 3);
+    int gn = n0 + row;
+    if (gn > p.N - 1) gn = p.N - 1;
+    b_src[j] = p.W + (size_t)gn * p.ldw + kslot * 8;
+  }
+  struct TileSrc { long a_off; int k0, dy, dx; };
+  auto tile_src = [&](int t) {
+    TileSrc ts;
+    ts.k0 = t * BKT;
+    ts.a_off = ts.k0;
+    ts.dy = ts.dx = 0;
+    if (AMODE == 1) {
+      const int per_tap = p.Cin / BKT;
+      const int tap_lin = t / per_tap;
+      const int c0 = (t - tap_lin * per_tap) * BKT;
+      const int g = tap_lin / 9, tap = tap_lin - g * 9;
+      ts.dy = tap / 3 - 1;
+      ts.dx = tap - (tap / 3) * 3 - 1;
+      ts.a_off = (long)g * p.a_group_stride + ((long)ts.dy * p.Wd + ts.dx) * p.lda + c0;
+    }
+    return ts;
+  };
+  // piece j (0-3: rows of A, 4-7: rows of W; 1 KiB each) of K tile `ts` into ring slot `buf`
+  auto piece = [&](int j, const TileSrc& ts, int buf) {
+    char* sa = smem + buf * STAGE_BYTES;
+    if (j < NA) {
+      const bf16_t* src = a_src[j] + ts.a_off;
+      if (AMODE == 1) {
+        const int yy = (a_yx[j] >> 16) + ts.dy, xx = (a_yx[j] & 0xffff) + ts.dx;
+        if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.Wd) src = p.zeros + (lane & 3) * 8;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sa + (j * NW + wave) * 1024), 16, 0, 0);
+    } else {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[j - NA] + ts.k0),
+                                       (__attribute__((address_space(3))) void*)(sa + A_BYTES + ((j - NA) * NW + wave) * 1024), 16, 0, 0);
+    }
+  };
+  float16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frow = lane & 31, fsw = (frow >> 2) & 3, fhi = lane >> 5;
+  const int a_row_off = (wm * 128 + frow) * ROWB;
+  const int b_row_off = (wn * 128 + frow) * ROWB;
+  const int slot_k0 = ((0 * 2 + fhi) ^ fsw) << 4, slot_k1 = ((1 * 2 + fhi) ^ fsw) << 4;
+  bf16x8 af0[TM], wf0[TN], af1[TM], wf1[TN];
+
+  auto ldfrag = [&](bf16x8 (&AF)[TM], bf16x8 (&WF)[TN], int buf, int slot) {
+    const char* sa = smem + buf * STAGE_BYTES;
+    const char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) AF[i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + slot);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) WF[j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
+  };
+  auto mma_row = [&](bf16x8 (&AF)[TM], bf16x8 (&WF)[TN], auto irow) {
+    constexpr int i = decltype(irow)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[j], AF[i], acc[i][j], 0, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  const int nt = t_end - t_begin;
+  if (nt > 0) {
+    // prologue: tiles 0-2 completely, the first half of tile 3 (its second half is iteration 0's share)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      if (t < nt) {
+        const TileSrc ts = tile_src(t_begin + t);
+#pragma unroll
+        for (int j = 0; j < NA + NB; ++j) piece(j, ts, t);
+      }
+    if (3 < nt) {
+      const TileSrc ts = tile_src(t_begin + 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) piece(j, ts, 3);
+    }
+    if (nt > 3) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (nt > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ldfrag(af0, wf0, 0, slot_k0);
+    // sched_group_barrier masks (LLVM SchedGroupMask): 0x8 MFMA, 0x10 VMEM, 0x100 DS read
+    auto body = [&](int i, auto steady_tag) {
+      constexpr bool STEADY = decltype(steady_tag)::value;   // tiles i+1 .. i+4 all exist: no branches in the body
+      const int buf = i & (RING - 1);
+      // ---- k-step 0: 16 MFMA on F0 | F1 <- (buf, k1) one read per MFMA | pieces 4-7 of tile i+3 every 2nd MFMA ----
+      ldfrag(af1, wf1, buf, slot_k1);
+      if (STEADY || i + 3 < nt) {
+        const TileSrc ts = tile_src(t_begin + i + 3);
+#pragma unroll
+        for (int j = 4; j < 8; ++j) piece(j, ts, (i + 3) & (RING - 1));
+      }
+      mma_row(af0, wf0, I0{}); mma_row(af0, wf0, I1{}); mma_row(af0, wf0, I2{}); mma_row(af0, wf0, I3{});
+      if (STEADY) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- k-step 1, first row: the pipe stays busy while the waves meet at the barrier ----
+      mma_row(af1, wf1, I0{});
+      // every fragment of buf i is in registers (the MFMAs above needed af1[0] and all of wf1; the explicit wait
+      // covers af1[1..3]); tile i+1 must have landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (STEADY || i + 3 < nt) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (i + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- k-step 1, rows 1-3: 12 MFMA | F0 <- (buf i+1, k0) | pieces 0-3 of tile i+4 into the slot tile i left ----
+      if (STEADY || i + 1 < nt) ldfrag(af0, wf0, (i + 1) & (RING - 1), slot_k0);
+      if (STEADY || i + 4 < nt) {
+        const TileSrc ts = tile_src(t_begin + i + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) piece(j, ts, buf);
+      }
+      mma_row(af1, wf1, I1{}); mma_row(af1, wf1, I2{}); mma_row(af1, wf1, I3{});
+      if (STEADY) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 1);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 1);
+          __builtin_amdgcn_sched_group_barrier(0x10, 1, 1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int i = 0;
+    for (; i + 4 < nt; ++i) body(i, std::true_type{});
+    for (; i < nt; ++i) body(i, std::false_type{});
+  }
+  const int em = lane & 31, en = 4 * (lane >> 5);
+  gemm_epilogue<TM, TN, 0, 2>(p, acc, m0 + wm * 128 + em, n0 + wn * 128 + en, split);
+  gemm_epilogue<TM, TN, 2, 2>(p, acc, m0 + wm * 128 + em, n0 + wn * 128 + en, split);
+}
+
+template <int AMODE>
+int launch_w4(GemmArgs& p, hipStream_t stream) {
+  {
+    const int nt = p.K / 32;
+    int splits = p.splits < 1 ? 1 : p.splits;
+    if (splits > nt) splits = nt;
+    p.tiles_per_split = g4r_ceil_div(nt, splits);
+    p.splits = g4r_ceil_div(nt, p.tiles_per_split);
+  }
+  p.tiles_m = g4r_ceil_div(p.M, 256);
+  p.tiles_n = g4r_ceil_div(p.N, 256);
+  const size_t lds = 4 * (256 + 256) * 32 * 2;
+  auto kern = gemm_bf16_w4_kernel<AMODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_w4: hipFuncSetAttribute");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(256), lds, stream, p);
+  G4R_CHECK_LAUNCH("gemm_bf16_w4");
+  if (p.splits > 1) {
+    long total = (long)p.M * p.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    G4R_CHECK_LAUNCH("splitk_reduce");
+  }
+  return G4R_OK;
+}
+
 template <int AMODE, bool PROBE = false>
 int launch_pp32(GemmArgs& p, hipStream_t stream) {
   {
@@ -1112,7 +1371,14 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 9: return launch_tile<256, 256, 2, 4, AMODE, true, 2>(p, stream);   // 128 KB, wave tile 128x64
     case 10: return launch_tile<128, 128, 2, 4, AMODE, true, 2>(p, stream);  // 8 waves x (64x32), 2 wg/CU
     case 11: return launch_tile<128, 64, 2, 2, AMODE, true, 2>(p, stream);   // 48 KB: 3 wg/CU
-    // (12-21 were the BK = 32 / interleaved-read ring experiments of DESIGN.md section 3; they lost and were removed)
+    // (12-21 of round 1 were the BK = 32 / interleaved-read ring experiments of DESIGN.md section 3; they lost and
+    // were removed.)  Small-M shapes (CLIP ViT, M = 577; K = 1024 is only 16 K tiles): fewer workgroups than CUs, so
+    // what matters is ONE workgroup's latency -> deep LDS-DMA rings instead of co-resident workgroups.
+    case 12: return launch_tile<64, 128, 1, 4, AMODE, true, 4>(p, stream);   // 96 KB ring of 4
+    case 13: return launch_tile<64, 128, 1, 4, AMODE, true, 3>(p, stream);   // 72 KB ring of 3: 2 wg/CU
+    case 14: return launch_tile<64, 64, 2, 2, AMODE, true, 4>(p, stream);    // 64 KB ring of 4: 2 wg/CU
+    case 15: return launch_tile<128, 64, 2, 2, AMODE, true, 4>(p, stream);   // 96 KB ring of 4
+    case 26: return launch_w4<AMODE>(p, stream);                                 // 256x256, 4 waves x (128x128): one wave per SIMD, K 32 ring of 4
     case 22: return launch_pp<AMODE>(p, stream);                                 // 256x256 ping-pong (4 barriers / K tile)
     case 24: return launch_pp32<AMODE>(p, stream);                               // 256x256 ping-pong, K 32 ring of 4
     case 25: return launch_pp32<AMODE, true>(p, stream);                         // same + s_memtime stamps (tools only)
