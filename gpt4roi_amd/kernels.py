@@ -50,6 +50,7 @@ _SIGS = {
     "g4r_vit_assemble_bf16": [P, P, P, P, c_int, c_int, c_int, P],
     "g4r_rope_qkv_bf16": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P],
     "g4r_greedy_advance_f32": [P, c_int, P, P, P, P, c_int, P],
+    "g4r_sample_advance_f32": [P, c_int, c_float, c_int, c_float, P, P, P, P, P, c_int, P, P],
     "g4r_swiglu_bf16": [P, P, c_int, c_int, P],
     "g4r_splice_embed_bf16": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_long, c_long, c_long,
                               c_long, c_int, P],
@@ -174,6 +175,13 @@ def pick_tile(M, N, K=0):
     t128 = -(-M // 128) * -(-N // 128)
     if t128 >= 192:
         return 7 if (K >= 4096 and t128 < 512) else 0     # o_proj 767x4096x4096: 47.8 us vs 63.8 (tools/proj_tiles.py)
+    # Small M (CLIP ViT at batch 1, M = 577): fewer workgroups than CUs and only 16-64 K tiles, so ONE workgroup's
+    # latency is the time -> deep LDS-DMA rings (tools/gemm_bench.cpp on MI355X, profiles/r02_gemm_tiles.md):
+    # 577x3072x1024 15.1 us on 64x64 ring-4 vs 22.1 on the two-stage 64x128; 577x1024x1024 12.3 vs 20.5;
+    # 577x4096x1024 18.1 on 64x128 ring-3 vs 21.2.
+    if K % 64 == 0 and K >= 512 and M > 64:
+        t64 = -(-M // 64) * -(-N // 64)
+        return 14 if t64 <= 512 else 13
     return 4
 
 
@@ -240,10 +248,12 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
     if tile_cfg is None:
         tile_cfg = pick_tile(M, N, K)
         if splits == 1 and tile_cfg == 4 and K >= 2048 and K % 64 == 0 and M > 1:
-            # few tiles and a long K: split K so the grid covers the 256 CUs (e.g. ViT fc2 577x1024x4096)
+            # few tiles and a long K: split K so the grid covers the 256 CUs
             tiles = -(-M // 64) * -(-N // 128)
             if tiles < 160:
                 splits = max(1, min(4, 256 // tiles, K // 1024))
+        if splits == 1 and tile_cfg == 14 and K >= 4096 and -(-M // 64) * -(-N // 64) <= 256:
+            splits = 2                 # ViT fc2 577x1024x4096: 24.2 us vs 27.1 unsplit (29.4 before: 64x128 x 3 splits)
     if splits > 1 and workspace is None:
         workspace = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
     _launch("g4r_gemm_bf16_nt", (
@@ -448,6 +458,18 @@ def greedy_advance(logits_row, tok, out_ids, step, pos):
     assert tok.dtype == torch.int64 and out_ids.dtype == torch.int64 and step.dtype == torch.int32 and pos.dtype == torch.int32
     _launch("g4r_greedy_advance_f32", (_p(logits_row), logits_row.numel(), _p(tok), _p(out_ids), _p(step), _p(pos),
                                        out_ids.numel(), _stream(logits_row),))
+
+
+def sample_advance(logits_row, tok, out_ids, step, pos, seed, temperature=1.0, top_k=50, top_p=1.0, u_out=None):
+    """One sampling step on the device (include/g4r_kernels.h: g4r_sample_advance_f32): tok[0] ~ softmax of the
+    temperature / top-k / top-p warped logits, drawn with the Philox uniform of (*step, *seed); counters advance."""
+    _f32(logits_row, u_out)
+    _lib.require_gpu(tok, out_ids, step, pos, seed)
+    assert tok.dtype == torch.int64 and out_ids.dtype == torch.int64 and step.dtype == torch.int32
+    assert pos.dtype == torch.int32 and seed.dtype == torch.int64 and seed.numel() == 1
+    _launch("g4r_sample_advance_f32", (_p(logits_row), logits_row.numel(), float(temperature), int(top_k or 0),
+                                       float(top_p), _p(seed), _p(tok), _p(out_ids), _p(step), _p(pos),
+                                       out_ids.numel(), _p(u_out), _stream(logits_row),))
 
 
 def argmax_rows(logits):

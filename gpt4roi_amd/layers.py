@@ -156,9 +156,10 @@ class MLVLFuseModule(nn.Module):
             all_affs.append(new_affs)
         return all_maps[-1], all_affs[-1], dict(xs=xs, maps=all_maps, affs=all_affs, B=B)
 
-    def backward(self, ctx, d_y):
+    def backward(self, ctx, d_y, on_grad=None):
         """d_y: list[num_levels] of fp32 NHWC gradients w.r.t. the POST GN+ReLU maps of the last round.
-        Returns {state_dict key: fp32 gradient in the reference layout}.  (No input gradient: the ViT is frozen.)"""
+        Returns {state_dict key: fp32 gradient in the reference layout}.  (No input gradient: the ViT is frozen.)
+        `on_grad(key, grad)` fires as each round's gradients are complete (last round first)."""
         r = self._ready
         C, B = self.embed_dims, ctx['B']
         dev = d_y[0].device
@@ -184,6 +185,9 @@ class MLVLFuseModule(nn.Module):
             grads[f'fuse_convs.{rnd}.conv.weight'] = dW
             grads[f'fuse_convs.{rnd}.gn.weight'] = dgamma
             grads[f'fuse_convs.{rnd}.gn.bias'] = dbeta
+            if on_grad is not None:
+                for k in (f'fuse_convs.{rnd}.gn.bias', f'fuse_convs.{rnd}.gn.weight', f'fuse_convs.{rnd}.conv.weight'):
+                    on_grad(k, grads[k])
             # transpose of the channel shuffle + resampling, gathered per source level (fuse_lvl_list is
             # (l, min(l+1, L-1), max(l-1, 0)) as in layers.py:108-112)
             d_y = [K.fuse_shuffle_bwd_gather(l, dinps) for l in range(self.num_levels)]
@@ -194,6 +198,10 @@ class MLVLFuseModule(nn.Module):
             dw = K.linear_wgrad(dm, x.view(-1, self.cpad))
             grads[f'input_conv.{lvl}.weight'] = dw[:, :cin].reshape(C, cin, 1, 1).contiguous()
             grads[f'input_conv.{lvl}.bias'] = K.colsum(dm)
+        if on_grad is not None:
+            for lvl in range(self.num_levels - 1, -1, -1):
+                on_grad(f'input_conv.{lvl}.bias', grads[f'input_conv.{lvl}.bias'])
+                on_grad(f'input_conv.{lvl}.weight', grads[f'input_conv.{lvl}.weight'])
         return grads
 
 
@@ -405,6 +413,7 @@ class MLVLROIQueryModule(nn.Module):
     def prepare(self):
         self.mlvl_fuse.prepare()
         self.roi_align.prepare()
+        self._stamp = self._param_stamp()
 
     def _tokens(self, mlvl_feats):
         toks = []
@@ -430,23 +439,67 @@ class MLVLROIQueryModule(nn.Module):
         return out, dict(fuse=fctx, roi=rctx)
 
     @torch.no_grad()
-    def backward(self, ctx, d_out):
+    def backward(self, ctx, d_out, on_grad=None):
         """d_out bf16 [N, out_dims] (rows in the order of cat(bboxes)) -> {state_dict key: fp32 gradient in the
         reference layout} for every parameter of the module (the gradients autograd gives the reference through
-        gpt4roi/models/layers.py:218-236)."""
+        gpt4roi/models/layers.py:218-236).  `on_grad(key, grad)` fires as gradients complete, in the reverse of the
+        module's parameter registration order (roi_align.* first, then the fuse rounds from the last to the first)."""
         g_roi, d_maps = self.roi_align.backward(ctx['roi'], d_out)
-        g_fuse = self.mlvl_fuse.backward(ctx['fuse'], d_maps)
         grads = {f'roi_align.{k}': v for k, v in g_roi.items()}
+        if on_grad is not None:
+            for k in reversed([n for n, _ in self.roi_align.named_parameters()]):
+                on_grad(f'roi_align.{k}', grads[f'roi_align.{k}'])
+        cb = (lambda k, g: on_grad(f'mlvl_fuse.{k}', g)) if on_grad is not None else None
+        g_fuse = self.mlvl_fuse.backward(ctx['fuse'], d_maps, on_grad=cb)
         grads.update({f'mlvl_fuse.{k}': v for k, v in g_fuse.items()})
         return grads
 
-    @torch.no_grad()
+    def _param_stamp(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _maybe_prepare(self):
+        """Re-derive the kernel-ready bf16 buffers when a parameter was written since the last prepare() (an
+        optimizer step, load_state_dict, .to()): tensors carry a version counter that every in-place write bumps."""
+        if self.mlvl_fuse._ready is None or self.roi_align._ready is None or \
+                getattr(self, '_stamp', None) != self._param_stamp():
+            self.prepare()
+            self._stamp = self._param_stamp()
+
     def forward(self, mlvl_feats, bboxes):
         """mlvl_feats: list[4] of [B, P*P, C] (token form, as spi_llava.py:80-82 passes) or
         [B, C, P, P]; bboxes: list[B] of [n_i, 4] normalised xyxy.  Returns list[B] of
-        [n_i, out_dims] bf16."""
-        toks, P, sizes = self._tokens(mlvl_feats)
-        maps, affs = self.mlvl_fuse(toks, P, sizes)
-        if isinstance(bboxes, PreparedBoxes):
-            assert bboxes.image_size == 14 * P, "PreparedBoxes built for another image size"
-        return self.roi_align(maps, bboxes, affines=affs, image_size=14 * P)
+        [n_i, out_dims] bf16.  With grad enabled and trainable parameters the result carries an autograd node whose
+        backward is the hand-written `backward` above (gradients for the module's parameters; the ViT features are
+        treated as constants, as the reference computes them under no_grad, spi_llava.py:50-82)."""
+        self._maybe_prepare()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            n_total = bboxes.n if isinstance(bboxes, PreparedBoxes) else sum(int(b.size(0)) for b in bboxes)
+            if n_total > 0:
+                named = [(k, p) for k, p in self.named_parameters() if p.requires_grad]
+                out = _RegionModuleFn.apply(self, mlvl_feats, bboxes, tuple(k for k, _ in named), *[p for _, p in named])
+                counts = bboxes.counts if isinstance(bboxes, PreparedBoxes) else [int(b.size(0)) for b in bboxes]
+                return list(torch.split(out, counts, 0))
+        with torch.no_grad():
+            toks, P, sizes = self._tokens(mlvl_feats)
+            maps, affs = self.mlvl_fuse(toks, P, sizes)
+            if isinstance(bboxes, PreparedBoxes):
+                assert bboxes.image_size == 14 * P, "PreparedBoxes built for another image size"
+            return self.roi_align(maps, bboxes, affines=affs, image_size=14 * P)
+
+
+class _RegionModuleFn(torch.autograd.Function):
+    """B2 seam under autograd: out = MLVLROIQueryModule(mlvl_feats, bboxes; parameters)."""
+
+    @staticmethod
+    def forward(ctx, module, mlvl_feats, bboxes, names, *params):
+        with torch.no_grad():
+            out, sctx = module.forward_train(mlvl_feats, bboxes)
+        ctx.module, ctx.sctx, ctx.names = module, sctx, names
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        with torch.no_grad():
+            grads = ctx.module.backward(ctx.sctx, d_out.to(torch.bfloat16).contiguous())
+        ctx.sctx = None
+        return (None, None, None, None) + tuple(grads[n] for n in ctx.names)

@@ -26,7 +26,7 @@ class LlamaDecoder:
 
         self.embed = g("model.embed_tokens.weight")
         self.vocab, self.hidden = self.embed.shape
-        self.heads, self.eps = heads, eps
+        self.heads, self.eps, self.theta = heads, eps, theta
         self.head_dim = self.hidden // heads
         if num_layers is None:
             num_layers = sum(1 for k in sd if k.endswith("input_layernorm.weight"))
@@ -49,6 +49,7 @@ class LlamaDecoder:
         self.cos, self.sin = ang.cos().to(device).contiguous(), ang.sin().to(device).contiguous()
         self.max_positions = max_positions
         self.device = device
+        self.train_weights = False
         self._alloc_cache(max_batch)
 
     def _alloc_cache(self, batch):
@@ -113,10 +114,14 @@ class LlamaDecoder:
     def trainable_tensors(self):
         """name -> tensor the kernels read, for stage-2 training (kernel layouts: fused q|k|v rows, interleaved
         gate/up rows; norm weights are fp32 already)."""
-        out = {"embed_tokens": self.embed, "norm": self.norm, "lm_head": self.lm_head}
+        # registration order = REVERSE of the order `backward` produces the gradients (lm_head, norm, last layer ...
+        # first layer, embedding rows), because the bucketed exchange fills its buckets from the end of this list
+        out = {"embed_tokens": self.embed}
         for i, L in enumerate(self.layers):
             for nm in ("wqkv", "wo", "wgu", "wd", "n1", "n2"):
                 out[f"{i}.{nm}"] = L[nm]
+        out["norm"] = self.norm
+        out["lm_head"] = self.lm_head
         return out
 
     def export_hf_state_dict(self):
@@ -133,55 +138,74 @@ class LlamaDecoder:
             sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = L['n1'], L['n2']
         return {k: v.detach().clone() for k, v in sd.items()}
 
-    def forward_train(self, inputs_embeds):
+    def _layer_forward_train(self, li, x, B, T):
+        """One decoder layer of `forward_train`: x [B*T, C] -> (x_out, everything its backward reads)."""
+        L = self.layers[li]
+        C, H, D = self.hidden, self.heads, self.head_dim
+        h = K.rmsnorm(x, L['n1'], self.eps)
+        qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
+        q = torch.empty((B, T, C), dtype=torch.bfloat16, device=x.device)
+        for b in range(B):
+            K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, 0)
+        lse = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
+        a = K.flash_attn(q, self.kc[li, :B, :T], self.vc[li, :B, :T], H, 1.0 / math.sqrt(D), True, lse=lse)
+        x1 = K.gemm(a.view(B * T, C), L['wo'], residual=x)
+        h2 = K.rmsnorm(x1, L['n2'], self.eps)
+        gu = K.gemm(h2, L['wgu'])
+        f = K.swiglu_il(gu)
+        x2 = K.gemm(f, L['wd'], residual=x1)
+        rec = dict(x=x, q=q, a=a, lse=lse, x1=x1, gu=gu)
+        if self.train_weights:
+            rec.update(h=h, h2=h2, f=f)
+        return x2, rec
+
+    def forward_train(self, inputs_embeds, checkpoint=False):
         """inputs_embeds [B,T,C] bf16 at positions 0..T-1 -> (logits fp32 [B*T, V], ctx).  Same kernels as
         `forward` except that the gate|up GEMM keeps its pre-activation output for the SwiGLU backward and
-        the attention kernel also returns the log-sum-exp."""
+        the attention kernel also returns the log-sum-exp.
+        checkpoint=True (`--gradient_checkpointing True`, train_stage1.sh:36; torch.utils.checkpoint per decoder layer in
+        HF): only each layer's INPUT is kept (2 B x C per token per layer instead of ~(6 C + 3 F) x 2 B) and `backward`
+        re-runs the layer forward before differentiating it -- one extra forward of the decoder per step, which is what
+        lets config 4's B = 16 x T = 767 tokens per GPU train inside 288 GB next to the 7 B replica and its Adam state."""
         B, T, C = inputs_embeds.shape
         assert T <= self.max_positions and B <= self.kc.size(1)
-        H, D = self.heads, self.head_dim
         x = inputs_embeds.reshape(B * T, C).contiguous()
-        scale = 1.0 / math.sqrt(D)
         saved = []
-        for li, L in enumerate(self.layers):
-            h = K.rmsnorm(x, L['n1'], self.eps)
-            qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
-            q = torch.empty((B, T, C), dtype=torch.bfloat16, device=x.device)
-            for b in range(B):
-                K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, 0)
-            lse = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
-            a = K.flash_attn(q, self.kc[li, :B, :T], self.vc[li, :B, :T], H, scale, True, lse=lse)
-            x1 = K.gemm(a.view(B * T, C), L['wo'], residual=x)
-            h2 = K.rmsnorm(x1, L['n2'], self.eps)
-            gu = K.gemm(h2, L['wgu'])
-            f = K.swiglu_il(gu)
-            x2 = K.gemm(f, L['wd'], residual=x1)
-            rec = dict(x=x, q=q, a=a, lse=lse, x1=x1, gu=gu)
-            if self.train_weights:
-                rec.update(h=h, h2=h2, f=f)
-            saved.append(rec)
+        for li in range(len(self.layers)):
+            x2, rec = self._layer_forward_train(li, x, B, T)
+            saved.append(dict(x=x) if checkpoint else rec)
             x = x2
         xn = K.rmsnorm(x, self.norm, self.eps)
         logits = K.gemm(xn, self.lm_head, out_dtype=torch.float32)
         self.pos = T
-        return logits, dict(B=B, T=T, saved=saved, x_final=x, xn=xn)
+        return logits, dict(B=B, T=T, saved=saved, x_final=x, xn=xn, checkpoint=checkpoint)
 
-    def backward(self, ctx, dlogits):
+    def backward(self, ctx, dlogits, on_grad=None):
         """dlogits bf16 [B*T, v_pad] (zero in the pad columns) -> d(inputs_embeds) [B*T, C] bf16.
         With `train_weights`, self.grads[name] receives the fp32 weight gradients (layer weights in the
-        kernel layout: fused qkv, interleaved gate|up)."""
+        kernel layout: fused qkv, interleaved gate|up); `on_grad(name, grad)` is called as soon as a layer's gradients
+        exist (last layer first), so a bucketed exchange can start while the earlier layers are still differentiating."""
         B, T = ctx["B"], ctx["T"]
         C, H, D = self.hidden, self.heads, self.head_dim
         scale = 1.0 / math.sqrt(D)
         tw = self.train_weights
         grads = {}
+
+        def emit(*names):
+            if on_grad is not None:
+                for n in names:
+                    on_grad(n, grads[n])
         if tw:
             grads["lm_head"] = K.linear_wgrad(dlogits[:, :self.vocab], ctx["xn"])
             grads["norm"] = torch.zeros_like(self.norm)
         dxn = K.gemm(dlogits, self.lm_head_t)
         dx = K.rmsnorm_bwd(ctx["x_final"], self.norm, dxn, dgamma=grads.get("norm"), eps=self.eps)
+        if tw:
+            emit("lm_head", "norm")
         for li in range(len(self.layers) - 1, -1, -1):
             L, S = self.layers[li], ctx["saved"][li]
+            if ctx.get("checkpoint"):
+                _, S = self._layer_forward_train(li, S['x'], B, T)        # recompute (also re-fills this layer's K/V)
             df = K.gemm(dx, L['wd_t'])
             dgu = K.swiglu_il_bwd(S['gu'], df)
             dh2 = K.gemm(dgu, L['wgu_t'])
@@ -201,6 +225,8 @@ class LlamaDecoder:
                 grads[f"{li}.wo"] = K.linear_wgrad(dx1, S['a'].view(B * T, C))
                 grads[f"{li}.wqkv"] = K.linear_wgrad(dqkv, S['h'])
             dx = K.rmsnorm_bwd(S['x'], L['n1'], dh, dres=dx1, dgamma=grads.get(f"{li}.n1"), eps=self.eps)
+            if tw:
+                emit(f"{li}.n2", f"{li}.n1", f"{li}.wd", f"{li}.wgu", f"{li}.wo", f"{li}.wqkv")
         self.grads = grads
         return dx
 
@@ -218,21 +244,33 @@ class LlamaDecoder:
         K.cross_entropy(logits, lab, loss_sum, gs, dlogits, self.v_pad)
         return loss_sum * gs, dlogits
 
-    # ---- device-resident greedy decode, one hipGraph replay per token ----------------------------
+    # ---- device-resident decode (greedy or sampled), one hipGraph replay per token ---------------
     def _decode_state(self, max_new):
         st = getattr(self, "_dstate", None)
         if st is None or st["out"].numel() < max_new:
             dev = self.device
+            n = max(max_new, 64)
             st = dict(tok=torch.zeros((1, 1), dtype=torch.int64, device=dev),
                       pos=torch.zeros(1, dtype=torch.int32, device=dev),
                       step=torch.zeros(1, dtype=torch.int32, device=dev),
-                      out=torch.zeros(max(max_new, 64), dtype=torch.int64, device=dev), graph=None)
+                      seed=torch.zeros(1, dtype=torch.int64, device=dev),
+                      u=torch.zeros(n, dtype=torch.float32, device=dev),
+                      out=torch.zeros(n, dtype=torch.int64, device=dev), graphs={})
             self._dstate = st
         return st
 
-    def _decode_step_device(self, st):
+    def _advance(self, logits_row, st, sampler):
+        """Token selection on the device: argmax (generate(do_sample=False)) or one temperature / top-k / top-p draw
+        (do_sample=True, app.py:293-300); sampler = (temperature, top_k, top_p)."""
+        if sampler is None:
+            K.greedy_advance(logits_row, st["tok"], st["out"], st["step"], st["pos"])
+        else:
+            K.sample_advance(logits_row, st["tok"], st["out"], st["step"], st["pos"], st["seed"], sampler[0], sampler[1],
+                             sampler[2], u_out=st["u"])
+
+    def _decode_step_device(self, st, sampler=None):
         """One token: embedding of st['tok'] at position st['pos'] -> 32 layers (K/V appended at *pos,
-        attention over *pos + 1 keys) -> logits -> argmax -> st['tok'], st['out'][step]; counters
+        attention over *pos + 1 keys) -> logits -> token selection -> st['tok'], st['out'][step]; counters
         advance on the device.  No host value enters the launch sequence."""
         C, H, D = self.hidden, self.heads, self.head_dim
         x, _ = K.splice_embed(st["tok"], self.embed, None, None, None, 0, -1, -1, -1, -1)
@@ -250,13 +288,16 @@ class LlamaDecoder:
             x = K.gemm(f, L['wd'], residual=x)
         xn = K.rmsnorm(x, self.norm, self.eps)
         logits = K.gemm(xn, self.lm_head, out_dtype=torch.float32)
-        K.greedy_advance(logits.view(-1), st["tok"], st["out"], st["step"], st["pos"])
+        self._advance(logits.view(-1), st, sampler)
 
     @torch.no_grad()
-    def greedy_graph(self, inputs_embeds, max_new_tokens, stop_ids=(), check_every=32, use_graph=True):
-        """generate(do_sample=False) for batch 1 with the per-token loop on the device: prefill eagerly,
-        then replay one captured hipGraph per token (token id, position and output slot live in device
-        memory).  The host only looks at the ids every `check_every` tokens to honour `stop_ids`."""
+    def decode_graph(self, inputs_embeds, max_new_tokens, stop_ids=(), check_every=32, use_graph=True, sampler=None,
+                     seed=0, on_tokens=None):
+        """generate() for batch 1 with the per-token loop on the device: prefill eagerly, then replay one captured
+        hipGraph per token (token id, position, output slot, sampling seed and step live in device memory).
+        sampler = None (greedy) or (temperature, top_k, top_p); the uniform of step s is Philox(seed, s).
+        The host looks at the ids every `check_every` tokens: `stop_ids` ends the sequence at the first hit
+        (inclusive); `on_tokens(list of new ids) -> bool` is the hook for HF-style stopping criteria."""
         assert inputs_embeds.size(0) == 1
         self.reset(1)
         logits = self.forward(inputs_embeds, all_logits=False)
@@ -265,34 +306,52 @@ class LlamaDecoder:
         st = self._decode_state(max_new_tokens)
         st["pos"].fill_(T - 1)
         st["step"].zero_()
-        K.greedy_advance(logits.view(-1), st["tok"], st["out"], st["step"], st["pos"])   # token 1, pos -> T
+        st["seed"].fill_(int(seed))
+        self._advance(logits.view(-1), st, sampler)                                       # token 1, pos -> T
         done = 1
-        if max_new_tokens > 1:
-            self._decode_step_device(st)                                                # token 2 (also warms up)
+        key = None if sampler is None else tuple(float(x) for x in sampler)
+        graph = st["graphs"].get(key) if use_graph else None
+
+        def finished(n):
+            ids = st["out"][:n].tolist()
+            hit = [i for i, t in enumerate(ids) if t in stop_ids]
+            if hit:
+                return hit[0] + 1
+            if on_tokens is not None:
+                for m in range(1, n + 1):          # criteria see the sequence token by token, like HF's loop
+                    if on_tokens(ids[:m]):
+                        return m
+            return None
+
+        end = finished(done) if (stop_ids or on_tokens) else None
+        if end is None and max_new_tokens > 1:
+            self._decode_step_device(st, sampler)                                           # token 2 (also warms up)
             done = 2
-        if use_graph and st["graph"] is None and max_new_tokens > 2:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            with torch.cuda.graph(g, stream=side):
-                self._decode_step_device(st)
-            st["graph"] = g
-        while done < max_new_tokens:
+            if use_graph and graph is None and max_new_tokens > 2:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()      # capture records the launches, it does not run them
+                side = torch.cuda.Stream()
+                with torch.cuda.graph(g, stream=side):
+                    self._decode_step_device(st, sampler)
+                st["graphs"][key] = graph = g
+        while end is None and done < max_new_tokens:
             n = min(check_every, max_new_tokens - done)
             for _ in range(n):
-                if use_graph and st["graph"] is not None:
-                    st["graph"].replay()
+                if graph is not None:
+                    graph.replay()
                 else:
-                    self._decode_step_device(st)
+                    self._decode_step_device(st, sampler)
             done += n
-            if stop_ids:
-                ids = st["out"][:done].tolist()
-                hit = [i for i, t in enumerate(ids) if t in stop_ids]
-                if hit:
-                    done = hit[0] + 1
-                    break
+            if stop_ids or on_tokens:
+                end = finished(done)
+        if end is not None:
+            done = end
         self.pos = T + done
         return st["out"][:done].tolist()
+
+    def greedy_graph(self, inputs_embeds, max_new_tokens, stop_ids=(), check_every=32, use_graph=True):
+        """generate(do_sample=False): decode_graph without a sampler."""
+        return self.decode_graph(inputs_embeds, max_new_tokens, stop_ids, check_every, use_graph)
 
     @torch.no_grad()
     def greedy_batch(self, inputs_embeds, max_new_tokens, stop_ids=()):

@@ -1,9 +1,12 @@
 """MI355X drop-in for `gpt4roi.models.spi_llava` (the model-level seam B3 of SURVEY.md 8b).
 
-Mirrors /root/reference/gpt4roi/models/spi_llava.py:
+Mirrors /root/reference/gpt4roi/models/spi_llava.py and the parts of llava/model/llava.py its callers touch:
   SPILlavaLlamaModel.forward(input_ids, attention_mask, img_metas, bboxes, past_key_values,
       inputs_embeds, use_cache, output_attentions, output_hidden_states, images, return_dict)  (:23-36)
   SPILlavaMPTForCausalLM.forward(*args, img_metas=None, bboxes=None, **kwargs)                (:226-240)
+  SPILlavaMPTForCausalLM.initialize_vision_tokenizer(...)                                     (:242-306)
+  LlavaLlamaModel.initialize_vision_modules(...)                                              (llava.py:54-86)
+  LlavaLlamaForCausalLM.prepare_inputs_for_generation / loss                                  (llava.py:235-283)
 with the same control flow -- the vision branch runs only when `images` is given and the call is
 not a single-token decode step (:47-48); `image_features = hs[-2][:,1:]`, levels
 `hs[-2::-3][::-1][-4:]` (:58-82); `spi_module(mlvl, bboxes)` (:83-85); `mm_projector` (:89-97);
@@ -11,20 +14,32 @@ patch splice + `<bbox>` injection (:99-196); decoder + lm_head (:198-205, llava.
 but every stage is a hand-written gfx950 kernel sequence (gpt4roi_amd/{vit,layers,llama}.py) and the
 per-sample host splice loop is ONE gather kernel (g4r_splice_embed_bf16).
 
-What is intentionally not reproduced: HF PreTrainedModel plumbing (from_pretrained, generate's
-sampling modes -- `generate()` here is the greedy path used for parity), the dummy projector
-call the reference makes for text-only samples (:94-97, a zero contribution).  `forward(labels=...)`
-returns the shifted-label loss; the training STEP (backward, exchange, AdamW) is gpt4roi_amd/train.py.
+How the reference's callers run unchanged against it:
+  * training (gpt4roi/train/train.py:698-712, HF Trainer.training_step): `model(**batch)` with grad enabled returns a
+    loss / logits that carry an autograd node; `loss.backward()` runs the hand-written backward of every stage
+    (LlamaDecoder.backward, MLVLROIQueryModule.backward) and fills `.grad` of the reference-keyed nn.Parameters
+    (`model.spi_module.*`, `model.mm_projector.*`: the stage-1 trainables, train.py:685-696); any torch optimizer then
+    steps them and the bf16 kernel copies are refreshed lazily on the next forward (parameter version stamps).
+    `gradient_checkpointing_enable()` (train_stage1.sh:36) recomputes each decoder layer in the backward.
+  * serving (gpt4roi/app.py:286-300): `model.forward = partial(model.orig_forward, img_metas=[None], bboxes=bboxes)`
+    followed by `model.generate(input_ids, images=..., do_sample=True, temperature=0.2, max_new_tokens=1024,
+    stopping_criteria=[KeywordsStoppingCriteria(...)])` -- generate() drives `self.forward` (so the bound boxes are
+    seen), samples on the device (g4r_sample_advance_f32) and returns the full id tensor [1, T + new] like HF.
+Not reproduced: the dummy projector call the reference makes for text-only samples (:94-97, a zero contribution), beam
+search and the other HF generation modes the callers never use.  Stage-2 (decoder weights trainable) goes through
+gpt4roi_amd/train.py::FullTrainer, whose masters are plain tensors in kernel layout.
 """
 import itertools
 from dataclasses import dataclass
 from types import SimpleNamespace
-from typing import List, Optional
+from typing import Optional
 
 import torch
 import torch.nn as nn
 
 from . import kernels as K
+from .generation import (KeywordsStoppingCriteria, SamplingConfig, StoppingCriteria,  # noqa: F401 (re-exported)
+                         check_right_padded, prepare_inputs_for_generation)
 from .layers import MLVLROIQueryModule, PreparedBoxes
 from .llama import LlamaDecoder
 from .vit import ClipVisionTower
@@ -40,36 +55,131 @@ class CausalLMOutputWithPast:
     past_key_values: Optional[object] = None
     hidden_states: Optional[torch.Tensor] = None
     loss: Optional[torch.Tensor] = None
+    attentions: Optional[object] = None
+
+    def __getitem__(self, i):          # HF outputs index as tuples with the None entries dropped: (loss?, logits, ...)
+        return [v for v in (self.loss, self.logits, self.past_key_values) if v is not None][i]
+
+
+def add_spatial_token(tokenizer):
+    """gpt4roi/models/spi_llava.py:208-212."""
+    spi_tokens = ['<bbox>', '<point>']
+    num_spi_tokens = tokenizer.add_tokens(spi_tokens, special_tokens=True)
+    return tokenizer, num_spi_tokens
+
+
+# ---------------------------------------------------------------------------------------------------- autograd seams
+class _RegionPathFn(torch.autograd.Function):
+    """logits = path(input_ids, images, bboxes; trainable parameters).  Forward = `forward_train` of every stage (keeps
+    what the hand-written backward needs), backward = LlamaDecoder.backward -> gather of the <bbox> / <im_patch> rows ->
+    region-module / projector parameter gradients, returned to autograd in the order the parameters were passed."""
+
+    @staticmethod
+    def forward(ctx, model, input_ids, images, bboxes, names, *params):
+        with torch.no_grad():
+            logits, pctx = model.forward_train(input_ids, images, bboxes)
+        ctx.model, ctx.pctx, ctx.names = model, pctx, names
+        ctx.shape = (input_ids.size(0), input_ids.size(1))
+        return logits.view(input_ids.size(0), input_ids.size(1), -1)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model, (B, T) = ctx.model, ctx.shape
+        dec = model.llama
+        with torch.no_grad():
+            dl = torch.zeros((B * T, dec.v_pad), dtype=torch.bfloat16, device=dlogits.device)
+            dl[:, :dec.vocab] = dlogits.reshape(B * T, dec.vocab)
+            grads = model.backward(ctx.pctx, dl, train_projector=any(n.startswith("mm_projector.") for n in ctx.names))
+        ctx.pctx = None
+        return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
+
+
+class _ShiftedCrossEntropyFn(torch.autograd.Function):
+    """llava/model/llava.py:240-252 (shift, flatten, CrossEntropyLoss with ignore_index -100) as the fused kernel: loss and
+    (softmax - onehot) / n_valid in one pass."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, dec):
+        B, T, V = logits.shape
+        with torch.no_grad():
+            loss, dl = dec.loss_and_dlogits(logits.reshape(B * T, V), labels)
+        ctx.dl, ctx.shape = dl, (B, T, V)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, V = ctx.shape
+        return (ctx.dl[:, :V].float() * g).view(B, T, V), None, None
 
 
 class SPILlavaLlamaModel(nn.Module):
-    """Holds the four stages; `forward` returns the decoder's final hidden states / logits."""
+    """Holds the four stages; `forward` returns the decoder's logits."""
 
-    def __init__(self, vision_tower: ClipVisionTower, llama: LlamaDecoder, token_ids: SimpleNamespace,
+    def __init__(self, vision_tower: Optional[ClipVisionTower], llama: LlamaDecoder, token_ids: SimpleNamespace,
                  embed_dims=1024, mm_projector: Optional[nn.Linear] = None):
         super().__init__()
         self.num_level_spi_features = 4
-        self.vision_tower = [vision_tower]          # a list, as in the reference (llava.py:48)
+        self.vision_tower = [vision_tower]          # a list, as in the reference (llava.py:48): not in the state_dict
         self.llama = llama
         self.config = token_ids                     # im_patch_token, im_start_token, im_end_token, bbox_token
         self.spi_module = MLVLROIQueryModule(embed_dims=embed_dims, out_dims=llama.hidden, num_levels=4)
         self.mm_projector = mm_projector if mm_projector is not None else nn.Linear(embed_dims, llama.hidden)
         self._proj = None
+        self._stamp = None
         self.last_status = None
+        self.gradient_checkpointing = False
+
+    # ---- kernel-ready copies of the nn.Parameters, refreshed when a parameter changed -------------------------
+    def _param_stamp(self):
+        return tuple((p.data_ptr(), p._version) for p in itertools.chain(self.spi_module.parameters(),
+                                                                         self.mm_projector.parameters()))
 
     def prepare(self):
         bf = torch.bfloat16
         dev = self.llama.device
         self.spi_module.to(dev)
+        self.mm_projector.to(dev)
         self.spi_module.prepare()
         self._proj = (self.mm_projector.weight.detach().to(device=dev, dtype=bf).contiguous(),
                       self.mm_projector.bias.detach().to(device=dev, dtype=bf).float().contiguous())
+        self._stamp = self._param_stamp()
 
+    def _maybe_prepare(self):
+        """An optimizer step (or load_state_dict) bumps the parameters' version counters: re-derive the bf16 copies."""
+        if self._proj is None or self._stamp != self._param_stamp():
+            self.prepare()
+
+    def initialize_vision_modules(self, vision_tower, mm_vision_select_layer=-2, pretrain_mm_mlp_adapter=None,
+                                  tune_mm_mlp_adapter=False):
+        """llava/model/llava.py:54-86.  `vision_tower`: a directory holding an HF CLIPVisionModel checkpoint, an HF-keyed
+        state dict, or a ready ClipVisionTower (there is no hub access here, so a hub name cannot be resolved).  The
+        tower stays frozen and outside the state_dict; `mm_projector` is (re)loaded from `pretrain_mm_mlp_adapter`."""
+        from . import checkpoint as ckpt
+        tower = vision_tower if isinstance(vision_tower, ClipVisionTower) else \
+            ckpt.load_vision_tower(vision_tower, device=self.llama.device, select_layer=mm_vision_select_layer)
+        self.vision_tower = [tower]
+        cfg = self.config
+        cfg.mm_vision_tower = vision_tower if isinstance(vision_tower, str) else getattr(cfg, "mm_vision_tower", None)
+        cfg.use_mm_proj = True
+        cfg.mm_hidden_size = tower.hidden
+        cfg.mm_vision_select_layer = mm_vision_select_layer
+        if self.mm_projector.in_features != tower.hidden:
+            self.mm_projector = nn.Linear(tower.hidden, self.llama.hidden)
+        if pretrain_mm_mlp_adapter is not None:
+            w = pretrain_mm_mlp_adapter if isinstance(pretrain_mm_mlp_adapter, dict) else \
+                torch.load(pretrain_mm_mlp_adapter, map_location='cpu')
+            self.mm_projector.load_state_dict({k.split('.')[-1]: v for k, v in w.items() if 'mm_projector' in k})
+        self._proj = None
+        image_size = getattr(tower, "image_size", None)
+        num_patches = (image_size // tower.patch) ** 2 if image_size else None
+        return dict(image_processor=ckpt.ClipImageProcessor(image_size or 224), image_token_len=num_patches,
+                    vision_config=cfg)
+
+    # ---- stages a4-a15 ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def embed_inputs(self, input_ids, images=None, bboxes=None):
         """Stages a4-a15 of SURVEY.md 8a: returns inputs_embeds [B,T,C] bf16 for the decoder."""
-        if self._proj is None:
-            self.prepare()
+        self._maybe_prepare()
         cfg = self.config
         B, T = input_ids.shape
         run_vision = images is not None and T != 1
@@ -88,7 +198,6 @@ class SPILlavaLlamaModel(nn.Module):
                 spi = torch.cat(feats, 0).contiguous() if len(feats) > 1 else feats[0]
                 off = bboxes.offsets
             n_patch = image_features.size(1)
-            C = image_features.size(2)
             # mm_projector over the patch tokens (strided view of the hidden state, CLS skipped)
             img_tok = torch.empty((B, n_patch, self.llama.hidden), dtype=torch.bfloat16, device=images.device)
             for b in range(B):
@@ -109,6 +218,7 @@ class SPILlavaLlamaModel(nn.Module):
         wave-quantisation tails and the latency-bound small kernels of a batch-1 request
         (+30 % region-tokens/s on MI355X)."""
         import copy
+        self._maybe_prepare()
         other = copy.copy(self)                      # nn.Module shallow copy: parameters are shared
         other.llama = copy.copy(self.llama)
         other.llama._alloc_cache(self.llama.kc.size(1))
@@ -127,53 +237,290 @@ class SPILlavaLlamaModel(nn.Module):
                 raise ValueError('The number of <bbox> tokens does not match the number of regions.')
             raise ValueError(f'malformed multimodal prompt (status {codes})')
 
+    # ---- training rows: the forward that keeps what the backward needs, and that backward ----------------------
     @torch.no_grad()
+    def forward_train(self, input_ids, images, bboxes):
+        """-> (logits fp32 [B*T, V], ctx).  Raises on a malformed prompt (per-sample <bbox>/region count,
+        <im_start>/<im_end>) exactly where the reference does (spi_llava.py:115-157)."""
+        self._maybe_prepare()
+        cfg = self.config
+        B, T = input_ids.shape
+        tower = self.vision_tower[0]
+        if isinstance(images, (list, tuple)):
+            images = torch.stack(list(images), 0)
+        keep = tower.forward(images)
+        image_features, mlvl = tower.select(keep)
+        if not isinstance(bboxes, PreparedBoxes):
+            bboxes = PreparedBoxes(bboxes, images.size(-1), images.device)
+        spi, sctx = self.spi_module.forward_train(mlvl, bboxes)
+        n_patch = image_features.size(1)
+        img_tok = torch.empty((B, n_patch, self.llama.hidden), dtype=torch.bfloat16, device=images.device)
+        for b in range(B):
+            K.gemm(image_features[b], self._proj[0], bias=self._proj[1], out=img_tok[b])
+        embeds, status = K.splice_embed(input_ids.contiguous(), self.llama.embed, img_tok, spi, bboxes.offsets, n_patch,
+                                        cfg.im_patch_token, cfg.bbox_token, cfg.im_start_token, cfg.im_end_token)
+        self.last_status = status
+        self.check_status()
+        if not hasattr(self.llama, "lm_head_t"):
+            self.llama.prepare_training(train_weights=False)
+        self.llama.reset(B)
+        logits, lctx = self.llama.forward_train(embeds, checkpoint=self.gradient_checkpointing)
+        return logits, dict(sctx=sctx, lctx=lctx, input_ids=input_ids, boxes=bboxes, image_features=image_features)
+
+    @torch.no_grad()
+    def backward(self, ctx, dlogits, train_projector=False, on_grad=None):
+        """dlogits bf16 [B*T, v_pad] -> {"spi_module.<key>": fp32 grad, ("mm_projector.weight"/".bias")} in the
+        reference's state_dict layouts.  `on_grad(name, grad)` is called as each gradient is produced (head of the
+        model first), which is what lets the bucketed exchange overlap with the rest of the backward."""
+        cfg = self.config
+        dec_cb = (lambda n, g: on_grad(f"llama.{n}", g)) if (on_grad is not None and self.llama.train_weights) else None
+        d_emb = self.llama.backward(ctx["lctx"], dlogits, on_grad=dec_cb)       # [B*T, C] bf16
+        self._d_emb = d_emb
+        flat = ctx["input_ids"].reshape(-1)
+        grads = {}
+        if train_projector:
+            image_features = ctx["image_features"]
+            idx_patch = (flat == cfg.im_patch_token).nonzero().flatten().to(torch.int32)
+            d_img = K.gather_rows(d_emb, idx_patch)                             # [B*n_patch, C]
+            x = image_features.reshape(-1, image_features.size(-1))
+            grads["mm_projector.weight"] = K.linear_wgrad(d_img, x)
+            grads["mm_projector.bias"] = K.colsum(d_img)
+            if on_grad is not None:
+                for k in ("mm_projector.bias", "mm_projector.weight"):
+                    on_grad(k, grads[k])
+        idx_bbox = (flat == cfg.bbox_token).nonzero().flatten().to(torch.int32)
+        assert idx_bbox.numel() == ctx["boxes"].n, "number of <bbox> tokens != number of regions"
+        cb = (lambda k, g: on_grad(f"spi_module.{k}", g)) if on_grad is not None else None
+        for k, g in self.spi_module.backward(ctx["sctx"], K.gather_rows(d_emb, idx_bbox), on_grad=cb).items():
+            grads[f"spi_module.{k}"] = g
+        return grads
+
+    def trainable_named(self):
+        """name -> nn.Parameter for the stage-1 trainables that currently require grad (train.py:685-696)."""
+        out = {f"spi_module.{k}": p for k, p in self.spi_module.named_parameters() if p.requires_grad}
+        out.update({f"mm_projector.{k}": p for k, p in self.mm_projector.named_parameters() if p.requires_grad})
+        return out
+
     def forward(self, input_ids: torch.LongTensor = None, attention_mask: Optional[torch.Tensor] = None,
                 img_metas=None, bboxes=None, past_key_values=None, inputs_embeds: Optional[torch.Tensor] = None,
                 use_cache: Optional[bool] = None, output_attentions: Optional[bool] = None,
                 output_hidden_states: Optional[bool] = None, images: Optional[torch.Tensor] = None,
                 return_dict: Optional[bool] = None, all_logits=True):
-        if inputs_embeds is None:
-            inputs_embeds = self.embed_inputs(input_ids, images, bboxes)
-        if past_key_values is None:
-            self.llama.reset(inputs_embeds.size(0))
-        return self.llama.forward(inputs_embeds, all_logits=all_logits)
+        check_right_padded(attention_mask)
+        if torch.is_grad_enabled() and inputs_embeds is None and images is not None and input_ids.size(1) != 1:
+            named = self.trainable_named()
+            if named:
+                names = tuple(named)
+                return _RegionPathFn.apply(self, input_ids, images, bboxes, names, *named.values())
+        with torch.no_grad():
+            if inputs_embeds is None:
+                inputs_embeds = self.embed_inputs(input_ids, images, bboxes)
+            if past_key_values is None:
+                self.llama.reset(inputs_embeds.size(0))
+            return self.llama.forward(inputs_embeds, all_logits=all_logits)
+
+
+class _EmbeddingView:
+    """What `get_input_embeddings()` / `get_output_embeddings()` hand to initialize_vision_tokenizer: `.weight.data`."""
+
+    def __init__(self, dec, attr):
+        self._dec, self._attr = dec, attr
+
+    @property
+    def weight(self):
+        return getattr(self._dec, self._attr)
+
+    def parameters(self):
+        return iter(())          # frozen bf16 tensors on this path (stage 2 trains them through FullTrainer)
 
 
 class SPILlavaMPTForCausalLM(nn.Module):
     """Same call shape as the reference class of that name (despite "MPT" it is the LLaMA model)."""
 
-    def __init__(self, model: SPILlavaLlamaModel):
+    def __init__(self, model: SPILlavaLlamaModel, config: Optional[SimpleNamespace] = None):
         super().__init__()
         self.model = model
+        self.config = config if config is not None else SimpleNamespace()
+        self.generation_config = SamplingConfig()
 
     def get_model(self):
         return self.model
 
-    @torch.no_grad()
+    def get_input_embeddings(self):
+        return _EmbeddingView(self.model.llama, "embed")
+
+    def get_output_embeddings(self):
+        return _EmbeddingView(self.model.llama, "lm_head")
+
+    def gradient_checkpointing_enable(self, *_, **__):
+        """`--gradient_checkpointing True` (train_stage1.sh:36): keep only each decoder layer's input and re-run the
+        layer in the backward (LlamaDecoder.forward_train(checkpoint=True))."""
+        self.model.gradient_checkpointing = True
+
+    def gradient_checkpointing_disable(self):
+        self.model.gradient_checkpointing = False
+
+    def resize_token_embeddings(self, new_num_tokens):
+        """HF `resize_token_embeddings`: grow (or cut) the embedding table and lm_head; new rows are zero until
+        initialize_vision_tokenizer gives them the mean of the old rows (spi_llava.py:262-272)."""
+        dec = self.model.llama
+        old = dec.embed.size(0)
+        if new_num_tokens == old:
+            return self.get_input_embeddings()
+        for attr in ("embed", "lm_head"):
+            w = getattr(dec, attr)
+            nw = torch.zeros((new_num_tokens, w.size(1)), dtype=w.dtype, device=w.device)
+            n = min(old, new_num_tokens)
+            nw[:n] = w[:n]
+            setattr(dec, attr, nw)
+        dec.vocab = new_num_tokens
+        if hasattr(dec, "lm_head_t"):
+            dec.prepare_training(train_weights=getattr(dec, "train_weights", False))
+        dec._dstate = None
+        self.config.vocab_size = new_num_tokens
+        return self.get_input_embeddings()
+
+    def initialize_vision_tokenizer(self, mm_use_im_start_end, tokenizer, device=None, tune_mm_mlp_adapter=False,
+                                    pretrain_mm_mlp_adapter=None):
+        """gpt4roi/models/spi_llava.py:242-306, same order of operations: add <im_patch>, resize; add <bbox>, <point>;
+        add <im_start>, <im_end>, resize; the last `num_new_tokens` (= 2 + the spatial tokens) rows of the input and
+        output embeddings become the mean of the rows before them; ids are written into the vision config; the
+        tokenizer is attached to every module."""
+        vision_config = self.model.config
+        vision_config.use_im_start_end = mm_use_im_start_end
+        tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
+        self.resize_token_embeddings(len(tokenizer))
+        tokenizer, num_spi_tokens = add_spatial_token(tokenizer)
+        if mm_use_im_start_end:
+            num_new_tokens = tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
+            self.resize_token_embeddings(len(tokenizer))
+            vision_config.im_start_token, vision_config.im_end_token = tokenizer.convert_tokens_to_ids(
+                [DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN])
+            num_new_tokens = num_new_tokens + num_spi_tokens
+            if num_new_tokens > 0:
+                input_embeddings = self.get_input_embeddings().weight.data
+                output_embeddings = self.get_output_embeddings().weight.data
+                input_embeddings_avg = input_embeddings[:-num_new_tokens].float().mean(dim=0, keepdim=True)
+                output_embeddings_avg = output_embeddings[:-num_new_tokens].float().mean(dim=0, keepdim=True)
+                input_embeddings[-num_new_tokens:] = input_embeddings_avg.to(input_embeddings.dtype)
+                output_embeddings[-num_new_tokens:] = output_embeddings_avg.to(output_embeddings.dtype)
+            if tune_mm_mlp_adapter:
+                self.model.orig_embeds_params = [self.get_input_embeddings().weight.data.clone()]
+            if pretrain_mm_mlp_adapter:
+                w = pretrain_mm_mlp_adapter if isinstance(pretrain_mm_mlp_adapter, dict) else \
+                    torch.load(pretrain_mm_mlp_adapter, map_location='cpu')
+                embed_tokens_weight = w['model.embed_tokens.weight']
+                input_embeddings = self.get_input_embeddings().weight.data
+                num_new_tokens = num_new_tokens - num_spi_tokens
+                if input_embeddings.shape == embed_tokens_weight.shape:
+                    input_embeddings[-num_new_tokens:] = embed_tokens_weight[-num_new_tokens:].to(input_embeddings)
+                elif embed_tokens_weight.shape[0] == num_new_tokens:
+                    input_embeddings[-num_new_tokens:] = embed_tokens_weight.to(input_embeddings)
+                else:
+                    raise ValueError(f'Unexpected embed_tokens_weight shape. Pretrained: {embed_tokens_weight.shape}. '
+                                     f'Current: {input_embeddings.shape}. Numer of new tokens: {num_new_tokens}.')
+            if hasattr(self.model.llama, "lm_head_t"):
+                self.model.llama.refresh_transposes()
+        vision_config.im_patch_token = tokenizer.convert_tokens_to_ids([DEFAULT_IMAGE_PATCH_TOKEN])[0]
+        vision_config.bbox_token = tokenizer.convert_tokens_to_ids(['<bbox>'])[0]
+        vision_config.point_token = tokenizer.convert_tokens_to_ids(['<point>'])[0]
+        for m in self.modules():          # "broadcast the tokenizer to all modules" (:304-306)
+            m.tokenizer = tokenizer
+
+    @classmethod
+    def from_pretrained(cls, path, **kwargs):
+        from . import checkpoint as ckpt
+        return ckpt.from_pretrained(cls, path, **kwargs)
+
+    def save_pretrained(self, path, **kwargs):
+        from . import checkpoint as ckpt
+        return ckpt.save_pretrained(self, path, **kwargs)
+
+    def state_dict(self, *args, **kwargs):
+        """The HF-keyed state dict the reference checkpoints carry (`model.layers.*`, `lm_head.weight`,
+        `model.spi_module.*`, `model.mm_projector.*`; no vision tower: llava.py:48 keeps it in a Python list)."""
+        sd = self.model.llama.export_hf_state_dict()
+        sd.update({f"model.spi_module.{k}": v.detach() for k, v in self.model.spi_module.state_dict().items()})
+        sd.update({f"model.mm_projector.{k}": v.detach() for k, v in self.model.mm_projector.state_dict().items()})
+        return sd
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None,
+                                      **kwargs):
+        return prepare_inputs_for_generation(input_ids, past_key_values, attention_mask, inputs_embeds, **kwargs)
+
     def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, images=None, return_dict=None,
-                *, img_metas=None, bboxes=None):
+                *, img_metas=None, bboxes=None, _last_only=False):
         logits = self.model(input_ids=input_ids, attention_mask=attention_mask, img_metas=img_metas, bboxes=bboxes,
-                            past_key_values=past_key_values, inputs_embeds=inputs_embeds, images=images)
+                            past_key_values=past_key_values, inputs_embeds=inputs_embeds, images=images,
+                            all_logits=not _last_only)
         loss = None
         if labels is not None:
-            # shifted-label token cross entropy, llava/model/llava.py:240-252 (evaluation of the loss only; the
-            # training step with its hand-written backward is gpt4roi_amd/train.py::RegionTrainer)
-            B, T, V = logits.shape
-            lab = torch.full((B, T), -100, dtype=torch.int64, device=logits.device)
-            lab[:, :-1] = labels[:, 1:]
-            lab = lab.reshape(-1).contiguous()
-            cnt = (lab >= 0).sum().clamp(min=1).float()
-            loss_sum = torch.zeros(1, dtype=torch.float32, device=logits.device)
-            K.cross_entropy(logits.view(B * T, V), lab, loss_sum)
-            loss = (loss_sum / cnt).reshape(())
+            # shifted-label token cross entropy, llava/model/llava.py:240-252
+            if logits.requires_grad:
+                loss = _ShiftedCrossEntropyFn.apply(logits, labels, self.model.llama)
+            else:
+                with torch.no_grad():
+                    B, T, V = logits.shape
+                    lab = torch.full((B, T), -100, dtype=torch.int64, device=logits.device)
+                    lab[:, :-1] = labels[:, 1:]
+                    lab = lab.reshape(-1).contiguous()
+                    cnt = ((lab >= 0) & (lab < V)).sum().clamp(min=1).float()
+                    loss_sum = torch.zeros(1, dtype=torch.float32, device=logits.device)
+                    K.cross_entropy(logits.view(B * T, V), lab, loss_sum)
+                    loss = (loss_sum / cnt).reshape(())
         return CausalLMOutputWithPast(logits=logits, past_key_values=self.model.llama, loss=loss)
 
     @torch.no_grad()
-    def generate(self, input_ids, images=None, bboxes=None, max_new_tokens=64, do_sample=False, stop_ids=(), **_):
-        """Greedy decode (the parity mode; app.py:294-300 samples with T=0.2 instead)."""
-        if do_sample:
-            raise NotImplementedError("only greedy decoding is implemented")
-        embeds = self.model.embed_inputs(input_ids, images, bboxes)
-        return self.model.llama.greedy(embeds, max_new_tokens, stop_ids)
+    def generate(self, input_ids=None, images=None, max_new_tokens=64, do_sample=None, temperature=None, top_k=None,
+                 top_p=None, stopping_criteria=None, eos_token_id=None, seed=None, bboxes=None, stop_ids=(),
+                 check_every=None, return_new_tokens=False, **_):
+        """HF-style `generate` for batch 1 (what gpt4roi/app.py:293-300 calls): prefill through `self.forward` -- so a
+        `partial(orig_forward, img_metas=..., bboxes=...)` bound by the caller is honoured (app.py:286-291; `bboxes=`
+        may also be passed here) -- then the device-resident decode loop.  do_sample=False: greedy (the parity mode);
+        do_sample=True: temperature / top-k / top-p sampling on the device with a Philox stream keyed by `seed`
+        (drawn from torch's generator when None).  `stopping_criteria`: callables criteria(ids [1, T+n], scores) -> bool
+        evaluated per generated token like HF (KeywordsStoppingCriteria); `eos_token_id` / `stop_ids` end the sequence
+        (inclusive).  Returns the full sequence LongTensor [1, T + n] (or the list of new ids if return_new_tokens)."""
+        assert input_ids.size(0) == 1, "generate() serves one request (the reference's app is batch 1)"
+        gc = self.generation_config
+        cfg = SamplingConfig(do_sample=gc.do_sample if do_sample is None else bool(do_sample),
+                             temperature=gc.temperature if temperature is None else temperature,
+                             top_k=gc.top_k if top_k is None else top_k, top_p=gc.top_p if top_p is None else top_p)
+        sampler = cfg.sampler()
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if sampler is not None else 0
+        fwd = self.forward                                   # instance attribute first: the caller may have rebound it
+        kw = dict(bboxes=bboxes) if bboxes is not None else {}
+        model_inputs = self.prepare_inputs_for_generation(input_ids, images=images)
+        dec = self.model.llama
+        # step 0 = prefill through the (possibly partial-bound) forward; only its embeddings are needed here: the
+        # decode loop owns the KV cache, so hand it the spliced embeddings
+        embeds = self._prefill_embeds(fwd, model_inputs, kw)
+        stops = set(int(s) for s in stop_ids)
+        if eos_token_id is not None:
+            stops.update([int(eos_token_id)] if not isinstance(eos_token_id, (list, tuple)) else map(int, eos_token_id))
+        on_tokens = None
+        if stopping_criteria:
+            for c in stopping_criteria:                      # HF calls every criterion once per generated token; the
+                c(input_ids, None)                           # reference's first call only records the prompt length
+            prompt = input_ids
+
+            def on_tokens(new_ids):
+                seq = torch.cat([prompt, torch.tensor([new_ids], dtype=prompt.dtype, device=prompt.device)], 1)
+                return any(bool(c(seq, None)) for c in stopping_criteria)
+            # the first call above consumed HF's "first token" call of the reference criteria (start_len recorded),
+            # so token 1 is tested like every later one
+        every = check_every if check_every is not None else (1 if stopping_criteria else 32)
+        new = dec.decode_graph(embeds, max_new_tokens, stop_ids=stops, check_every=every, sampler=sampler, seed=seed,
+                               on_tokens=on_tokens)
+        if return_new_tokens:
+            return new
+        return torch.cat([input_ids, torch.tensor([new], dtype=input_ids.dtype, device=input_ids.device)], 1)
+
+    def _prefill_embeds(self, fwd, model_inputs, kw):
+        """The spliced prompt embeddings of step 0.  When `forward` was rebound with partial(bboxes=...) the boxes live
+        in its keywords (app.py:286-291); they are read from there, the rest of the call is `embed_inputs`."""
+        bound = getattr(fwd, "keywords", None) or {}
+        bboxes = kw.get("bboxes", bound.get("bboxes"))
+        return self.model.embed_inputs(model_inputs["input_ids"], model_inputs.get("images"), bboxes)

@@ -76,49 +76,42 @@ class RegionTrainer:
         self.last_grad_norm = None
 
     # ---- forward + backward: parameter gradients in the reference layout ------------------------------------
+    def _exchange_tensors(self):
+        """name -> the tensor object the reducer was built over (nn.Parameters here; FullTrainer adds its masters)."""
+        return self.params
+
     @torch.no_grad()
-    def loss_and_grads(self, input_ids, images, bboxes, labels):
+    def loss_and_grads(self, input_ids, images, bboxes, labels, exchange=False):
+        """One forward + backward.  exchange=True (world > 1): every gradient is handed to the bucketed reducer the
+        moment its kernel sequence has been issued (`on_grad`), so a bucket's reduce-scatter + all-gather runs on the
+        communication stream while the backward of the earlier layers is still executing; the returned gradients are
+        then the rank-averaged views into the reducer's flat buckets."""
         m = self.model
-        cfg = m.config
-        B, T = input_ids.shape
-        tower = m.vision_tower[0]
-        if isinstance(images, (list, tuple)):
-            images = torch.stack(list(images), 0)
-        keep = tower.forward(images)
-        image_features, mlvl = tower.select(keep)
-        if not isinstance(bboxes, PreparedBoxes):
-            bboxes = PreparedBoxes(bboxes, images.size(-1), images.device)
-        spi, sctx = m.spi_module.forward_train(mlvl, bboxes)
-        n_patch, Cv = image_features.size(1), image_features.size(2)
-        img_tok = torch.empty((B, n_patch, m.llama.hidden), dtype=torch.bfloat16, device=images.device)
-        for b in range(B):
-            K.gemm(image_features[b], m._proj[0], bias=m._proj[1], out=img_tok[b])
-        embeds, status = K.splice_embed(input_ids.contiguous(), m.llama.embed, img_tok, spi, bboxes.offsets, n_patch,
-                                        cfg.im_patch_token, cfg.bbox_token, cfg.im_start_token, cfg.im_end_token)
-        m.last_status = status
-        m.check_status()        # per-sample <bbox>/region or <im_start>/<im_end> mismatch raises, as spi_llava.py:115-157 does
-        m.llama.reset(B)
-        logits, lctx = m.llama.forward_train(embeds)
+        logits, ctx = m.forward_train(input_ids, images, bboxes)
         loss, dlogits = m.llama.loss_and_dlogits(logits, labels)
-        d_emb = m.llama.backward(lctx, dlogits)                                  # [B*T, C] bf16
-        self._d_emb = d_emb
-        flat = input_ids.reshape(-1)
-        idx_bbox = (flat == cfg.bbox_token).nonzero().flatten().to(torch.int32)
-        assert idx_bbox.numel() == bboxes.n, "number of <bbox> tokens != number of regions"
-        grads = {f"spi_module.{k}": g for k, g in m.spi_module.backward(sctx, K.gather_rows(d_emb, idx_bbox)).items()}
-        if self.train_projector:
-            idx_patch = (flat == cfg.im_patch_token).nonzero().flatten().to(torch.int32)
-            d_img = K.gather_rows(d_emb, idx_patch)                              # [B*n_patch, C]
-            x = image_features.reshape(B * n_patch, Cv)
-            grads["mm_projector.weight"] = K.linear_wgrad(d_img, x)
-            grads["mm_projector.bias"] = K.colsum(d_img)
+        on_grad = None
+        live = exchange and self.reducer is not None
+        if live:
+            tensors = self._exchange_tensors()
+            self.reducer.reset()
+            on_grad = lambda name, g: self.reducer.ready(tensors[name], g.reshape(tensors[name].shape))  # noqa: E731
+        grads = m.backward(ctx, dlogits, train_projector=self.train_projector, on_grad=on_grad)
+        self._d_emb = m._d_emb
+        self._last_input_ids = input_ids
+        grads = self._extra_grads(grads, on_grad)
+        if live:
+            red = self.reducer.finish()
+            grads = {k: red[id(t)] for k, t in tensors.items()}
         return loss, grads
+
+    def _extra_grads(self, grads, on_grad):
+        return grads
 
     # ---- exchange, clip, AdamW ---------------------------------------------------------------------------------
     @torch.no_grad()
-    def apply(self, grads, lr=None):
+    def apply(self, grads, lr=None, exchanged=False):
         names = list(self.params)
-        if self.reducer is not None:
+        if self.reducer is not None and not exchanged:
             grads = exchange_gradients(self.reducer, self.params, grads)
         scale = 1.0
         if self.max_grad_norm is not None and self.max_grad_norm > 0:
@@ -136,8 +129,8 @@ class RegionTrainer:
         self.model.prepare()                                # refresh the bf16 kernel copies of the updated weights
 
     def step(self, input_ids, images, bboxes, labels, lr=None):
-        loss, grads = self.loss_and_grads(input_ids, images, bboxes, labels)
-        self.apply(grads, lr)
+        loss, grads = self.loss_and_grads(input_ids, images, bboxes, labels, exchange=self.reducer is not None)
+        self.apply(grads, lr, exchanged=self.reducer is not None)
         return loss
 
 
@@ -169,26 +162,30 @@ class FullTrainer(RegionTrainer):
             self.reducer = GradBucketReducer(tensors, bucket_bytes=bucket_bytes, group=group, comm_dtype=torch.float32,
                                              trainable_only=False)
 
-    @torch.no_grad()
-    def loss_and_grads(self, input_ids, images, bboxes, labels):
-        loss, grads = super().loss_and_grads(input_ids, images, bboxes, labels)
+    def _exchange_tensors(self):
+        return {**self.params, **self.dec_master}
+
+    def _extra_grads(self, grads, on_grad):
+        """Decoder weight gradients (produced inside LlamaDecoder.backward and already reported through `on_grad`) and the
+        embedding rows: every position that took embed[id] in the splice (not <im_patch>, not <bbox>)."""
         m = self.model
         dec, cfg = m.llama, m.config
         for k, g in dec.grads.items():
             grads[f"llama.{k}"] = g
-        # embedding rows: every position that took embed[id] in the splice (not <im_patch>, not <bbox>)
-        flat = input_ids.reshape(-1)
+        flat = self._last_input_ids.reshape(-1)
         idx = torch.where((flat == cfg.im_patch_token) | (flat == cfg.bbox_token), torch.full_like(flat, -1), flat)
         ge = torch.zeros(dec.embed.shape, dtype=torch.float32, device=dec.embed.device)
         K.scatter_add_rows(self._d_emb, idx.to(torch.int32).contiguous(), ge)
         grads["llama.embed_tokens"] = ge
-        return loss, grads
+        if on_grad is not None:
+            on_grad("llama.embed_tokens", ge)
+        return grads
 
     @torch.no_grad()
-    def apply(self, grads, lr=None):
+    def apply(self, grads, lr=None, exchanged=False):
         names = list(self.params) + list(self.dec_master)
         tensors = {**{k: p.data for k, p in self.params.items()}, **self.dec_master}
-        if self.reducer is not None:
+        if self.reducer is not None and not exchanged:
             grads = exchange_gradients(self.reducer, {**self.params, **self.dec_master}, grads)
         scale = 1.0
         if self.max_grad_norm is not None and self.max_grad_norm > 0:

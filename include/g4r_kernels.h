@@ -154,6 +154,19 @@ int g4r_image_preprocess_u8_f32(const void* image, int height, int width, long r
                                 int out_h, int out_w, float mean_r, float mean_g, float mean_b, float std_r,
                                 float std_g, float std_b, void* stream);
 
+/*
+ * One sampling step of generate(do_sample=True, temperature, top_k, top_p) with the decode state on the device
+ * (gpt4roi/app.py:293-300 calls HF generate with do_sample=True, temperature=0.2; HF's warper order is temperature ->
+ * top-k -> top-p, GenerationConfig defaults top_k = 50, top_p = 1.0): keeps the tokens whose logit is >= the top_k-th
+ * largest (top_k = 0: all), optionally the top-p nucleus of those, and draws by inverse CDF in ascending vocabulary
+ * order with u = Philox4x32-10(counter = (*step, 0, 0, 0), key = *seed)[0] >> 8 scaled to [0, 1).
+ * tok[0] = id; out_ids[*step] = id; u_out[*step] = u (nullable); ++*step; ++*pos.  top_k in [0, 1024]; top_p < 1 needs
+ * top_k >= 1.  Same device-state contract as g4r_greedy_advance_f32 (hipGraph-replayable; the seed is read from memory).
+ */
+int g4r_sample_advance_f32(const float* logits, int N, float temperature, int top_k, float top_p,
+                           const unsigned long long* seed, long* tok, long* out_ids, int* step, int* pos,
+                           int max_steps, float* u_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
