@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="independent batch-1 requests in flight per GPU, one HIP stream each (1 = strictly serial)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--train-steps", type=int, default=4,
+                    help="extra (not part of `value`): timed stage-1 training steps (SURVEY.md 8d config 3: batch 8 per GPU, "
+                         "region module + projector trainable, gradient exchange over RCCL when N > 1); 0 = skip")
+    ap.add_argument("--train-batch", type=int, default=8)
     ap.add_argument("--decode-tokens", type=int, default=16,
                     help="extra (not part of `value`): greedy KV-cache decode steps timed after the prefill")
     return ap.parse_args()
@@ -93,7 +97,6 @@ def cpu_baseline(args):
     construction) on the 4 pyramid levels + CLIP ViT-L/14 fp32 on the host cores, one image."""
     import numpy as np
     from oracle import roi_align as O
-    from oracle import transformer_oracle as T
     from gpt4roi_amd import synthetic as syn
     P = args.image_size // 14
     g = torch.Generator().manual_seed(0)
@@ -106,21 +109,109 @@ def cpu_baseline(args):
         t0 = time.perf_counter()
         (O.ref_forward if kind == "reference" else O.forward)(x, rois, 14, np.float32(1.0 / stride), 2)
         t_roi += time.perf_counter() - t0
-    torch.set_num_threads(min(32, os.cpu_count()))   # more threads than ~32 slow this M=577 workload down
+    # CLIP ViT-L/14 on the host cores: HF transformers' own CLIPVisionModel (the arithmetic the reference calls at
+    # spi_llava.py:66-67; third-party, pinned by the reference at git cae78c46 -- the container's release is timed), all
+    # 24 layers with output_hidden_states=True as the reference runs it, fp32, random weights.  Timed with ALL host cores
+    # and with 32 threads (this M = 577 workload does not scale past a few dozen threads); the faster one is reported.
+    import transformers
+    from transformers import CLIPVisionConfig, CLIPVisionModel
     v = syn.CLIP_L14
-    sd = syn.vit_state(v["hidden"], v["inter"], 23, args.image_size, seed=0)
+    cfg = CLIPVisionConfig(hidden_size=v["hidden"], intermediate_size=v["inter"], num_hidden_layers=v["layers"],
+                           num_attention_heads=v["heads"], patch_size=14, image_size=args.image_size)
+    torch.manual_seed(0)
+    hf = CLIPVisionModel(cfg).eval()
     img = torch.randn(1, 3, args.image_size, args.image_size, generator=g)
+    t_by_threads = {}
     with torch.no_grad():
-        T.clip_vit_hidden_states(sd, img, heads=16, n_layers=1)           # thread pool warm-up
-        t0 = time.perf_counter()
-        T.clip_vit_hidden_states(sd, img, heads=16, n_layers=23)
-        t_vit = time.perf_counter() - t0
-    return {"value": round(args.rois / (t_roi + t_vit), 3), "unit": "region-tokens/s", "cores": torch.get_num_threads(),
+        for nthr in sorted({min(32, os.cpu_count()), os.cpu_count()}):
+            torch.set_num_threads(nthr)
+            hf(pixel_values=img, output_hidden_states=True)               # thread pool warm-up
+            t0 = time.perf_counter()
+            for _ in range(3):
+                hf(pixel_values=img, output_hidden_states=True)
+            t_by_threads[nthr] = (time.perf_counter() - t0) / 3
+    nbest = min(t_by_threads, key=t_by_threads.get)
+    t_vit = t_by_threads[nbest]
+    return {"value": round(args.rois / (t_roi + t_vit), 3), "unit": "region-tokens/s", "cores": nbest,
             "kind": kind, "host_cpu_count": os.cpu_count(),
-            "sample": (f"1 image {args.image_size}^2, {args.rois} RoIs: mmcv CPU roi_align fp32 x4 levels (1 thread, "
-                       f"{t_roi:.3f} s) + CLIP ViT-L/14 fp32 23 blocks ({torch.get_num_threads()} threads, {t_vit:.3f} s); "
-                       "fuse convs / LLaMA-7B are not part of the CPU sample"),
+            "parts": {"roi_align": {"kind": kind, "what": "the reference's own mmcv cpu/roi_align.cpp compiled unmodified (oracle/_ref)"
+                                    if kind == "reference" else "oracle/roi_align_oracle.c restatement",
+                                    "threads": 1, "seconds": round(t_roi, 4)},
+                      "vit": {"kind": "third-party", "what": f"HF transformers {transformers.__version__} CLIPVisionModel, 24 layers, "
+                                                               "output_hidden_states=True, fp32",
+                              "threads": nbest, "seconds": round(t_vit, 4),
+                              "seconds_by_threads": {str(k): round(x, 4) for k, x in t_by_threads.items()}}},
+            "sample": (f"1 image {args.image_size}^2, {args.rois} RoIs: mmcv CPU roi_align fp32 x4 levels (1 thread, single-threaded "
+                       f"by construction, {t_roi:.3f} s) + HF CLIPVisionModel ViT-L/14 fp32 ({nbest} of {os.cpu_count()} host "
+                       f"threads, {t_vit:.3f} s); fuse convs / LLaMA-7B are not part of the CPU sample"),
             "roi_align_s": round(t_roi, 4), "vit_s": round(t_vit, 4)}
+
+
+def vit_roofline(model, args, device):
+    """CLIP ViT-L/14 alone (FLOPs_ViT(23 layers) / t_ViT / 2.5 PF) at batch 1 and at the batch the training
+    configs feed it (configs 3/4: B = 8/16), timed with HIP events on the launch stream."""
+    tower = model.vision_tower[0]
+    S = (args.image_size // 14) ** 2 + 1
+    C = tower.hidden
+    per_layer = 24.0 * S * C * C + 4.0 * S * S * C                  # 8SC^2 (q,k,v,o) + 16SC^2 (MLP) + 4S^2C (attention)
+    flops1 = len(tower.layers) * per_layer + 2.0 * (S - 1) * 588 * C
+    out = {}
+    for B in (1, 8):
+        img = torch.randn(B, 3, args.image_size, args.image_size, device=device)
+        for _ in range(2):
+            tower.forward(img)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 5
+        e0.record()
+        for _ in range(n):
+            tower.forward(img)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        tf = B * flops1 / (ms * 1e-3) / 1e12
+        out[f"batch{B}"] = {"ms": round(ms, 3), "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tf / PEAK_BF16_TFLOPS, 4), "flops": int(B * flops1)}
+    return out
+
+
+def train_leg(args, model, ids, device, rank, world, dist, agg_device):
+    """Stage-1 training step (train_stage1.sh: region module [+ projector] trainable, ViT / LLaMA frozen) on RefCOCO-shaped
+    synthetic batches (B images per GPU, 1..15 regions each, refcoco.py:55), data-parallel over the
+    ranks: gradients go to the bucketed reduce-scatter + all-gather exchange as the backward produces them.  Timed like
+    the headline (barrier + synchronize both sides, max over ranks)."""
+    from gpt4roi_amd import replicas
+    from gpt4roi_amd import synthetic as syn
+    from gpt4roi_amd.train import RegionTrainer
+    B, P = args.train_batch, args.image_size // 14
+    g = torch.Generator().manual_seed(5000 + rank)
+    n_i = torch.randint(1, 16, (B,), generator=g).tolist()
+    images = torch.randn(B, 3, args.image_size, args.image_size, generator=g).to(device)
+    boxes = [syn.boxes(n, g).to(device) for n in n_i]
+    prompt = torch.stack([syn.prompt_ids(ids, P, n, g, question_len=20 + 4 * (15 - n)) for n in n_i]).to(device)
+    labels = prompt.clone()
+    labels[:, :42 + P * P] = -100
+    labels[labels >= 32000] = -100
+    torch.cuda.reset_peak_memory_stats(device)
+    tr = RegionTrainer(model, lr=2e-5, train_projector=True)
+    tr.step(prompt, images, boxes, labels)
+    tr.step(prompt, images, boxes, labels)
+    losses = []
+
+    def step():
+        losses.append(tr.step(prompt, images, boxes, labels))
+    dt_local = replicas.timed_steps(step, args.train_steps, torch.cuda.synchronize, dist)
+    regions = sum(n_i)
+    tot, dt = replicas.aggregate(regions * args.train_steps, dt_local, dist, device=agg_device)
+    tot = int(round(tot))
+    out = {"what": "stage-1 step (SURVEY.md 8d config 3): forward + hand-written backward + exchange + clip + fused AdamW",
+           "batch_per_gpu": B, "tokens_per_sequence": int(prompt.size(1)), "regions_per_step_all_ranks": tot // max(1, args.train_steps),
+           "steps": args.train_steps, "ms_per_step": round(1e3 * dt / args.train_steps, 2),
+           "images_per_s": round(B * world * args.train_steps / dt, 2),
+           "region_tokens_trained_per_s": round(tot / dt, 1), "peak_mem_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
+           "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
+           "exchange": None if tr.reducer is None else {"algo": tr.reducer.algo, "buckets": tr.reducer.describe(),
+                                                        "overlapped_with_backward": True}}
+    return out
 
 
 def main():
@@ -157,6 +248,8 @@ def main():
     counter = {"i": 0}
     # host-side request preparation happens once, outside the launch sequence (RoI table, offsets)
     reqs = [c.prepare_boxes(boxes, args.image_size) for c in ctxs]
+
+    torch.set_grad_enabled(False)        # inference (app.py runs under torch.inference_mode): no autograd seam, no host sync
 
     def eager(i):
         return ctxs[i](input_ids=prompt, images=image, bboxes=reqs[i])      # logits [1, T, V] fp32
@@ -266,6 +359,26 @@ def main():
         decode = {"ms_per_token": round(1e3 * dtd, 3), "tokens_per_s": round(1.0 / dtd, 1),
                   "weight_stream_GBps": round(wbytes / dtd / 1e9, 1), "note": "batch 1, KV cache, one hipGraph replay per token (token id and position stay on the device)"}
 
+    vit = None
+    if rank == 0 and not args.no_roofline:
+        try:
+            vit = vit_roofline(model, args, device)
+        except Exception as ex:
+            vit = {"error": repr(ex)}
+        if roofline is not None:
+            roofline["vit"] = vit
+    train = None
+    if args.train_steps > 0:
+        try:
+            del graphs, ctxs, reqs                       # release the captured inference pools before training
+            last.clear()
+            torch.cuda.empty_cache()
+            train = train_leg(args, model, ids, device, rank, world, dist, device if backend == "nccl" else "cpu")
+        except Exception as ex:                                      # never lose the headline
+            train = {"error": repr(ex)}
+            if dist is not None:
+                raise
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -293,7 +406,7 @@ def main():
                        "parallelism": f"replicas x{world} (no data-path collective); {len(ctxs)} batch-1 requests in "
                                       f"flight per GPU on separate HIP streams",
                        "valid": args.llama_layers == 32 and args.image_size == 336 and args.rois == 32},
-            "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "train": train, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -66,10 +66,13 @@ __global__ __launch_bounds__(256) void sample_advance_kernel(const float* __rest
   philox4x32_10((uint32_t)st, 0u, 0u, 0u, (uint32_t)sd, (uint32_t)(sd >> 32), r4);
   const float u = (float)(r4[0] >> 8) * (1.0f / 16777216.0f);        // 24-bit uniform in [0, 1)
   int choice = -1;
-  if (top_k >= 1 && top_k < N) {
+  const int k_eff = top_k < N ? top_k : N;   // HF: top_k = min(top_k, vocabulary)
+  uint32_t kth = 0;                          // order key of the k-th largest logit (0: every token kept)
+  bool use_list = false;
+  if (top_k >= 1 && (k_eff < N || N <= LIST_CAP)) {
     // ---- k-th largest logit by MSB radix select on the order-preserving key (ties with the k-th are all kept, as
     //      HF's TopKLogitsWarper does: scores < kth are removed) ----
-    if (tid == 0) { sel_prefix = 0; sel_mask = 0; sel_k = (unsigned)top_k; }
+    if (tid == 0) { sel_prefix = 0; sel_mask = 0; sel_k = (unsigned)k_eff; }
     for (int pass = 3; pass >= 0; --pass) {
       hist[tid] = 0;
       __syncthreads();
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void sample_advance_kernel(const float* __rest
       }
       __syncthreads();
     }
-    const uint32_t kth = sel_prefix;
+    kth = sel_prefix;
     if (tid == 0) list_n = 0;
     __syncthreads();
     for (int i = tid; i < N; i += 256) {
@@ -107,8 +110,11 @@ __global__ __launch_bounds__(256) void sample_advance_kernel(const float* __rest
       }
     }
     __syncthreads();
-    if (tid == 0) {
-      int n = (int)(list_n < (unsigned)LIST_CAP ? list_n : (unsigned)LIST_CAP);
+    // more than LIST_CAP tokens tie at the k-th logit (degenerate rows, e.g. constant logits): the kept set does not
+    // fit the list -> chunked draw over the tokens with key >= kth below (top_p is not applied in that case)
+    use_list = list_n <= (unsigned)LIST_CAP;
+    if (use_list && tid == 0) {
+      int n = (int)list_n;
       // ascending vocabulary order (insertion sort: n ~ top_k)
       for (int a = 1; a < n; ++a) {
         const int ii = list_idx[a];
@@ -145,12 +151,14 @@ __global__ __launch_bounds__(256) void sample_advance_kernel(const float* __rest
       }
       if (choice < 0) choice = last;
     }
-  } else {
-    // ---- every token kept: chunked inverse CDF in ascending vocabulary order ----
+  }
+  if (!use_list) {
+    // ---- chunked inverse CDF in ascending vocabulary order over the tokens with key >= kth (kth = 0: all) ----
     const int chunk = (N + 255) / 256;
     const int c0 = tid * chunk, c1 = min(N, c0 + chunk);
     double s = 0.0;
-    for (int i = c0; i < c1; ++i) s += (double)expf((logits[i] - m) * inv_temp);
+    for (int i = c0; i < c1; ++i)
+      if (order_key(logits[i]) >= kth) s += (double)expf((logits[i] - m) * inv_temp);
     chunk_sum[tid] = s;
     __syncthreads();
     if (tid == 0) {
@@ -164,11 +172,16 @@ __global__ __launch_bounds__(256) void sample_advance_kernel(const float* __rest
         acc += chunk_sum[c];
       }
       const int b0 = c * chunk, b1 = min(N, b0 + chunk);
-      choice = b1 - 1 >= 0 ? b1 - 1 : 0;
+      choice = -1;
       for (int i = b0; i < b1; ++i) {
+        if (order_key(logits[i]) < kth) continue;
+        choice = i;                       // the last kept token seen: the fallback if rounding leaves acc <= target
         acc += (double)expf((logits[i] - m) * inv_temp);
-        if (acc > target) { choice = i; break; }
+        if (acc > target) break;
       }
+      if (choice < 0)                     // rounding pushed the target past the last chunk: the last kept token
+        for (int i = N - 1; i >= 0; --i)
+          if (order_key(logits[i]) >= kth) { choice = i; break; }
     }
   }
   if (tid == 0) {
@@ -190,8 +203,8 @@ extern "C" int g4r_sample_advance_f32(const float* logits, int N, float temperat
   G4R_REQUIRE(N > 0 && temperature > 0.f, "sample_advance: N > 0 and temperature > 0");
   G4R_REQUIRE(top_p > 0.f && top_p <= 1.f, "sample_advance: top_p in (0, 1]");
   G4R_REQUIRE(top_k >= 0 && top_k <= LIST_CAP, "sample_advance: top_k in [0, 1024] (0 = disabled)");
-  if (top_p < 1.f && !(top_k >= 1 && top_k < N))
-    return g4r_note_error(G4R_ERR_UNSUPPORTED, "sample_advance: top_p < 1 needs top_k in [1, 1024]");
+  if (top_p < 1.f && !(top_k >= 1 && (top_k < N || N <= LIST_CAP)))
+    return g4r_note_error(G4R_ERR_UNSUPPORTED, "sample_advance: top_p < 1 needs top_k in [1, 1024] (below the vocabulary size)");
   hipLaunchKernelGGL(sample_advance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, N, 1.0f / temperature,
                      top_k, top_p, seed, tok, out_ids, step, pos, max_steps, u_out);
   G4R_CHECK_LAUNCH("sample_advance");

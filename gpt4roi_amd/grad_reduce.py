@@ -45,7 +45,12 @@ class GradBucketReducer:
     parameter as its gradient is produced (any order); reducer.finish() -> {param: averaged grad view}."""
 
     def __init__(self, params, bucket_bytes=256 << 20, group=None, comm_dtype=None, average=True,
-                 trainable_only=True):
+                 trainable_only=True, algo="rs_ag"):
+        """algo: "rs_ag" = reduce_scatter_tensor + all_gather_into_tensor in place (every xGMI link carries 1/world of
+        the bucket in each phase; the default on every backend, so the gloo tests execute the code RCCL runs), or
+        "all_reduce" = one all-reduce per bucket (the measured alternative)."""
+        assert algo in ("rs_ag", "all_reduce")
+        self.algo = algo
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
@@ -102,7 +107,7 @@ class GradBucketReducer:
             self._reduce(b)
 
     def _reduce(self, b):
-        if self.backend == "nccl":
+        if self.algo == "rs_ag":
             # direct algorithm over all xGMI links: reduce-scatter then all-gather, in place
             shard = b.flat.numel() // self.world
             rank = dist.get_rank(self.group)
@@ -111,7 +116,7 @@ class GradBucketReducer:
             if self.average:
                 mine.div_(self.world)
             dist.all_gather_into_tensor(b.flat, mine, group=self.group)
-        else:                                             # gloo: plain all-reduce
+        else:
             dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.average:
                 b.flat.div_(self.world)

@@ -32,6 +32,9 @@ _SIGS = {
     "g4r_gather_rows_bf16": [P, P, P, c_int, c_int, c_long, c_long, P],
     "g4r_scatter_add_rows_f32": [P, P, P, c_int, c_int, c_long, c_long, P],
     "g4r_adamw_f32": [P, P, c_int, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P],
+    "g4r_multi_sumsq": [P, P, P, P, c_int, c_int, P, P, P],
+    "g4r_multi_adamw_f32": [P, P, P, P, P, P, P, P, c_int, c_int, P, c_float, c_float, c_float, c_float, c_float, c_float,
+                            c_float, c_int, P],
     "g4r_groupnorm_stats_nhwc_bf16": [P, P, P, c_int, c_int, c_int, c_int, c_float, P],
     "g4r_gn_relu_bwd_nhwc_bf16": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "g4r_fuse_shuffle_bwd_nhwc_bf16": [P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P],
@@ -711,6 +714,89 @@ def adamw(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e
                               _p(param_bf16), param.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
                               float(weight_decay), int(step), float(grad_scale), _stream(param),),
             tag="g4r_adamw_f32")
+
+
+class MultiTensorAdamW:
+    """clip_grad_norm_ + AdamW over a fixed list of fp32 master tensors in two launches (include/g4r_train.h:
+    g4r_multi_sumsq / g4r_multi_adamw_f32).  The pointer table of the masters / moments / bf16 copies is built once; the
+    gradient pointers are re-uploaded only when they change (they are stable when the bucketed reducer owns them)."""
+    CHUNK = 4096
+
+    def __init__(self, params, bf16_copies=None, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = list(params)
+        _f32(*self.params)
+        for p in self.params:
+            assert p.is_contiguous()
+        dev = self.params[0].device
+        self.device = dev
+        self.copies = list(bf16_copies) if bf16_copies is not None else [None] * len(self.params)
+        for p, c in zip(self.params, self.copies):
+            if c is not None:
+                _bf16(c)
+                assert c.is_contiguous() and c.numel() == p.numel()
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.steps = 0
+        i64 = lambda xs: torch.tensor(xs, dtype=torch.int64, device=dev)  # noqa: E731
+        self._p = i64([p.data_ptr() for p in self.params])
+        self._m = i64([t.data_ptr() for t in self.exp_avg])
+        self._v = i64([t.data_ptr() for t in self.exp_avg_sq])
+        self._pb = i64([c.data_ptr() if c is not None else 0 for c in self.copies])
+        numel = [p.numel() for p in self.params]
+        self._numel = i64(numel)
+        starts = [0]
+        for n in numel:
+            starts.append(starts[-1] + -(-n // self.CHUNK))
+        self.n_chunks = starts[-1]
+        self._starts = torch.tensor(starts, dtype=torch.int32, device=dev)
+        self._partial = torch.empty(max(self.n_chunks, 1), dtype=torch.float64, device=dev)
+        self.total_sq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._g_key, self._g, self._gflag = None, None, None
+
+    def _grad_table(self, grads):
+        key = tuple((g.data_ptr(), g.dtype) for g in grads)
+        if key != self._g_key:
+            for g, p in zip(grads, self.params):
+                assert g.is_cuda and g.is_contiguous() and g.numel() == p.numel() and g.dtype in (torch.float32, torch.bfloat16)
+            self._g = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64, device=self.device)
+            self._gflag = torch.tensor([int(g.dtype == torch.bfloat16) for g in grads], dtype=torch.int32, device=self.device)
+            self._g_key = key
+        return self._g, self._gflag
+
+    def grad_norm_sq(self, grads):
+        """Device fp64 [1]: sum of squares over every gradient (no host sync)."""
+        g, flag = self._grad_table(grads)
+        _launch("g4r_multi_sumsq", (_p(g), _p(self._numel), _p(flag), _p(self._starts), len(self.params), self.n_chunks,
+                                    _p(self._partial), _p(self.total_sq), _stream(self.total_sq)), tag="g4r_multi_sumsq")
+        return self.total_sq
+
+    def step(self, grads, lr, max_grad_norm=None, pre_scale=1.0):
+        """One update.  max_grad_norm > 0 clips by the global norm like torch.nn.utils.clip_grad_norm_ (computed and
+        applied on the device).  Returns the device tensor holding the squared gradient norm (before clipping)."""
+        grads = list(grads)
+        assert len(grads) == len(self.params)
+        clip = max_grad_norm is not None and max_grad_norm > 0
+        total = self.grad_norm_sq(grads) if clip else None
+        g, flag = self._grad_table(grads)
+        self.steps += 1
+        _launch("g4r_multi_adamw_f32", (_p(self._p), _p(g), _p(self._m), _p(self._v), _p(self._pb), _p(self._numel), _p(flag),
+                                        _p(self._starts), len(self.params), self.n_chunks, _p(total),
+                                        float(max_grad_norm) if clip else 0.0, float(pre_scale), float(lr),
+                                        float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                                        int(self.steps), _stream(self.params[0])), tag="g4r_multi_adamw_f32",
+                nbytes=float(sum(p.numel() for p in self.params)) * 30.0)
+        return total
+
+    def state_dict(self):
+        return dict(step=self.steps, exp_avg=[t.clone() for t in self.exp_avg], exp_avg_sq=[t.clone() for t in self.exp_avg_sq])
+
+    def load_state_dict(self, sd):
+        self.steps = int(sd["step"])
+        for dst, src in zip(self.exp_avg, sd["exp_avg"]):
+            dst.copy_(src)
+        for dst, src in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
+            dst.copy_(src)
 
 
 def linear_dgrad(dy, w_t, out=None, residual=None):

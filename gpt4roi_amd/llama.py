@@ -250,14 +250,21 @@ class LlamaDecoder:
         if st is None or st["out"].numel() < max_new:
             dev = self.device
             n = max(max_new, 64)
-            st = dict(tok=torch.zeros((1, 1), dtype=torch.int64, device=dev),
-                      pos=torch.zeros(1, dtype=torch.int32, device=dev),
-                      step=torch.zeros(1, dtype=torch.int32, device=dev),
-                      seed=torch.zeros(1, dtype=torch.int64, device=dev),
-                      u=torch.zeros(n, dtype=torch.float32, device=dev),
-                      out=torch.zeros(n, dtype=torch.int64, device=dev), graphs={})
+            # the state outlives the call: keep it an ordinary tensor even when the caller runs under inference_mode
+            # (app.py:285), or a later in-place update outside that mode would be refused
+            with torch.inference_mode(False):
+                st = self._new_decode_state(dev, n)
             self._dstate = st
         return st
+
+    @staticmethod
+    def _new_decode_state(dev, n):
+        return dict(tok=torch.zeros((1, 1), dtype=torch.int64, device=dev),
+                    pos=torch.zeros(1, dtype=torch.int32, device=dev),
+                    step=torch.zeros(1, dtype=torch.int32, device=dev),
+                    seed=torch.zeros(1, dtype=torch.int64, device=dev),
+                    u=torch.zeros(n, dtype=torch.float32, device=dev),
+                    out=torch.zeros(n, dtype=torch.int64, device=dev), graphs={})
 
     def _advance(self, logits_row, st, sampler):
         """Token selection on the device: argmax (generate(do_sample=False)) or one temperature / top-k / top-p draw
@@ -331,8 +338,11 @@ class LlamaDecoder:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()      # capture records the launches, it does not run them
                 side = torch.cuda.Stream()
-                with torch.cuda.graph(g, stream=side):
-                    self._decode_step_device(st, sampler)
+                # capture outside inference_mode even if the caller is inside it (app.py:285): torch's capture registers
+                # generator state tensors, which must stay ordinary tensors for later captures in the process
+                with torch.inference_mode(False), torch.no_grad():
+                    with torch.cuda.graph(g, stream=side):
+                        self._decode_step_device(st, sampler)
                 st["graphs"][key] = graph = g
         while end is None and done < max_new_tokens:
             n = min(check_every, max_new_tokens - done)

@@ -91,7 +91,7 @@ class _RegionPathFn(torch.autograd.Function):
             dl[:, :dec.vocab] = dlogits.reshape(B * T, dec.vocab)
             grads = model.backward(ctx.pctx, dl, train_projector=any(n.startswith("mm_projector.") for n in ctx.names))
         ctx.pctx = None
-        return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
+        return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
 
 class _ShiftedCrossEntropyFn(torch.autograd.Function):
@@ -250,9 +250,13 @@ class SPILlavaLlamaModel(nn.Module):
             images = torch.stack(list(images), 0)
         keep = tower.forward(images)
         image_features, mlvl = tower.select(keep)
+        if bboxes is None:
+            bboxes = [images.new_zeros((0, 4)) for _ in range(B)]
         if not isinstance(bboxes, PreparedBoxes):
             bboxes = PreparedBoxes(bboxes, images.size(-1), images.device)
-        spi, sctx = self.spi_module.forward_train(mlvl, bboxes)
+        # a batch without any region still trains the projector (the reference keeps the graph alive with a dummy zero
+        # term, layers.py:314-317 / spi_llava.py:94-108); the region module then simply receives no gradient
+        spi, sctx = self.spi_module.forward_train(mlvl, bboxes) if bboxes.n > 0 else (None, None)
         n_patch = image_features.size(1)
         img_tok = torch.empty((B, n_patch, self.llama.hidden), dtype=torch.bfloat16, device=images.device)
         for b in range(B):
@@ -288,6 +292,8 @@ class SPILlavaLlamaModel(nn.Module):
             if on_grad is not None:
                 for k in ("mm_projector.bias", "mm_projector.weight"):
                     on_grad(k, grads[k])
+        if ctx["sctx"] is None:
+            return grads
         idx_bbox = (flat == cfg.bbox_token).nonzero().flatten().to(torch.int32)
         assert idx_bbox.numel() == ctx["boxes"].n, "number of <bbox> tokens != number of regions"
         cb = (lambda k, g: on_grad(f"spi_module.{k}", g)) if on_grad is not None else None

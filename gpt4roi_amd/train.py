@@ -68,7 +68,7 @@ class RegionTrainer:
         for p in self.params.values():
             assert p.dtype == torch.float32 and p.is_contiguous()
             p.requires_grad_(True)
-        self.state = {k: (torch.zeros_like(p.data), torch.zeros_like(p.data)) for k, p in self.params.items()}
+        self.opt = K.MultiTensorAdamW([p.data for p in self.params.values()], None, betas, eps, weight_decay)
         self.steps = 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.reducer = GradBucketReducer(list(self.params.values()), bucket_bytes=bucket_bytes, group=group,
@@ -110,23 +110,33 @@ class RegionTrainer:
     # ---- exchange, clip, AdamW ---------------------------------------------------------------------------------
     @torch.no_grad()
     def apply(self, grads, lr=None, exchanged=False):
+        """clip_grad_norm_(max_grad_norm) + AdamW over every trainable tensor in two launches (kernels.MultiTensorAdamW):
+        the global norm and the clip coefficient stay on the device (`last_grad_norm` is a device tensor; reading it is
+        the only host sync, and nothing here does)."""
         names = list(self.params)
         if self.reducer is not None and not exchanged:
             grads = exchange_gradients(self.reducer, self.params, grads)
-        scale = 1.0
-        if self.max_grad_norm is not None and self.max_grad_norm > 0:
-            norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(grads[k]) for k in names]))
-            self.last_grad_norm = norm
-            scale = min(1.0, self.max_grad_norm / (float(norm) + 1e-6))      # torch.nn.utils.clip_grad_norm_
+        gl = [grads[k].reshape(self.params[k].shape) for k in names]
+        gl = [g if g.is_contiguous() else g.contiguous() for g in gl]
         self.steps += 1
-        lr = self.lr if lr is None else lr
-        for k in names:
-            p = self.params[k]
-            m_, v_ = self.state[k]
-            g = grads[k]
-            K.adamw(p.data, g.contiguous() if g.dtype == torch.float32 else g.float().contiguous(), m_, v_,
-                    self.steps, lr, self.betas, self.eps, self.weight_decay, grad_scale=scale)
+        total_sq = self.opt.step(gl, self.lr if lr is None else lr, self.max_grad_norm)
+        self.last_grad_norm = total_sq.sqrt() if total_sq is not None else None
         self.model.prepare()                                # refresh the bf16 kernel copies of the updated weights
+
+    def state_dict(self):
+        """Optimizer state under the reference's parameter names (resume: train.py:708-712 reloads optimizer.pt)."""
+        sd = self.opt.state_dict()
+        names = list(self._all_names())
+        return {"step": sd["step"], "exp_avg": dict(zip(names, sd["exp_avg"])), "exp_avg_sq": dict(zip(names, sd["exp_avg_sq"]))}
+
+    def load_state_dict(self, sd):
+        names = list(self._all_names())
+        self.opt.load_state_dict({"step": sd["step"], "exp_avg": [sd["exp_avg"][k] for k in names],
+                                  "exp_avg_sq": [sd["exp_avg_sq"][k] for k in names]})
+        self.steps = int(sd["step"])
+
+    def _all_names(self):
+        return self.params.keys()
 
     def step(self, input_ids, images, bboxes, labels, lr=None):
         loss, grads = self.loss_and_grads(input_ids, images, bboxes, labels, exchange=self.reducer is not None)
@@ -153,8 +163,12 @@ class FullTrainer(RegionTrainer):
         self.dec_live = {f"llama.{k}": v for k, v in dec.trainable_tensors().items()}
         # fp32 masters (norm weights are fp32 already and are their own master)
         self.dec_master = {k: (v if v.dtype == torch.float32 else v.float()) for k, v in self.dec_live.items()}
-        for k, v in self.dec_master.items():
-            self.state[k] = (torch.zeros_like(v), torch.zeros_like(v))
+        # ONE fused optimizer over the region module / projector parameters and the decoder masters; the decoder's bf16
+        # kernel tensors are written by the same kernel (no separate refresh pass)
+        masters = [p.data for p in self.params.values()] + list(self.dec_master.values())
+        copies = [None] * len(self.params) + [(self.dec_live[k] if self.dec_live[k].dtype == torch.bfloat16 else None)
+                                               for k in self.dec_master]
+        self.opt = K.MultiTensorAdamW(masters, copies, betas, eps, weight_decay)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.reducer = None
         if self.world > 1:
@@ -181,26 +195,19 @@ class FullTrainer(RegionTrainer):
             on_grad("llama.embed_tokens", ge)
         return grads
 
+    def _all_names(self):
+        return list(self.params) + list(self.dec_master)
+
     @torch.no_grad()
     def apply(self, grads, lr=None, exchanged=False):
         names = list(self.params) + list(self.dec_master)
         tensors = {**{k: p.data for k, p in self.params.items()}, **self.dec_master}
         if self.reducer is not None and not exchanged:
             grads = exchange_gradients(self.reducer, {**self.params, **self.dec_master}, grads)
-        scale = 1.0
-        if self.max_grad_norm is not None and self.max_grad_norm > 0:
-            norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(grads[k].float()) for k in names]))
-            self.last_grad_norm = norm
-            scale = min(1.0, self.max_grad_norm / (float(norm) + 1e-6))
+        gl = [grads[k].reshape(tensors[k].shape) for k in names]
+        gl = [g if g.is_contiguous() else g.contiguous() for g in gl]
         self.steps += 1
-        lr = self.lr if lr is None else lr
-        for k in names:
-            p = tensors[k]
-            m_, v_ = self.state[k]
-            g = grads[k].reshape(p.shape)
-            live = self.dec_live.get(k)
-            K.adamw(p, g.contiguous() if g.dtype == torch.float32 else g.float().contiguous(), m_, v_, self.steps, lr,
-                    self.betas, self.eps, self.weight_decay, grad_scale=scale,
-                    param_bf16=live if (live is not None and live.dtype == torch.bfloat16) else None)
+        total_sq = self.opt.step(gl, self.lr if lr is None else lr, self.max_grad_norm)
+        self.last_grad_norm = total_sq.sqrt() if total_sq is not None else None
         self.model.prepare()
         self.model.llama.refresh_transposes()

@@ -134,6 +134,25 @@ int g4r_roi_align_mlvl_nhwc_bwd_bf16(const void* dout, long lvl_stride, long pix
                                      const float* rois, int batch, int channels, int n_rois, int pooled_h,
                                      int pooled_w, int sampling_ratio, int aligned, void* stream);
 
+/*
+ * Multi-tensor clip + AdamW: the foreach that `torch.nn.utils.clip_grad_norm_` + `torch.optim.AdamW.step()` run under HF
+ * Trainer (gpt4roi/train/train.py:698-712), as two launches over a device-resident table of n_tensors tensors.
+ * Table arrays (device memory): *_ptrs = uint64 device addresses; numel [n]; g_is_bf16 [n] (gradient dtype per tensor);
+ * chunk_start [n + 1] = prefix sums of ceil(numel / 4096); n_chunks = chunk_start[n].
+ *   g4r_multi_sumsq     : total[0] = sum over every tensor of sum(grad^2) (fp64, fixed reduction order); `partial` is a
+ *                         workspace of n_chunks doubles.
+ *   g4r_multi_adamw_f32 : grad' = grad * pre_scale * min(1, max_norm / (pre_scale * sqrt(total_sq[0]) + 1e-6)) (max_norm <= 0
+ *                         or total_sq NULL: no clipping), then the AdamW update of g4r_adamw_f32 on p / m / v; pb_ptrs[i] != 0
+ *                         receives the bf16 copy the kernels read.  The clip coefficient is computed on the device: no
+ *                         host synchronisation between backward and update.
+ */
+int g4r_multi_sumsq(const void* g_ptrs, const long* numel, const int* g_is_bf16, const int* chunk_start, int n_tensors,
+                    int n_chunks, double* partial, double* total, void* stream);
+int g4r_multi_adamw_f32(const void* p_ptrs, const void* g_ptrs, const void* m_ptrs, const void* v_ptrs, const void* pb_ptrs,
+                        const long* numel, const int* g_is_bf16, const int* chunk_start, int n_tensors, int n_chunks,
+                        const double* total_sq, float max_norm, float pre_scale, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,169 @@
+"""GPU: the drop-in seams under autograd -- what the reference's training caller does
+(gpt4roi/train/train.py:698-712: HF Trainer.training_step = forward -> loss.backward() -> optimizer.step()) must run
+unchanged against the MI355X classes and give the step gpt4roi_amd/train.py::RegionTrainer gives."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from gpt4roi_amd import synthetic as syn
+    from gpt4roi_amd.layers import MLVLROIQueryModule
+    from gpt4roi_amd.llama import LlamaDecoder
+    from gpt4roi_amd.spi_llava import SPILlavaLlamaModel, SPILlavaMPTForCausalLM
+    from gpt4roi_amd.train import RegionTrainer
+    from gpt4roi_amd.vit import ClipVisionTower
+
+DEV = "cuda"
+
+
+def relerr(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return ((got - want).abs().max() / want.abs().max().clamp_min(1e-12)).item()
+
+
+def _mini(seed=0, layers=2, train_projector=True):
+    H, P, image = 512, 8, 112
+    ids = syn.token_ids(vocab_base=990)
+    tower = ClipVisionTower(syn.vit_state(H, 4 * H, 12, image, seed=8), heads=8, device=DEV)
+    dec = LlamaDecoder(syn.llama_state(512, 1408, layers, ids.vocab, seed=9), heads=4, max_positions=256, device=DEV,
+                       max_batch=2)
+    model = SPILlavaLlamaModel(tower, dec, ids, embed_dims=H)
+    model.spi_module.load_state_dict(syn.spi_state(model.spi_module, 3 + seed))
+    model.spi_module.to(DEV)
+    model.mm_projector.to(DEV)
+    for p in model.mm_projector.parameters():
+        p.requires_grad_(train_projector)
+    g = torch.Generator().manual_seed(21 + seed)
+    img = torch.randn(2, 3, image, image, generator=g).to(DEV)
+    boxes = [syn.boxes(3, g).to(DEV), syn.boxes(1, g).to(DEV)]
+    p0 = syn.prompt_ids(ids, P, 3, g, sys_len=5, question_len=6, vocab_base=990)
+    p1 = syn.prompt_ids(ids, P, 1, g, sys_len=5, question_len=6 + 8, vocab_base=990)
+    prompt = torch.stack([p0, p1]).to(DEV)
+    labels = prompt.clone()
+    labels[:, :7 + P * P] = -100
+    labels[labels >= 990] = -100
+    return model, ids, prompt, img, boxes, labels
+
+
+def test_training_step_through_autograd_equals_region_trainer():
+    """HF Trainer.training_step, spelled out: model.train(); loss = model(**batch).loss; loss.backward();
+    clip_grad_norm_; torch.optim.AdamW.step() -- against RegionTrainer.step on an identical second model."""
+    a, ids, prompt, img, boxes, labels = _mini()
+    b, *_ = _mini()
+    b.mm_projector.load_state_dict(a.mm_projector.state_dict())     # nn.Linear's default init is not seeded
+    lm = SPILlavaMPTForCausalLM(a)
+    lm.train()
+    attn = torch.ones_like(prompt)
+    out = lm(input_ids=prompt, attention_mask=attn, labels=labels, images=img, img_metas=[None, None], bboxes=boxes)
+    assert out.loss.requires_grad and out.logits.shape == (2, prompt.size(1), ids.vocab)
+    out.loss.backward()
+    named = {**{f"spi_module.{k}": p for k, p in a.spi_module.named_parameters()},
+             **{f"mm_projector.{k}": p for k, p in a.mm_projector.named_parameters()}}
+    assert all(p.grad is not None for p in named.values())
+    tr = RegionTrainer(b, lr=2e-5, max_grad_norm=1.0, train_projector=True)
+    loss_b, grads_b = tr.loss_and_grads(prompt, img, boxes, labels)
+    assert abs(out.loss.item() - loss_b.item()) <= 1e-5 * abs(loss_b.item())
+    for k, p in named.items():
+        assert relerr(p.grad, grads_b[k]) <= 1e-2, k            # the same kernels ran: equal up to the order of the
+                                                                # RoIAlign-backward atomics (bf16 re-rounding downstream)
+    # optimizer step: torch AdamW on the nn.Parameters vs the fused kernel of the trainer
+    torch.nn.utils.clip_grad_norm_(list(named.values()), 1.0)
+    opt = torch.optim.AdamW(list(named.values()), lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    tr.apply(grads_b, lr=2e-5)
+    for k, p in named.items():
+        assert relerr(p.detach(), tr.params[k].detach()) < 1e-4, k
+    # second step: the bf16 kernel copies must follow the optimizer's in-place update (parameter version stamps)
+    l2 = lm(input_ids=prompt, labels=labels, images=img, bboxes=boxes).loss
+    l2b, _ = tr.loss_and_grads(prompt, img, boxes, labels)
+    assert abs(l2.item() - l2b.item()) < 2e-3 * abs(l2b.item()), (l2.item(), l2b.item())
+    assert l2.item() != out.loss.item()
+
+
+def test_logits_seam_accepts_an_arbitrary_downstream_loss():
+    """Not only the built-in loss: any torch loss on the returned logits backpropagates into the parameters."""
+    a, ids, prompt, img, boxes, labels = _mini(seed=1)
+    lm = SPILlavaMPTForCausalLM(a)
+    logits = lm(input_ids=prompt, images=img, bboxes=boxes).logits
+    assert logits.requires_grad
+    shift = logits[:, :-1].reshape(-1, ids.vocab)
+    loss = torch.nn.functional.cross_entropy(shift, labels[:, 1:].reshape(-1), ignore_index=-100)
+    loss.backward()
+    g_torch = {k: p.grad.clone() for k, p in a.spi_module.named_parameters()}
+    a.zero_grad(set_to_none=True)
+    lm(input_ids=prompt, images=img, bboxes=boxes, labels=labels).loss.backward()
+    for k, p in a.spi_module.named_parameters():
+        # torch's CE gives fp32 dlogits, the fused kernel bf16 ones: agreement to bf16 rounding of the loss gradient
+        assert relerr(p.grad, g_torch[k]) < 3e-2, k
+
+
+def test_gradient_checkpointing_changes_memory_not_results():
+    a, ids, prompt, img, boxes, labels = _mini(seed=2, layers=3)
+    lm = SPILlavaMPTForCausalLM(a)
+    lm(input_ids=prompt, images=img, bboxes=boxes, labels=labels).loss.backward()
+    ref = {k: p.grad.clone() for k, p in a.spi_module.named_parameters()}
+    a.zero_grad(set_to_none=True)
+    lm.gradient_checkpointing_enable()
+    _, ctx = a.forward_train(prompt, img, boxes)
+    assert all(set(rec) == {"x"} for rec in ctx["lctx"]["saved"])           # only the layer inputs are kept
+    out = lm(input_ids=prompt, images=img, bboxes=boxes, labels=labels)
+    out.loss.backward()
+    for k, p in a.spi_module.named_parameters():
+        assert relerr(p.grad, ref[k]) <= 1e-2, k                 # recomputation is bit-identical; atomics order is not
+
+
+def test_region_module_seam_B2_under_autograd():
+    """MLVLROIQueryModule.forward(mlvl_feats, bboxes) (layers.py:218-236) with grad enabled: out.backward() fills the
+    module's .grad with what the explicit forward_train / backward pair returns; no_grad gives the inference result."""
+    C, P = 512, 8
+    m = MLVLROIQueryModule(embed_dims=C, out_dims=512, num_levels=4)
+    m.load_state_dict(syn.spi_state(m, 7))
+    m.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    feats = [torch.randn(2, P * P, C, generator=g).to(DEV).to(torch.bfloat16) for _ in range(4)]
+    boxes = [syn.boxes(2, g).to(DEV), syn.boxes(3, g).to(DEV)]
+    outs = m(feats, boxes)
+    assert [o.shape for o in outs] == [(2, 512), (3, 512)] and outs[0].requires_grad
+    d = torch.randn(5, 512, generator=g).to(DEV)
+    (torch.cat(outs).float() * d).sum().backward()
+    with torch.no_grad():
+        out2, ctx = m.forward_train(feats, boxes)
+        want = m.backward(ctx, d.to(torch.bfloat16))
+        inf = torch.cat(m(feats, boxes))
+    assert torch.equal(torch.cat(outs).detach(), out2)
+    assert relerr(inf, out2) < 1e-2                              # inference path: same maths, fused kernels
+    for k, p in m.named_parameters():
+        assert relerr(p.grad, want[k]) <= 1e-2, k
+    # an optimizer step invalidates the prepared bf16 buffers
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.05)
+        assert relerr(torch.cat(m(feats, boxes)), inf) > 1e-3
+
+
+def test_batch_without_regions_still_trains_the_projector():
+    a, ids, prompt, img, boxes, labels = _mini(seed=3)
+    P = 8
+    g = torch.Generator().manual_seed(4)
+    p0 = syn.prompt_ids(ids, P, 0, g, sys_len=5, question_len=9, vocab_base=990)[None].to(DEV)
+    lab = p0.clone()
+    lab[:, :7 + P * P] = -100
+    lm = SPILlavaMPTForCausalLM(a)
+    out = lm(input_ids=p0, images=img[:1], bboxes=[torch.zeros(0, 4, device=DEV)], labels=lab)
+    out.loss.backward()
+    assert a.mm_projector.weight.grad is not None and a.mm_projector.weight.grad.abs().sum() > 0
+    assert all(p.grad is None for p in a.spi_module.parameters())
+
+
+def test_malformed_training_batch_raises_like_the_reference():
+    a, ids, prompt, img, boxes, labels = _mini(seed=4)
+    lm = SPILlavaMPTForCausalLM(a)
+    bad = [boxes[0][:2], torch.cat([boxes[1], boxes[0][2:]])]       # totals match (2 + 2), per-sample counts do not
+    with pytest.raises(ValueError):
+        lm(input_ids=prompt, images=img, bboxes=bad, labels=labels)
+    left_padded = torch.ones_like(prompt)
+    left_padded[0, :3] = 0
+    with pytest.raises(ValueError):
+        lm(input_ids=prompt, attention_mask=left_padded, images=img, bboxes=boxes, labels=labels)

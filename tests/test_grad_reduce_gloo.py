@@ -28,12 +28,13 @@ def _grad(p_index, shape, rank, step):
     return torch.randn(shape, generator=g)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, algo="rs_ag"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         params = _params()
-        red = GradBucketReducer(params, bucket_bytes=4096)         # small buckets -> several of them
+        red = GradBucketReducer(params, bucket_bytes=4096, algo=algo)   # small buckets -> several of them
+        assert red.algo == algo
         desc = red.describe()
         results = []
         for step in range(2):
@@ -48,11 +49,17 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_two_ranks():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("algo", ["rs_ag", "all_reduce"])
+def test_bucketed_allreduce_two_ranks(algo):
+    """algo="rs_ag" is the branch RCCL runs on the node (in-place reduce_scatter_tensor into a view of its own input, then
+    all_gather_into_tensor); gloo executes the very same calls here.  Odd bucket sizes exercise the shard padding."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, algo)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])

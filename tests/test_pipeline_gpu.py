@@ -28,6 +28,14 @@ if torch.cuda.is_available():
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """This file checks the INFERENCE path (app.py runs it under torch.inference_mode, app.py:285); with grad enabled
+    the same calls would take the autograd seam (tests/test_autograd_gpu.py)."""
+    with torch.no_grad():
+        yield
+
+
 def relerr(got, want):
     got, want = got.float().cpu(), want.float().cpu()
     return ((got - want).abs().max() / want.abs().max().clamp_min(1e-6)).item()
@@ -250,7 +258,7 @@ def test_end_to_end_embeds_logits_and_greedy_ids():
         top2 = trace[k].topk(2).values
         pytest.fail(f"greedy ids diverge at step {k}: {got_ids} vs {want_ids}; margin {float(top2[0]-top2[1]):.2e}")
     gen = lm.generate(prompt.to(DEV), images=img.to(DEV), bboxes=[b.to(DEV) for b in boxes], max_new_tokens=4)
-    assert len(gen) == 4
+    assert gen.shape == (1, prompt.size(1) + 4) and torch.equal(gen[:, :prompt.size(1)].cpu(), prompt)
 
 
 def test_baseline_config0_full_size_vit_region_module_projector():

@@ -9,6 +9,7 @@ import time
 from types import SimpleNamespace
 
 import torch
+torch.set_grad_enabled(False)   # inference tool: no autograd seam
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -4,6 +4,7 @@ wave-quantisation tails?  (experiment; bench.py's headline stays single-stream u
 import copy, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+torch.set_grad_enabled(False)   # inference tool: no autograd seam
 import bench
 args = bench.parse()
 dev = "cuda:0"
