@@ -368,10 +368,13 @@ def main():
         if roofline is not None:
             roofline["vit"] = vit
     train = None
+    n_ctx, graph_ok = len(ctxs), all(g is not None for g in graphs)
     if args.train_steps > 0:
         try:
             del graphs, ctxs, reqs                       # release the captured inference pools before training
+            graph_error = last.get("graph_error")
             last.clear()
+            last["graph_error"] = graph_error
             torch.cuda.empty_cache()
             train = train_leg(args, model, ids, device, rank, world, dist, device if backend == "nccl" else "cpu")
         except Exception as ex:                                      # never lose the headline
@@ -395,15 +398,15 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "value_per_gpu": round(total_regions / dt / world, 2),
-            "in_flight_requests_per_gpu": len(ctxs), "hipMalloc_calls_in_timed_region": device_allocs_in_timed_region,
-            "hipgraph": all(g is not None for g in graphs), "hipgraph_error": last.get("graph_error"),
+            "in_flight_requests_per_gpu": n_ctx, "hipMalloc_calls_in_timed_region": device_allocs_in_timed_region,
+            "hipgraph": graph_ok, "hipgraph_error": last.get("graph_error"),
             "single_stream": {"ms_per_image": round(1e3 * dt_serial / args.steps, 3),
                               "region_tokens_per_s_per_gpu": round(args.rois * args.steps / dt_serial, 2)},
             "config": {"workload": f"configs[1]: 1x{args.image_size}^2 image, {args.rois} RoIs, batch 1 per GPU, "
                                    f"ViT-L/14(23 blocks) + SPI(P={P}) + LLaMA-7B({args.llama_layers} layers) prefill "
                                    f"T={prompt.size(1)} with full logits",
                        "image_size": args.image_size, "rois_per_image": args.rois, "prompt_tokens": int(prompt.size(1)),
-                       "parallelism": f"replicas x{world} (no data-path collective); {len(ctxs)} batch-1 requests in "
+                       "parallelism": f"replicas x{world} (no data-path collective); {n_ctx} batch-1 requests in "
                                       f"flight per GPU on separate HIP streams",
                        "valid": args.llama_layers == 32 and args.image_size == 336 and args.rois == 32},
             "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "train": train, "kernels": kernels,

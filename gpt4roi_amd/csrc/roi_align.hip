@@ -669,6 +669,100 @@ __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_bwd_kernel(MlvlGradAr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the fused multi-level NHWC RoIAlign WITHOUT atomics (round 2): the transpose of the forward written as
+// a GATHER per output texel row.  workgroup = (level, image, map row y, tile of 48 columns, chunk of 256 channels);
+// thread = one channel.  The workgroup walks the RoIs of its image; a RoI touches row y through the sample rows whose
+// y_low or y_high equals y (weight hy / ly, the separable taps of roi_align_cuda_kernel.cuh:141-148), and each such
+// bin row folds its PW x sr horizontal samples into the LDS row buffer S[x][c] -- every S[.][c] is only ever touched
+// by the thread that owns channel c, so there is no race and no atomic.  After the last RoI the row tile is written
+// once: every texel of every gradient map is stored exactly once (texels under no RoI get their 0 here: the maps need
+// no zero-fill), the summation order is fixed (bit-reproducible, unlike the reference's atomicAdd order), and HBM sees
+// one coalesced fp32 write per texel instead of a read-modify-write per corner tap.
+// ---------------------------------------------------------------------------------------------
+#define MLVL_GATHER_TW 48
+#define MLVL_GATHER_CH 256
+
+__global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_bwd_gather_kernel(
+    MlvlGradArgs a, const float* __restrict__ rois, const int* __restrict__ roi_offsets, const bf16_t* __restrict__ dout,
+    long lvl_stride, long pix_stride, int L, int B, int C, int N, int PH, int PW, int sr, int aligned) {
+  __shared__ float S[MLVL_GATHER_TW * MLVL_GATHER_CH];
+  __shared__ Tap1D<float> xtab[MLVL_MAX_XTAB];
+  __shared__ float wrow[MLVL_MAX_XTAB];     // per bin row ph: summed vertical weight of its samples onto map row y
+  __shared__ int any_row;
+  const int tid = threadIdx.x;
+  // block -> (level, image, row, column tile)
+  int r = blockIdx.x, l = 0, tiles = 1;
+  for (; l < L; ++l) {
+    tiles = (a.W[l] + MLVL_GATHER_TW - 1) / MLVL_GATHER_TW;
+    const int nb = B * a.H[l] * tiles;
+    if (r < nb) break;
+    r -= nb;
+  }
+  if (l >= L) return;
+  const int H = a.H[l], W = a.W[l];
+  const int xt = r % tiles, y = (r / tiles) % H, b = r / (tiles * H);
+  const int x0 = xt * MLVL_GATHER_TW;
+  const int tw = min(MLVL_GATHER_TW, W - x0);
+  const int c = blockIdx.y * MLVL_GATHER_CH + tid;
+  const bool ch_ok = c < C;
+  for (int i = tid; i < MLVL_GATHER_TW * MLVL_GATHER_CH; i += 256) S[i] = 0.f;
+  const float inv_count = 1.f / (float)(sr * sr);
+  const int n0 = roi_offsets ? roi_offsets[b] : 0, n1 = roi_offsets ? roi_offsets[b + 1] : N;
+  for (int n = n0; n < n1; ++n) {
+    const RoiGeom<float> g = roi_geometry<float>(rois + (size_t)5 * n, a.scale[l], aligned, PH, PW, sr);
+    if (g.batch != b) continue;                       // uniform across the workgroup
+    __syncthreads();                                  // the previous RoI's tables are no longer read
+    if (tid == 0) any_row = 0;
+    __syncthreads();
+    if (tid < PH) {
+      float w = 0.f;
+      for (int iy = 0; iy < sr; ++iy) {
+        const Tap1D<float> ty = make_tap1d<float>(sample_coord<float>(g.start_h, g.bin_h, tid, iy, sr), H);
+        if (!ty.valid) continue;
+        const float ly = ty.frac, hy = 1.f - ly;
+        if (ty.lo == y) w += hy;
+        if (ty.hi == y) w += ly;
+      }
+      wrow[tid] = w;
+      if (w != 0.f) any_row = 1;
+    }
+    for (int i = tid - 64; i >= 0 && i < PW * sr; i += 192)
+      xtab[i] = make_tap1d<float>(sample_coord<float>(g.start_w, g.bin_w, i / sr, i % sr, sr), W);
+    __syncthreads();
+    if (!any_row || !ch_ok) continue;
+    const bf16_t* dn = dout + (size_t)l * lvl_stride + (size_t)n * PH * PW * pix_stride + c;
+    for (int ph = 0; ph < PH; ++ph) {
+      const float wy = wrow[ph];
+      if (wy == 0.f) continue;
+      const float wq = wy * inv_count;
+      for (int pw = 0; pw < PW; ++pw) {
+        float d = 0.f;
+        bool loaded = false;
+        for (int ix = 0; ix < sr; ++ix) {
+          const Tap1D<float> tx = xtab[pw * sr + ix];
+          if (!tx.valid) continue;
+          const int xl = tx.lo - x0, xh = tx.hi - x0;
+          const bool in_l = xl >= 0 && xl < tw, in_h = xh >= 0 && xh < tw;
+          if (!in_l && !in_h) continue;
+          if (!loaded) {
+            d = bf16_to_f32(dn[((size_t)ph * PW + pw) * pix_stride]) * wq;
+            loaded = true;
+          }
+          const float lx = tx.frac, hx = 1.f - lx;
+          if (in_l) S[xl * MLVL_GATHER_CH + tid] += hx * d;
+          if (in_h) S[xh * MLVL_GATHER_CH + tid] += lx * d;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (!ch_ok) return;
+  float* gm = a.grad[l] + (((size_t)b * H + y) * W + x0) * C + c;
+  for (int x = 0; x < tw; ++x) gm[(size_t)x * C] = S[x * MLVL_GATHER_CH + tid];
+}
+
 template <typename TI>
 int launch_mlvl(const void* const* feats, const float* const* affines, const int* heights, const int* widths, const float* scales,
                 int levels, const float* rois, void* output, int B, int C, int N, int PH, int PW,
@@ -802,6 +896,37 @@ int g4r_roi_align_mlvl_nhwc_bwd_bf16(const void* dout, long lvl_stride, long pix
                      (const bf16_t*)dout, lvl_stride, pix_stride, levels, batch, channels, n_rois, pooled_h, pooled_w,
                      sampling_ratio, aligned);
   G4R_CHECK_LAUNCH("roi_align_mlvl_nhwc_bwd");
+  return G4R_OK;
+}
+
+int g4r_roi_align_mlvl_nhwc_bwd_gather_bf16(const void* dout, long lvl_stride, long pix_stride, float* const* grads,
+                                            const int* heights, const int* widths, const float* scales, int levels,
+                                            const float* rois, const int* roi_offsets, int batch, int channels,
+                                            int n_rois, int pooled_h, int pooled_w, int sampling_ratio, int aligned,
+                                            void* stream) {
+  G4R_REQUIRE(levels > 0 && levels <= G4R_MAX_LEVELS, "roi_align_mlvl_bwd_gather: 1..8 levels");
+  G4R_REQUIRE(channels > 0 && (channels % 8) == 0, "roi_align_mlvl_bwd_gather: channels must be a multiple of 8");
+  G4R_REQUIRE(pooled_h > 0 && pooled_w > 0 && batch > 0 && n_rois >= 0, "roi_align_mlvl_bwd_gather: bad shape");
+  if (sampling_ratio <= 0 || sampling_ratio > MLVL_MAX_YTAB || pooled_w * sampling_ratio > MLVL_MAX_XTAB ||
+      pooled_h > MLVL_MAX_XTAB || pooled_h > 256)
+    return g4r_note_error(G4R_ERR_UNSUPPORTED, "roi_align_mlvl_bwd_gather: needs 0 < sampling_ratio <= 16, PW*sr <= 256, PH <= 256");
+  G4R_REQUIRE(grads && heights && widths && scales && (n_rois == 0 || (dout && rois)), "roi_align_mlvl_bwd_gather: null pointer");
+  MlvlGradArgs a;
+  long blocks = 0;
+  for (int l = 0; l < G4R_MAX_LEVELS; ++l) {
+    const int s = l < levels ? l : 0;
+    a.grad[l] = grads[s];
+    a.H[l] = heights[s];
+    a.W[l] = widths[s];
+    a.scale[l] = scales[s];
+    G4R_REQUIRE(grads[s] && heights[s] > 0 && widths[s] > 0, "roi_align_mlvl_bwd_gather: bad level");
+    if (l < levels) blocks += (long)batch * heights[s] * ((widths[s] + MLVL_GATHER_TW - 1) / MLVL_GATHER_TW);
+  }
+  G4R_REQUIRE(blocks < 2147483647L, "roi_align_mlvl_bwd_gather: grid too large");
+  hipLaunchKernelGGL(roi_align_mlvl_nhwc_bwd_gather_kernel, dim3((unsigned)blocks, (channels + MLVL_GATHER_CH - 1) / MLVL_GATHER_CH),
+                     dim3(256), 0, (hipStream_t)stream, a, rois, roi_offsets, (const bf16_t*)dout, lvl_stride, pix_stride,
+                     levels, batch, channels, n_rois, pooled_h, pooled_w, sampling_ratio, aligned);
+  G4R_CHECK_LAUNCH("roi_align_mlvl_nhwc_bwd_gather");
   return G4R_OK;
 }
 

@@ -43,6 +43,8 @@ _SIGS = {
     "g4r_nhwc_to_cm_padded_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_int, P],
     "g4r_roi_align_mlvl_nhwc_bwd_bf16": [P, c_long, c_long, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_int, P],
+    "g4r_roi_align_mlvl_nhwc_bwd_gather_bf16": [P, c_long, c_long, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int,
+                                                c_int, c_int, c_int, P],
     "g4r_layernorm_bf16": [P, P, P, P, c_int, c_int, c_long, c_long, c_float, c_int, P],
     "g4r_rmsnorm_bf16": [P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "g4r_groupnorm_affine_nhwc_bf16": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P],
@@ -875,8 +877,11 @@ def fuse_shuffle_bwd_gather(level, dinps):
     return out
 
 
-def roi_align_mlvl_bwd(dout, lvl_stride, pix_stride, grads, rois, output_size, scales, sampling_ratio=2, aligned=True):
-    """dout bf16 (any layout described by the two strides, see g4r_train.h); grads: list of fp32 NHWC maps."""
+def roi_align_mlvl_bwd(dout, lvl_stride, pix_stride, grads, rois, output_size, scales, sampling_ratio=2, aligned=True,
+                       roi_offsets=None, atomic=False):
+    """dout bf16 (any layout described by the two strides, see g4r_train.h); grads: list of fp32 NHWC maps.
+    Default: the atomic-free gather kernel -- every element of `grads` is written once (the maps may be uninitialised),
+    bit-reproducible.  atomic=True: the reference-style atomicAdd scatter into ZEROED maps (kept for A/B)."""
     _bf16(dout)
     L = len(grads)
     for g in grads:
@@ -892,10 +897,19 @@ def roi_align_mlvl_bwd(dout, lvl_stride, pix_stride, grads, rois, output_size, s
     ha = (c_int * L)(*[g.size(1) for g in grads])
     wa = (c_int * L)(*[g.size(2) for g in grads])
     sa = (c_float * L)(*[float(s) for s in scales])
-    _launch("g4r_roi_align_mlvl_nhwc_bwd_bf16", (_p(dout), int(lvl_stride), int(pix_stride), ctypes.cast(ga, P),
-                                                 ctypes.cast(ha, P), ctypes.cast(wa, P), ctypes.cast(sa, P), L,
-                                                 _p(rois), B, C, N, ph, pw, int(sampling_ratio), int(bool(aligned)),
-                                                 _stream(rois)), tag="roi_align_mlvl_nhwc_bwd")
+    nbytes = float(sum(g.numel() for g in grads) * 4 + L * N * ph * pw * C * 2)
+    if atomic:
+        _launch("g4r_roi_align_mlvl_nhwc_bwd_bf16", (_p(dout), int(lvl_stride), int(pix_stride), ctypes.cast(ga, P),
+                                                     ctypes.cast(ha, P), ctypes.cast(wa, P), ctypes.cast(sa, P), L,
+                                                     _p(rois), B, C, N, ph, pw, int(sampling_ratio), int(bool(aligned)),
+                                                     _stream(rois)), tag="roi_align_mlvl_nhwc_bwd", nbytes=nbytes)
+        return
+    if roi_offsets is not None:
+        assert roi_offsets.dtype == torch.int32 and roi_offsets.numel() == B + 1 and roi_offsets.is_cuda
+    _launch("g4r_roi_align_mlvl_nhwc_bwd_gather_bf16", (
+        _p(dout), int(lvl_stride), int(pix_stride), ctypes.cast(ga, P), ctypes.cast(ha, P), ctypes.cast(wa, P),
+        ctypes.cast(sa, P), L, _p(rois), _p(roi_offsets), B, C, N, ph, pw, int(sampling_ratio), int(bool(aligned)),
+        _stream(rois)), tag="roi_align_mlvl_nhwc_bwd_gather", nbytes=nbytes)
 
 
 def conv3x3_dgrad_weight(ws):

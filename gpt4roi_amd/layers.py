@@ -390,10 +390,12 @@ class MlvlRoIExtractor(BaseRoIExtractor):
             g[f'pconvs.{l}.bias'] = db if l == 0 else db.clone()
             g[f'pconvs.{l}.weight'] = self._pplan.wgrad(ctx['roi_feats'][l], d_pre)
         d_roi = K.conv3x3(d_pre, K.conv3x3_dgrad_weight([c.weight.detach() for c in self.pconvs]))  # [N,oh,ow,L*C]
-        d_maps = [torch.zeros(sh, dtype=torch.float32, device=dev) for sh in ctx['shapes']]
+        # the gather kernel writes every texel once: no zero-fill, no atomics, fixed summation order
+        d_maps = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx['shapes']]
         rl = self.roi_layers[0]
         K.roi_align_mlvl_bwd(d_roi, C, L * C, d_maps, prep.rois5, rl.output_size,
-                             [l.spatial_scale for l in self.roi_layers], rl.sampling_ratio, rl.aligned)
+                             [l.spatial_scale for l in self.roi_layers], rl.sampling_ratio, rl.aligned,
+                             roi_offsets=prep.offsets)
         return g, d_maps
 
 

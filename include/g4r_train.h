@@ -135,6 +135,20 @@ int g4r_roi_align_mlvl_nhwc_bwd_bf16(const void* dout, long lvl_stride, long pix
                                      int pooled_w, int sampling_ratio, int aligned, void* stream);
 
 /*
+ * The same gradient WITHOUT atomics: gather per (level, image, map row, 48-column tile, 256-channel chunk) over the RoIs
+ * of that image (g4r_roi_align_mlvl_nhwc_bwd_bf16 above keeps the reference's atomicAdd scatter,
+ * roi_align_cuda_kernel.cuh:141-148,197-204).  Every element of every gradient map is WRITTEN exactly once -- the maps
+ * need no zero-fill -- in a fixed summation order (bit-reproducible).  roi_offsets (nullable): int32 [batch + 1], the
+ * RoIs of image b are rows roi_offsets[b] .. roi_offsets[b+1]-1 (RoIs grouped by image, as layers.py:295-302 builds
+ * them); NULL = scan all n_rois and test the batch index.
+ */
+int g4r_roi_align_mlvl_nhwc_bwd_gather_bf16(const void* dout, long lvl_stride, long pix_stride, float* const* grads,
+                                            const int* heights, const int* widths, const float* scales, int levels,
+                                            const float* rois, const int* roi_offsets, int batch, int channels,
+                                            int n_rois, int pooled_h, int pooled_w, int sampling_ratio, int aligned,
+                                            void* stream);
+
+/*
  * Multi-tensor clip + AdamW: the foreach that `torch.nn.utils.clip_grad_norm_` + `torch.optim.AdamW.step()` run under HF
  * Trainer (gpt4roi/train/train.py:698-712), as two launches over a device-resident table of n_tensors tensors.
  * Table arrays (device memory): *_ptrs = uint64 device addresses; numel [n]; g_is_bf16 [n] (gradient dtype per tensor);

@@ -74,7 +74,8 @@ def test_training_step_through_autograd_equals_region_trainer():
     opt.zero_grad(set_to_none=True)
     tr.apply(grads_b, lr=2e-5)
     for k, p in named.items():
-        assert relerr(p.detach(), tr.params[k].detach()) < 1e-4, k
+        assert relerr(p.detach(), tr.params[k].detach()) < 1e-3, k       # first Adam step ~ lr * sign(g): noise-level
+                                                                         # gradient entries may flip between the two runs
     # second step: the bf16 kernel copies must follow the optimizer's in-place update (parameter version stamps)
     l2 = lm(input_ids=prompt, labels=labels, images=img, bboxes=boxes).loss
     l2b, _ = tr.loss_and_grads(prompt, img, boxes, labels)

@@ -317,11 +317,12 @@ def test_roi_align_full_size_properties():
     ones = K.roi_align_mlvl([torch.full_like(a, 1.5) for a in x], rois, 14, scales)
     assert float((ones - 1.5).abs().max()) < 1e-5                     # every sample of these boxes is inside the map
     w = torch.randn(fx.shape, generator=g).to(torch.bfloat16).to(DEV)    # [L, N, 14, 14, C]
-    grads = [torch.zeros_like(a) for a in x]
-    K.roi_align_mlvl_bwd(w, w.stride(0), w.stride(3), grads, rois, 14, scales, 2, True)
     lhs = float((fx.double() * w.double()).sum())
-    rhs = float(sum((a.double() * gr.double()).sum() for a, gr in zip(x, grads)))
-    assert abs(lhs - rhs) < 2e-6 * float(fx.double().norm() * w.double().norm()), (lhs, rhs)
+    for atomic in (False, True):       # the atomic-free gather (default; writes every texel: NaN-poisoned start) and the scatter
+        grads = [torch.zeros_like(a) if atomic else torch.full_like(a, float("nan")) for a in x]
+        K.roi_align_mlvl_bwd(w, w.stride(0), w.stride(3), grads, rois, 14, scales, 2, True, atomic=atomic)
+        rhs = float(sum((a.double() * gr.double()).sum() for a, gr in zip(x, grads)))
+        assert abs(lhs - rhs) < 2e-6 * float(fx.double().norm() * w.double().norm()), (atomic, lhs, rhs)
     # and the bf16 production kernel agrees with the fp32 instantiation to bf16 rounding
     fb = K.roi_align_mlvl([a.to(torch.bfloat16) for a in x], rois, 14, scales)
     fr = K.roi_align_mlvl([a.to(torch.bfloat16).float() for a in x], rois, 14, scales)

@@ -332,13 +332,28 @@ def test_roi_align_mlvl_backward():
     rois = torch.tensor([[0, 3.3, 4.1, 30.2, 25.7], [1, 10.0, 2.0, 75.0, 70.0], [0, -3.0, -2.0, 9.0, 12.0],
                          [1, 20.5, 20.5, 21.0, 23.0], [0, 0.0, 0.0, 47.9, 47.9]], dtype=torch.float32)
     dout = rnd(N, 7, 7, L * C, seed=83)
-    grads = [torch.zeros((B, s, s, C), dtype=torch.float32, device=DEV) for s in sizes]
+    # gather kernel (default): every texel is WRITTEN once -> start from NaN-poisoned maps; bit-reproducible
+    grads = [torch.full((B, s, s, C), float("nan"), dtype=torch.float32, device=DEV) for s in sizes]
     K.roi_align_mlvl_bwd(dout, C, L * C, grads, rois.to(DEV), 7, scales, 2, True)
+    again = [torch.full((B, s, s, C), float("nan"), dtype=torch.float32, device=DEV) for s in sizes]
+    K.roi_align_mlvl_bwd(dout, C, L * C, again, rois.to(DEV), 7, scales, 2, True)
+    # the reference-style atomic scatter (kept for A/B) into zeroed maps
+    atom = [torch.zeros((B, s, s, C), dtype=torch.float32, device=DEV) for s in sizes]
+    K.roi_align_mlvl_bwd(dout, C, L * C, atom, rois.to(DEV), 7, scales, 2, True, atomic=True)
+    # RoIs grouped by image + per-image offsets (what the region module passes)
+    order = torch.tensor([0, 2, 4, 1, 3])
+    offs = torch.tensor([0, 3, 5], dtype=torch.int32, device=DEV)
+    grouped = [torch.full((B, s, s, C), float("nan"), dtype=torch.float32, device=DEV) for s in sizes]
+    K.roi_align_mlvl_bwd(dout[order.to(DEV)].contiguous(), C, L * C, grouped, rois[order].to(DEV), 7, scales, 2, True,
+                         roi_offsets=offs)
     from oracle import roi_align as RO
     for l in range(L):
         g = dout[..., l * C:(l + 1) * C].float().cpu().permute(0, 3, 1, 2).contiguous().numpy()
         want = RO.backward(g, rois.numpy(), (B, C, sizes[l], sizes[l]), 7, scales[l], 2, "avg", True)
+        assert torch.isfinite(grads[l]).all() and torch.equal(grads[l], again[l])
         assert relerr(grads[l].permute(0, 3, 1, 2), torch.from_numpy(want)) < 1e-5, l
+        assert relerr(atom[l].permute(0, 3, 1, 2), torch.from_numpy(want)) < 1e-5, l
+        assert relerr(grouped[l], grads[l]) < 1e-6, l
 
 
 @pytest.mark.parametrize("rounds", [1, 2])

@@ -2,7 +2,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/r2d; mkdir -p $O
-timeout 1800 python -m pytest tests/test_generation_gpu.py tests/test_autograd_gpu.py tests/test_train_gpu.py -q -m gpu > $O/pytest.log 2>&1
+timeout 1800 python -m pytest tests/test_autograd_gpu.py tests/test_train_gpu.py tests/test_kernels_gpu.py -q -m gpu -k "autograd or train or roi_align" > $O/pytest.log 2>&1
 echo "pytest rc $?" >> $O/pytest.log
 grep -E "passed|failed|rc |^FAILED|^E  " $O/pytest.log | tail -30 | cut -c1-220
 timeout 900 python bench.py --steps 10 --warmup 3 > $O/bench.log 2> $O/bench.err
@@ -20,7 +20,7 @@ except Exception as e:
     print("bench parse failed", e)
 PY
 # rocprof stats + counter passes of the serial, eager bench (kernel-trace only)
-BENCH="python bench.py --steps 2 --warmup 1 --streams 1 --no-graph --no-cpu-baseline --train-steps 0 --decode-tokens 0 --no-roofline"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --streams 1 --no-graph --no-cpu-baseline --train-steps 0 --decode-tokens 0 --no-roofline"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof_stats --output-format csv -- $BENCH ) > $O/prof_stats.log 2>&1
 ( cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $GRAFT_REPO_ROOT/$O/pmc_mfma --output-format csv -- $BENCH ) > $O/pmc_mfma.log 2>&1
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/$O/pmc_fetch --output-format csv -- $BENCH ) > $O/pmc_fetch.log 2>&1
