@@ -64,6 +64,76 @@ class ToyTokenizer:
         return out
 
 
+class HFToyTokenizer:
+    """HF call signature for the prompt functions (train.py:125-148): tokenizer(text | [texts], return_tensors='pt',
+    padding='longest', max_length=..., truncation=True).input_ids; a BOS id in front of EVERY tokenisation (as LLaMA's
+    tokenizer does -- the reference's span arithmetic depends on it), special tokens split out of running text, ids handed
+    out on first sight."""
+    SPECIALS = ['<im_start>', '<im_end>', '<im_patch>', '<bbox>', '<point>', '<image>']
+
+    def __init__(self, model_max_length=512):
+        self.vocab = {'<pad>': 0, '<s>': 1}
+        self.pad_token_id, self.bos_token_id = 0, 1
+        self.model_max_length = model_max_length
+
+    def _ids(self, text):
+        import re
+        out = [self.bos_token_id]
+        pat = '(' + '|'.join(re.escape(t) for t in self.SPECIALS) + ')'
+        for piece in re.split(pat, text):
+            for w in ([piece] if piece in self.SPECIALS else piece.split()):
+                out.append(self.vocab.setdefault(w, len(self.vocab)))
+        return out[:self.model_max_length]
+
+    def __call__(self, text, return_tensors=None, padding=None, max_length=None, truncation=None):
+        rows = [self._ids(t) for t in ([text] if isinstance(text, str) else text)]
+        n = max(len(r) for r in rows)
+        ids = torch.tensor([r + [self.pad_token_id] * (n - len(r)) for r in rows], dtype=torch.int64)
+        return types.SimpleNamespace(input_ids=ids)
+
+
+def prompt_cases():
+    return [
+        [{'from': 'human', 'value': '<image>\nWhat is in region1 <bbox> and region2 <bbox> ?'},
+         {'from': 'gpt', 'value': 'A cat sits next to a dog .'},
+         {'from': 'human', 'value': 'What colour is region1 <bbox> ?'},
+         {'from': 'gpt', 'value': 'It is black .'}],
+        [{'from': 'human', 'value': 'Describe <bbox> briefly .\n<image>'},
+         {'from': 'gpt', 'value': 'A red car .'}],
+    ]
+
+
+def run_ref_prompt():
+    """preprocess_multimodal + preprocess of gpt4roi/train/train.py on the cases above (its module-level imports of the
+    trainer and of llava.model are stubs; llava/conversation.py is the reference's own file)."""
+    conv = _import(f"{REF}/llava/conversation.py", "llava.conversation", {})
+    llava_pkg = types.ModuleType("llava")
+    llava_pkg.conversation = conv
+    model_pkg = types.ModuleType("llava.model")
+    model_pkg.__all__ = []
+    trainer = types.ModuleType("gpt4roi.train.llava_trainer")
+    trainer.LLaVATrainer = object
+    mod = _import(f"{REF}/gpt4roi/train/train.py", "ref_train",
+                  {"llava": llava_pkg, "llava.conversation": conv, "llava.model": model_pkg,
+                   "gpt4roi": types.ModuleType("gpt4roi"), "gpt4roi.train": types.ModuleType("gpt4roi.train"),
+                   "gpt4roi.train.llava_trainer": trainer})
+    out = []
+    for front in (False, True):
+        for use_se in (True, False):
+            tok = HFToyTokenizer()
+            import copy
+            src = copy.deepcopy(prompt_cases())
+            if front:
+                src = [s for s in src if '<image>' in s[0]['value']]
+            cfg = dict(is_multimodal=True, sep_image_conv_front=front, use_im_start_end=use_se)
+            src = mod.preprocess_multimodal(src, cfg, 4)
+            texts = [[t['value'] for t in s] for s in copy.deepcopy(src)]
+            d = mod.preprocess(src, tok)
+            out.append(dict(front=front, use_im_start_end=use_se, after_multimodal=texts,
+                            input_ids=[t.tolist() for t in d['input_ids']], labels=[t.tolist() for t in d['labels']]))
+    return out
+
+
 def toy_tokenizer():
     return ToyTokenizer(["<unk>", "<s>", "</s>"] + [f"w{i}" for i in range(20)] + ["###", "stop"])
 
@@ -248,6 +318,6 @@ if __name__ == "__main__":
                         **{f"target::{k}": v.numpy() for k, v in target.items()})
     with open(os.path.join(HERE, "setup_ref.json"), "w") as f:
         json.dump(dict(token_ids=ids, tokenizer_len=n_tok, stopping=run_ref_stopping(),
-                       prepare_inputs=run_ref_prepare_inputs()), f, indent=1)
+                       prepare_inputs=run_ref_prepare_inputs(), prompt=run_ref_prompt()), f, indent=1)
     print("token ids", ids, "len", n_tok)
     print("wrote setup_ref.npz / setup_ref.json")

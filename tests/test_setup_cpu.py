@@ -187,3 +187,35 @@ def test_sampling_config_and_mask_validation():
     check_right_padded(torch.tensor([[1, 1, 1, 0], [1, 1, 1, 1]]))
     with pytest.raises(ValueError):
         check_right_padded(torch.tensor([[0, 1, 1, 1], [1, 1, 1, 1]]))
+
+
+def test_prompt_assembly_matches_the_reference(ref):
+    """preprocess_multimodal + preprocess (gpt4roi/train/train.py:185-208, 354-386) on two conversations, with and
+    without <im_start>/<im_end> and with the image moved to the front -- ids AND label masks equal to the reference's."""
+    import copy
+    from make_setup_golden import HFToyTokenizer, prompt_cases
+    from gpt4roi_amd import prompt as PR
+    _, meta = ref
+    assert len(meta["prompt"]) == 4
+    for case in meta["prompt"]:
+        tok = HFToyTokenizer()
+        src = copy.deepcopy(prompt_cases())
+        if case["front"]:
+            src = [s for s in src if '<image>' in s[0]['value']]
+        src = PR.preprocess_multimodal(src, dict(is_multimodal=True, sep_image_conv_front=case["front"],
+                                                 use_im_start_end=case["use_im_start_end"]), 4)
+        assert [[t['value'] for t in s] for s in src] == case["after_multimodal"]
+        out = PR.preprocess(src, tok)
+        assert [t.tolist() for t in out["input_ids"]] == case["input_ids"]
+        assert [t.tolist() for t in out["labels"]] == case["labels"]
+        assert any(v == PR.IGNORE_INDEX for v in case["labels"][0]) and any(v != PR.IGNORE_INDEX for v in case["labels"][0])
+    assert PR.region_question("what is <region1> and <2> next to <> ?") == "what is region1 <bbox> and region2 <bbox> next to <bbox> ?"
+    one = PR.build_sample(prompt_cases()[0], HFToyTokenizer(), 4)
+    assert one["input_ids"].dtype == torch.int64 and one["input_ids"].shape == one["labels"].shape
+    # the result goes straight into the collator of the batch contract
+    from gpt4roi_amd.data import DataCollatorForDetDataset
+    batch = DataCollatorForDetDataset(pad_token_id=0)([
+        dict(one, image=torch.zeros(3, 28, 28), bboxes=torch.zeros(2, 4), img_metas={}),
+        dict(PR.build_sample(prompt_cases()[1], HFToyTokenizer(), 4), image=torch.zeros(3, 28, 28), bboxes=torch.zeros(1, 4),
+             img_metas={})])
+    assert batch["input_ids"].shape == batch["labels"].shape and batch["input_ids"].size(0) == 2
