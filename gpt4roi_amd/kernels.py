@@ -249,7 +249,10 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
             return out
     if tile_cfg is None and splits == 1 and K >= 8192 and K % 64 == 0 and (-(-M // 256) * 256) <= 1.1 * M \
             and 32 <= -(-M // 256) * -(-N // 256) <= 64:
-        tile_cfg, splits = 24, 4       # LLaMA down_proj 767x4096x11008: 48 tiles x 4 K-slices, 101.5 us vs 110 (128x128 ring)
+        # LLaMA down_proj 767x4096x11008 (48 tiles of 256x256): 5 K-slices on the one-wave-per-SIMD kernel, 100.2 us
+        # (incl. the reduce) vs 110.4 for the ring ping-pong kernel x 4 slices and 115.3 for the 128x128 ring on the
+        # same box (tools/gemm_bench.cpp, profiles/r02_gemm_tiles.md)
+        tile_cfg, splits = 26, 5
     if tile_cfg is None:
         tile_cfg = pick_tile(M, N, K)
         if splits == 1 and tile_cfg == 4 and K >= 2048 and K % 64 == 0 and M > 1:

@@ -214,3 +214,66 @@ def test_config1_end_to_end_full_width_with_two_decoder_layers():
     with torch.no_grad():
         got = dec.greedy(spliced.to(DEV).to(torch.bfloat16), 16)
         _check_greedy(got, lb, lsd, spliced, 32, 16)
+
+
+# ------------------------------------------------------------------------------------------ configs[2] and configs[4] shapes
+def test_config3_shape_batch8_ragged_regions_full_width():
+    """BASELINE configs[2]: B = 8 images of 336^2 per GPU with 1..15 regions each (refcoco.py:55),
+    full-width ViT-L/14 + region module.  Every stage is per-image, so the batched launch sequence must
+    reproduce the eight single-image runs; two of the images are additionally checked against the CPU oracle."""
+    Hv, P, image, heads_v = 1024, 24, 336, 16
+    vsd = syn.vit_state(Hv, 4 * Hv, 24, image, seed=61)
+    tower = ClipVisionTower(vsd, heads=heads_v, device=DEV)
+    from gpt4roi_amd.layers import MLVLROIQueryModule
+    m = MLVLROIQueryModule(embed_dims=Hv, out_dims=4096, num_levels=4)
+    orc = S.MLVLROIQueryOracle(embed_dims=Hv, P=P)
+    sd = S.synthetic_state(orc, 62)
+    orc.load_state_dict(sd)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    g = torch.Generator().manual_seed(63)
+    B = 8
+    imgs = torch.randn(B, 3, image, image, generator=g)
+    n_i = torch.randint(1, 16, (B,), generator=g).tolist()
+    boxes = [syn.boxes(n, g) for n in n_i]
+    with torch.no_grad():
+        keep = tower.forward(imgs.to(DEV))
+        _, lv = tower.select(keep)
+        got = m(lv, [b.to(DEV) for b in boxes])
+        assert [t.shape for t in got] == [(n, 4096) for n in n_i]
+        for b in (0, 3, 7):
+            k1 = tower.forward(imgs[b:b + 1].to(DEV))
+            _, lv1 = tower.select(k1)
+            one = m(lv1, [boxes[b].to(DEV)])[0]
+            # not bit-equal: B changes the GEMM M (tile / split-K choice, fp32 summation order)
+            assert relerr(got[b], one) < 1.5e-2, (b, relerr(got[b], one))
+        vb = {k: bf(v) for k, v in vsd.items()}
+        for b in (2, 5):
+            hs = T.clip_vit_hidden_states(vb, imgs[b:b + 1], heads=heads_v, n_layers=23, emulate=True)
+            _, olv = T.select_spi_levels(hs + [hs[-1]], -2, 4)
+            want = orc(olv, [boxes[b]], emulate=True)[0]
+            e = relerr(got[b], want)
+            print(f"configs[2] shape, image {b} of the batch of 8 ({n_i[b]} regions): region tokens vs oracle {e:.4f}")
+            assert e < 3e-2
+
+
+def test_config5_shape_224_crops_64_regions_full_width():
+    """BASELINE configs[4]: the reference-native 224^2 shape (P = 16, layers.py:220-222) with 64
+    regions per image, full-width region module, against the CPU oracle with bf16 rounding points."""
+    Hv, P = 1024, 16
+    from gpt4roi_amd.layers import MLVLROIQueryModule
+    m = MLVLROIQueryModule(embed_dims=Hv, out_dims=4096, num_levels=4)
+    orc = S.MLVLROIQueryOracle(embed_dims=Hv, P=P)
+    sd = S.synthetic_state(orc, 71)
+    orc.load_state_dict(sd)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    feats, _ = S.synthetic_inputs(72, 1, P, Hv, [1])
+    g = torch.Generator().manual_seed(73)
+    boxes = [syn.boxes(64, g)]
+    with torch.no_grad():
+        got = m([f.to(DEV) for f in feats], [b.to(DEV) for b in boxes])[0]
+        want = orc([bf(f) for f in feats], boxes, emulate=True)[0]
+    e = relerr(got, want)
+    print(f"configs[4] shape (224^2, 64 regions, C = 1024): region tokens vs oracle {e:.4f}")
+    assert got.shape == (64, 4096) and e < 3e-2
