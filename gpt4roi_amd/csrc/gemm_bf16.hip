@@ -200,6 +200,136 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float16v (&acc)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Epilogue of the 256 x 256 kernels, staged through LDS (round 2).  In the swapped-operand accumulator layout a lane
+// owns ONE output row m and scattered column quads, so the direct epilogue above issues stores of 64 x 8 bytes on 32
+// different rows: every store instruction touches 32-64 cache lines with 8 bytes each.  Measured: ~20 us of a ~105 us
+// K = 4096 launch outside the K loop (profiles/r02_gemm_tiles.md).  Here each wave parks its accumulators (fp32, 64 rows at
+// a time) in its own slice of the -- now idle -- operand ring and reads them back ROW-major: 8 consecutive columns per
+// lane, WTN/8 lanes per row, so every store / bias / residual access is a whole 16-byte (bf16) or 32-byte (fp32) run of
+// one row and a wave instruction covers complete 128-byte lines.  The arithmetic and its order are those of
+// gemm_epilogue (bias -> activation -> residual -> one rounding), so results are bit-identical to the direct path.
+// ---------------------------------------------------------------------------------------------
+template <int TN, int PR = 64>
+struct EpiLds {
+  static constexpr int WTN = 32 * TN;            // wave-tile columns
+  static constexpr int RS = WTN * 4 + 16;        // row stride in bytes (fp32 row + 16 B: conflict-free b128 writes)
+  static constexpr int WAVE_BYTES = PR * RS;     // PR (32 or 64) rows per pass
+};
+
+template <int TM, int TN, int PR = 64>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, float16v (&acc)[TM][TN], char* wave_lds, int m_wave0,
+                                                  int n_wave0, int lane, int split) {
+  using E = EpiLds<TN, PR>;
+  constexpr int LPR = E::WTN / 8;                // lanes per row (8 columns each)
+  constexpr int RPI = 64 / LPR;                  // rows per wave instruction
+  constexpr int BPP = PR / 32;                   // 32-row accumulator blocks per pass
+  static_assert((TM * 32) % PR == 0 && PR % RPI == 0, "pass geometry");
+  const int wr = lane & 31, wh = lane >> 5;
+  const int rrow = lane / LPR, rcol = (lane % LPR) * 8;
+  const bool vec_n = (p.N & 7) == 0;
+  const bool swiglu = p.act == 4;
+#pragma unroll
+  for (int half = 0; half < TM / BPP; ++half) {
+    // ---- park PR rows: lane writes its 4-column quads (16-byte LDS stores, rows = lanes) ----
+#pragma unroll
+    for (int i2 = 0; i2 < BPP; ++i2)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float16v& c = acc[half * BPP + i2][j];
+          *reinterpret_cast<float4v*>(wave_lds + (i2 * 32 + wr) * E::RS + (j * 32 + q * 8 + wh * 4) * 4) =
+              float4v{c[q * 4], c[q * 4 + 1], c[q * 4 + 2], c[q * 4 + 3]};
+        }
+    // ---- read back row-major and finish ----
+#pragma unroll 2
+    for (int it = 0; it < PR / RPI; ++it) {
+      const int r = it * RPI + rrow;
+      const int m = m_wave0 + half * PR + r, n = n_wave0 + rcol;
+      const float4v a0 = *reinterpret_cast<const float4v*>(wave_lds + r * E::RS + rcol * 4);
+      const float4v a1 = *reinterpret_cast<const float4v*>(wave_lds + r * E::RS + rcol * 4 + 16);
+      if (m >= p.M || n >= p.N) continue;
+      float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const int nv = p.N - n < 8 ? p.N - n : 8;           // valid columns of this run
+      if (p.splits > 1) {
+        float* dst = p.ws + ((size_t)split * p.M + m) * p.N + n;
+        if (nv == 8 && vec_n) {
+          *reinterpret_cast<float4v*>(dst) = a0;
+          *reinterpret_cast<float4v*>(dst + 4) = a1;
+        } else {
+          for (int k = 0; k < nv; ++k) dst[k] = v[k];
+        }
+        continue;
+      }
+      if (p.bias) {
+        if (nv == 8 && vec_n) {
+          const float4v b0 = *reinterpret_cast<const float4v*>(p.bias + n), b1 = *reinterpret_cast<const float4v*>(p.bias + n + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        } else {
+          for (int k = 0; k < nv; ++k) v[k] += p.bias[n + k];
+        }
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] / (1.f + __expf(-1.702f * v[k]));
+      } else if (p.act == 3) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] / (1.f + __expf(-v[k]));
+      }
+      if (swiglu) {
+        // (gate, up) column pairs -> N/2 output columns (the launcher guarantees N % 4 == 0, bf16 out, no bias/residual)
+        bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + (n >> 1);
+        uint32_t w2[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float g0 = v[4 * k], u0 = v[4 * k + 1], g1 = v[4 * k + 2], u1 = v[4 * k + 3];
+          const float s0 = bf16lo(pack_bf16x2(g0 / (1.f + __expf(-g0)), 0.f));
+          const float s1 = bf16lo(pack_bf16x2(g1 / (1.f + __expf(-g1)), 0.f));
+          w2[k] = pack_bf16x2(s0 * u0, s1 * u1);
+        }
+        if (nv == 8 && (p.ldc & 3) == 0) {
+          *reinterpret_cast<uint2v*>(dst) = uint2v{w2[0], w2[1]};
+        } else {
+          *reinterpret_cast<uint32_t*>(dst) = w2[0];
+          if (nv > 4) *reinterpret_cast<uint32_t*>(dst + 2) = w2[1];
+        }
+        continue;
+      }
+      if (p.residual) {
+        const bf16_t* rp = p.residual + (size_t)m * p.ldr + n;
+        if (nv == 8 && vec_n && (p.ldr & 7) == 0) {
+          const uint4v rr = *reinterpret_cast<const uint4v*>(rp);
+          v[0] += bf16lo(rr.x); v[1] += bf16hi(rr.x); v[2] += bf16lo(rr.y); v[3] += bf16hi(rr.y);
+          v[4] += bf16lo(rr.z); v[5] += bf16hi(rr.z); v[6] += bf16lo(rr.w); v[7] += bf16hi(rr.w);
+        } else {
+          for (int k = 0; k < nv; ++k) v[k] += bf16_to_f32(rp[k]);
+        }
+      }
+      if (p.out_f32) {
+        float* dst = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+        if (nv == 8 && vec_n && (p.ldc & 3) == 0) {
+          *reinterpret_cast<float4v*>(dst) = float4v{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<float4v*>(dst + 4) = float4v{v[4], v[5], v[6], v[7]};
+        } else {
+          for (int k = 0; k < nv; ++k) dst[k] = v[k];
+        }
+      } else {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+        if (nv == 8 && vec_n && (p.ldc & 7) == 0) {
+          *reinterpret_cast<uint4v*>(dst) = uint4v{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                   pack_bf16x2(v[6], v[7])};
+        } else {
+          for (int k = 0; k < nv; ++k) dst[k] = f32_to_bf16(v[k]);
+        }
+      }
+    }
+  }
+}
+
 // STAGES == 2: double buffer, one __syncthreads per K tile, latency hidden by 2-3 co-resident
 //              workgroups per CU.
 // STAGES >= 3: ring of LDS buffers, STAGES-1 tiles of LDS-DMA in flight, counted s_waitcnt vmcnt
@@ -433,10 +563,9 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
     }
   }
 
-  // ---- epilogue.  D[i = n][j = m]: m = lane & 31, n = 8*(r>>2) + 4*(lane>>5) + (r&3) ----
-  const int em = lane & 31, en = 4 * (lane >> 5);
-  const int mw = m0 + wm * WTM + em, nw = n0 + wn * WTN + en;
-  gemm_epilogue<TM, TN>(p, acc, mw, nw, split);
+  // ---- epilogue through LDS (row-major, whole-line stores: see gemm_epilogue_lds), 32 rows per pass ----
+  __syncthreads();   // every wave has read its last fragments: the staging buffers are free
+  gemm_epilogue_lds<TM, TN, 32>(p, acc, smem + wave * EpiLds<TN, 32>::WAVE_BYTES, m0 + wm * WTM, n0 + wn * WTN, lane, split);
 }
 
 // split-K combine + epilogue: C = act(sum_s ws[s] + bias) + residual
@@ -802,8 +931,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     }
     if (grp == 0) G4R_PP_BARRIER();
   }
-  const int em = lane & 31, en = 4 * (lane >> 5);
-  gemm_epilogue<TM, TN>(p, acc, m0 + wm * 128 + em, n0 + wn * 64 + en, split);
+  __syncthreads();   // every wave is done with the operand ring: its space now stages the epilogue
+  gemm_epilogue_lds<TM, TN>(p, acc, smem + wave * EpiLds<TN>::WAVE_BYTES, m0 + wm * 128, n0 + wn * 64, lane, split);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1002,8 +1131,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     }
     if (grp == 0) G4R_PP_BARRIER();
   }
-  const int em = lane & 31, en = 4 * (lane >> 5);
-  gemm_epilogue<TM, TN>(p, acc, m0 + wm * 128 + em, n0 + wn * 64 + en, split);
+  __syncthreads();   // every wave is done with the operand ring: its space now stages the epilogue
+  gemm_epilogue_lds<TM, TN>(p, acc, smem + wave * EpiLds<TN>::WAVE_BYTES, m0 + wm * 128, n0 + wn * 64, lane, split);
 }
 
 
@@ -1223,9 +1352,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
     for (; i + 4 < nt; ++i) body(i, std::true_type{});
     for (; i < nt; ++i) body(i, std::false_type{});
   }
-  const int em = lane & 31, en = 4 * (lane >> 5);
-  gemm_epilogue<TM, TN, 0, 2>(p, acc, m0 + wm * 128 + em, n0 + wn * 128 + en, split);
-  gemm_epilogue<TM, TN, 2, 2>(p, acc, m0 + wm * 128 + em, n0 + wn * 128 + en, split);
+  __syncthreads();   // the operand ring is idle: stage the epilogue through it
+  gemm_epilogue_lds<TM, TN>(p, acc, smem + wave * EpiLds<TN>::WAVE_BYTES, m0 + wm * 128, n0 + wn * 128, lane, split);
 }
 
 template <int AMODE>
@@ -1239,7 +1367,8 @@ int launch_w4(GemmArgs& p, hipStream_t stream) {
   }
   p.tiles_m = g4r_ceil_div(p.M, 256);
   p.tiles_n = g4r_ceil_div(p.N, 256);
-  const size_t lds = 4 * (256 + 256) * 32 * 2;
+  const size_t ring = 4 * (256 + 256) * 32 * 2, epi = 4 * (size_t)EpiLds<4>::WAVE_BYTES;
+  const size_t lds = ring > epi ? ring : epi;
   auto kern = gemm_bf16_w4_kernel<AMODE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1271,7 +1400,8 @@ int launch_pp32(GemmArgs& p, hipStream_t stream) {
   }
   p.tiles_m = g4r_ceil_div(p.M, 256);
   p.tiles_n = g4r_ceil_div(p.N, 256);
-  const size_t lds = 4 * (256 + 256) * 32 * 2;
+  const size_t ring = 4 * (256 + 256) * 32 * 2, epi = 8 * (size_t)EpiLds<2>::WAVE_BYTES;
+  const size_t lds = ring > epi ? ring : epi;
   auto kern = gemm_bf16_pp32_kernel<AMODE, PROBE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1303,7 +1433,8 @@ int launch_pp(GemmArgs& p, hipStream_t stream) {
   }
   p.tiles_m = g4r_ceil_div(p.M, 256);
   p.tiles_n = g4r_ceil_div(p.N, 256);
-  const size_t lds = 2 * (256 + 256) * 64 * 2;
+  const size_t ring = 2 * (256 + 256) * 64 * 2, epi = 8 * (size_t)EpiLds<2>::WAVE_BYTES;
+  const size_t lds = ring > epi ? ring : epi;
   auto kern = gemm_bf16_pp_kernel<AMODE, PROBE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1335,7 +1466,8 @@ int launch_tile(GemmArgs& p, hipStream_t stream) {
   }
   p.tiles_m = g4r_ceil_div(p.M, BM);
   p.tiles_n = g4r_ceil_div(p.N, BN);
-  const size_t lds = (size_t)STAGES * (BM + BN) * BKT * 2;
+  const size_t ring = (size_t)STAGES * (BM + BN) * BKT * 2, epi = (size_t)WM * WN * EpiLds<BN / WN / 32, 32>::WAVE_BYTES;
+  const size_t lds = ring > epi ? ring : epi;
   auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, AMODE, GLDS, STAGES, BKT, STYLE>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -183,6 +183,22 @@ def test_gemm_epilogue(act):
     close(K.gemm(a, w, bias=bias, residual=res, act=act), ref, 0.05, 1e-2, f"epilogue {act}")
     close(K.gemm(a, w, bias=bias, residual=res, act=act, out_dtype=torch.float32), ref, 0.02, 2e-3, "f32 out")
     close(K.gemm(a, w, bias=bias, residual=res, act=act, splits=4), ref, 0.05, 1e-2, "split-K")
+    # the 256x256 kernels finish through LDS (row-major, whole-line stores): same arithmetic, bit-identical results to the
+    # direct epilogue of the 128-wide tiles on the same fp32 sums -- checked on ragged shapes too (N not a multiple of 8,
+    # strided output / residual, fp32 output, split-K partials)
+    for tile in (22, 24, 26):
+        close(K.gemm(a, w, bias=bias, residual=res, act=act, tile_cfg=tile), ref, 0.05, 1e-2, f"epilogue {act} tile {tile}")
+        close(K.gemm(a, w, bias=bias, residual=res, act=act, out_dtype=torch.float32, tile_cfg=tile), ref, 0.02, 2e-3,
+              f"f32 out tile {tile}")
+        close(K.gemm(a, w, bias=bias, residual=res, act=act, splits=3, tile_cfg=tile), ref, 0.05, 1e-2, f"split-K tile {tile}")
+        Nr = 203                                                    # ragged: runs of 8 are cut, rows are odd-strided
+        big = torch.zeros(M, 260, dtype=torch.bfloat16, device=DEV)
+        rr = rnd(M, 217, seed=40)[:, :Nr]
+        got = K.gemm(a, w[:Nr], bias=bias[:Nr], residual=rr, act=act, out=big[:, 5:5 + Nr], tile_cfg=tile)
+        xr = a.float() @ w[:Nr].float().t() + bias[:Nr]
+        xr = {None: xr, "relu": torch.relu(xr), "quick_gelu": xr * torch.sigmoid(1.702 * xr), "silu": F.silu(xr)}[act]
+        close(got, xr + rr.float(), 0.05, 1e-2, f"ragged N tile {tile}")
+        assert float(big[:, :5].abs().max()) == 0 and float(big[:, 5 + Nr:].abs().max()) == 0     # nothing outside the view
 
 
 def test_gemm_swiglu_epilogue():
