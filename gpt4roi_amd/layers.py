@@ -24,10 +24,11 @@ Differences from the reference, all parameterised and the reference's values the
   * the hard-wired 16x16 / 224 constants (layers.py:220-222, 289-291, 297) are derived from the
     input (P = sqrt(tokens), image side 14*P);
   * `out_dims` is honoured (the reference hard-codes Linear(1024, 4096) and ignores the argument);
-  * parameters are read under no_grad and converted once into kernel-ready buffers (`prepare()`); call
-    `prepare()` again after changing weights (the trainers do).  There is no autograd graph: training uses
-    `forward_train()` / `backward()` (hand-written backward of every stage, gradients returned under the
-    reference's state_dict keys and layouts; gpt4roi_amd/train.py drives them).
+  * parameters are converted into kernel-ready bf16 buffers (`prepare()`), re-derived automatically when a parameter
+    was written since (version stamps).  Training: `forward_train()` / `backward()` are the hand-written backward of
+    every stage (gradients under the reference's state_dict keys and layouts; gpt4roi_amd/train.py drives them), and
+    with grad enabled `forward()` wraps exactly that pair in an autograd node, so `out.backward()` fills `.grad` the
+    way autograd does for the reference.
 There is no CPU path: on a machine without the HIP library or a GPU the module raises.
 """
 import math
