@@ -973,6 +973,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   int t_end = t_begin + p.tiles_per_split;
   const int nt_total = p.K / BKT;
   if (t_end > nt_total) t_end = nt_total;
+  // PROBE (tools/pp32_probe3.py): every workgroup's wave 0 records entry / loop begin / loop end / exit (s_memtime) and
+  // its XCC id at ws + 16 + 8 * blockIdx.x  (int64)
+  long long* wg_stamps = reinterpret_cast<long long*>(p.ws) + 16 + 8 * (long)blockIdx.x;
+  const bool wg_probe = PROBE && blockIdx.y == 0 && wave == 0 && lane == 0;
+  if (PROBE) { if (wg_probe) { wg_stamps[0] = __builtin_amdgcn_s_memtime(); wg_stamps[4] = __builtin_amdgcn_s_getreg(6164); wg_stamps[5] = wall_clock64(); } }
 
   const bf16_t* a_src[NA];
   int a_y[NA], a_x[NA];
@@ -1099,6 +1104,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
       const int i = 0;
       G4R_PP32_STAMP(6);
     }
+    if (PROBE) { if (wg_probe) wg_stamps[1] = __builtin_amdgcn_s_memtime(); }
     for (int i = 0; i < nt; ++i) {
       const int buf = i & (RING - 1);
       G4R_PP32_STAMP(0);
@@ -1129,10 +1135,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
       const int i = 0;
       G4R_PP32_STAMP(7);
     }
+    if (PROBE) { if (wg_probe) wg_stamps[2] = __builtin_amdgcn_s_memtime(); }
     if (grp == 0) G4R_PP_BARRIER();
   }
   __syncthreads();   // every wave is done with the operand ring: its space now stages the epilogue
   gemm_epilogue_lds<TM, TN>(p, acc, smem + wave * EpiLds<TN>::WAVE_BYTES, m0 + wm * 128, n0 + wn * 64, lane, split);
+  if (PROBE) { if (wg_probe) { wg_stamps[3] = __builtin_amdgcn_s_memtime(); wg_stamps[6] = wall_clock64(); } }
 }
 
 

@@ -198,6 +198,23 @@ class FullTrainer(RegionTrainer):
     def _all_names(self):
         return list(self.params) + list(self.dec_master)
 
+    def state_dict(self):
+        """Optimizer moments (reference parameter names for the region module / projector, `llama.<kernel tensor>` for the
+        decoder) PLUS the decoder's fp32 master weights: `export_hf_state_dict()` only carries their bf16 roundings, so a
+        resume from it alone would lose the master precision."""
+        sd = super().state_dict()
+        sd["masters"] = {k: v.clone() for k, v in self.dec_master.items()}
+        return sd
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        for k, v in sd.get("masters", {}).items():
+            self.dec_master[k].copy_(v)
+            live = self.dec_live[k]
+            if live.dtype == torch.bfloat16:
+                live.copy_(v)                        # the kernels read the bf16 rounding of the master
+        self.model.llama.refresh_transposes()
+
     @torch.no_grad()
     def apply(self, grads, lr=None, exchanged=False):
         names = list(self.params) + list(self.dec_master)

@@ -382,6 +382,9 @@ def test_fuse_module_backward_isolated(rounds):
         assert relerr(y.permute(0, 3, 1, 2), ys[l].detach()) < 1e-2, l
         flips = ((y.permute(0, 3, 1, 2).cpu() > 0) != (ys[l].detach() > 0)).float().mean().item()
         print(f"rounds {rounds} level {l}: ReLU mask mismatches {flips:.2e}")
+        # the loose max-norm tolerances below are attributed to ReLU-mask flips between two bf16 pipelines: that rate itself
+        # is bounded here (identical inputs: a few 1e-4 observed), so a kernel bug cannot hide behind the explanation
+        assert flips < 2e-3, (l, flips)
     grads = m.backward(ctx, [d.permute(0, 2, 3, 1).contiguous().to(DEV) for d in d_y])
     ref = {k: v.grad for k, v in o.named_parameters()}
     assert set(grads) == set(ref)
