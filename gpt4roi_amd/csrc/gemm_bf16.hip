@@ -222,9 +222,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, float16v (&
                                                   int n_wave0, int lane, int split) {
   using E = EpiLds<TN, PR>;
   constexpr int LPR = E::WTN / 8;                // lanes per row (8 columns each)
-  constexpr int RPI = 64 / LPR;                  // rows per wave instruction
+  constexpr int RPI = 64 / LPR;                  // rows per wave instruction (WTN = 96: 5 rows, 4 lanes idle)
   constexpr int BPP = PR / 32;                   // 32-row accumulator blocks per pass
-  static_assert((TM * 32) % PR == 0 && PR % RPI == 0, "pass geometry");
+  constexpr int NIT = (PR + RPI - 1) / RPI;      // read-back iterations per pass
+  static_assert((TM * 32) % PR == 0, "pass geometry");
   const int wr = lane & 31, wh = lane >> 5;
   const int rrow = lane / LPR, rcol = (lane % LPR) * 8;
   const bool vec_n = (p.N & 7) == 0;
@@ -244,8 +245,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, float16v (&
         }
     // ---- read back row-major and finish ----
 #pragma unroll 2
-    for (int it = 0; it < PR / RPI; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int r = it * RPI + rrow;
+      if (rrow >= RPI || r >= PR) continue;      // idle lanes / the last, partial iteration (no barrier inside the loop)
       const int m = m_wave0 + half * PR + r, n = n_wave0 + rcol;
       const float4v a0 = *reinterpret_cast<const float4v*>(wave_lds + r * E::RS + rcol * 4);
       const float4v a1 = *reinterpret_cast<const float4v*>(wave_lds + r * E::RS + rcol * 4 + 16);
@@ -946,11 +948,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 //   waves 0-3:   read(t)+DMA(t+3)   MFMA(t)      read(t+1)+DMA(t+4)
 //   waves 4-7:   MFMA(t-1)          read(t)+DMA(t+3)   MFMA(t)
 // ---------------------------------------------------------------------------------------------
-template <int AMODE, bool PROBE = false>
+// BM x BN = 256 x 256 (wave tile 128 x 64) or 128 x 384 (wave tile 64 x 96: 6 x 32 = 192 workgroups for the LLaMA fused-qkv
+// shape 767 x 12288, where 256 x 256 tiles give only 144 of the 256 CUs a tile); both stage 32 KB per K tile = 4 LDS-DMA
+// pieces per wave, so the ring, the waits and the phase structure are identical.
+template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
-  constexpr int BM = 256, BN = 256, NW = 8, NT = 512, BKT = 32, RING = 4;
+  constexpr int NW = 8, NT = 512, BKT = 32, RING = 4;
   constexpr int ROWB = 64, SPR = 4;
-  constexpr int TM = 4, TN = 2;
+  constexpr int WTM = BM / 2, WTN = BN / 4;      // wave tile: 2 row groups (the two ping-pong groups) x 4 column slices
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(BM + BN == 512 && WTM % 32 == 0 && WTN % 32 == 0, "32 KB per K tile, 32x32 accumulator blocks");
   constexpr int NA = BM * SPR / NT, NB = BN * SPR / NT;  // 2 + 2 pieces per wave per K tile
   constexpr int A_BYTES = BM * BKT * 2, STAGE_BYTES = (BM + BN) * BKT * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // RING * STAGE_BYTES = 128 KB
@@ -1053,10 +1060,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int frow = lane & 31, fsw = (frow >> 2) & 3, fhi = lane >> 5;
-  const int a_row_off = (wm * 128 + frow) * ROWB;
-  const int b_row_off = (wn * 64 + frow) * ROWB;
+  const int a_row_off = (wm * WTM + frow) * ROWB;
+  const int b_row_off = (wn * WTN + frow) * ROWB;
   bf16x8 af[2][TM], wf[2][TN];
-  // the 12 fragment reads of a K tile (three chunks of four)
+  // the 2 x (TM + TN) fragment reads of a K tile in three chunks
   auto ldchunk = [&](int buf, int c) {
     const char* sa = smem + buf * STAGE_BYTES;
     const char* sb = sa + A_BYTES;
@@ -1068,10 +1075,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) wf[0][j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + s0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[1][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + s1);
+      for (int i = 0; i < TM / 2; ++i) af[1][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + s1);
     } else {
 #pragma unroll
-      for (int i = 2; i < TM; ++i) af[1][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + s1);
+      for (int i = TM / 2; i < TM; ++i) af[1][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + s1);
 #pragma unroll
       for (int j = 0; j < TN; ++j) wf[1][j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + s1);
     }
@@ -1139,7 +1146,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     if (grp == 0) G4R_PP_BARRIER();
   }
   __syncthreads();   // every wave is done with the operand ring: its space now stages the epilogue
-  gemm_epilogue_lds<TM, TN>(p, acc, smem + wave * EpiLds<TN>::WAVE_BYTES, m0 + wm * 128, n0 + wn * 64, lane, split);
+  constexpr int EPR = TN == 2 ? 64 : 32;     // rows per epilogue pass: 8 waves x pass must fit the 160 KB of LDS
+  gemm_epilogue_lds<TM, TN, EPR>(p, acc, smem + wave * EpiLds<TN, EPR>::WAVE_BYTES, m0 + wm * WTM, n0 + wn * WTN, lane, split);
   if (PROBE) { if (wg_probe) { wg_stamps[3] = __builtin_amdgcn_s_memtime(); wg_stamps[6] = wall_clock64(); } }
 }
 
@@ -1397,7 +1405,7 @@ int launch_w4(GemmArgs& p, hipStream_t stream) {
   return G4R_OK;
 }
 
-template <int AMODE, bool PROBE = false>
+template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256>
 int launch_pp32(GemmArgs& p, hipStream_t stream) {
   {
     const int nt = p.K / 32;
@@ -1406,11 +1414,12 @@ int launch_pp32(GemmArgs& p, hipStream_t stream) {
     p.tiles_per_split = g4r_ceil_div(nt, splits);
     p.splits = g4r_ceil_div(nt, p.tiles_per_split);
   }
-  p.tiles_m = g4r_ceil_div(p.M, 256);
-  p.tiles_n = g4r_ceil_div(p.N, 256);
-  const size_t ring = 4 * (256 + 256) * 32 * 2, epi = 8 * (size_t)EpiLds<2>::WAVE_BYTES;
+  p.tiles_m = g4r_ceil_div(p.M, BM);
+  p.tiles_n = g4r_ceil_div(p.N, BN);
+  constexpr int TN = BN / 4 / 32;
+  const size_t ring = 4 * (BM + BN) * 32 * 2, epi = 8 * (size_t)EpiLds<TN, (TN == 2 ? 64 : 32)>::WAVE_BYTES;
   const size_t lds = ring > epi ? ring : epi;
-  auto kern = gemm_bf16_pp32_kernel<AMODE, PROBE>;
+  auto kern = gemm_bf16_pp32_kernel<AMODE, PROBE, BM, BN>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1521,6 +1530,7 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 26: return launch_w4<AMODE>(p, stream);                                 // 256x256, 4 waves x (128x128): one wave per SIMD, K 32 ring of 4
     case 22: return launch_pp<AMODE>(p, stream);                                 // 256x256 ping-pong (4 barriers / K tile)
     case 24: return launch_pp32<AMODE>(p, stream);                               // 256x256 ping-pong, K 32 ring of 4
+    case 27: return launch_pp32<AMODE, false, 128, 384>(p, stream);              // 128x384 ring ping-pong (767 x 12288: 192 workgroups)
     case 25: return launch_pp32<AMODE, true>(p, stream);                         // same + s_memtime stamps (tools only)
     case 23: return launch_pp<AMODE, true>(p, stream);                           // same + s_memtime stamps into ws (tools only)
     default: return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");

@@ -776,13 +776,19 @@ class MultiTensorAdamW:
                                     _p(self._partial), _p(self.total_sq), _stream(self.total_sq)), tag="g4r_multi_sumsq")
         return self.total_sq
 
-    def step(self, grads, lr, max_grad_norm=None, pre_scale=1.0):
+    def step(self, grads, lr, max_grad_norm=None, pre_scale=1.0, total_sq=None):
         """One update.  max_grad_norm > 0 clips by the global norm like torch.nn.utils.clip_grad_norm_ (computed and
-        applied on the device).  Returns the device tensor holding the squared gradient norm (before clipping)."""
+        applied on the device).  Returns the device tensor holding the squared gradient norm (before clipping).
+        `total_sq` (device fp64 [1]) overrides the norm this object would compute: the sharded optimizer passes the
+        all-reduced sum over every rank's shards."""
         grads = list(grads)
         assert len(grads) == len(self.params)
         clip = max_grad_norm is not None and max_grad_norm > 0
-        total = self.grad_norm_sq(grads) if clip else None
+        if clip and total_sq is not None:
+            assert total_sq.dtype == torch.float64 and total_sq.is_cuda
+            total = total_sq
+        else:
+            total = self.grad_norm_sq(grads) if clip else None
         g, flag = self._grad_table(grads)
         self.steps += 1
         _launch("g4r_multi_adamw_f32", (_p(self._p), _p(g), _p(self._m), _p(self._v), _p(self._pb), _p(self._numel), _p(flag),

@@ -124,6 +124,21 @@ class LlamaDecoder:
         out["lm_head"] = self.lm_head
         return out
 
+    def rebind_tensor(self, name, tensor):
+        """Replace the tensor the kernels read for `name` (a key of trainable_tensors()) by `tensor` -- same shape, dtype
+        and values, different storage: the sharded optimizer moves every weight into its flat all-gather buckets."""
+        cur = self.trainable_tensors()[name]
+        assert tensor.shape == cur.shape and tensor.dtype == cur.dtype and tensor.is_contiguous()
+        if name == "embed_tokens":
+            self.embed = tensor
+        elif name == "norm":
+            self.norm = tensor
+        elif name == "lm_head":
+            self.lm_head = tensor
+        else:
+            li, nm = name.split(".")
+            self.layers[int(li)][nm] = tensor
+
     def export_hf_state_dict(self):
         """The HF-named state dict of the current weights (undoes the q|k|v fusion and the gate/up interleave)."""
         C = self.hidden
@@ -194,7 +209,8 @@ class LlamaDecoder:
         def emit(*names):
             if on_grad is not None:
                 for n in names:
-                    on_grad(n, grads[n])
+                    if on_grad(n, grads[n]):                # truthy = the consumer copied it (sharded buckets): free it now
+                        del grads[n]
         if tw:
             grads["lm_head"] = K.linear_wgrad(dlogits[:, :self.vocab], ctx["xn"])
             grads["norm"] = torch.zeros_like(self.norm)

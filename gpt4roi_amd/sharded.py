@@ -1,0 +1,187 @@
+"""Sharded optimizer state for stage 2: the memory strategy of the reference's FSDP launch
+(/root/reference/train_stage2.sh:51-52, `--fsdp "full_shard auto_wrap"`), rebuilt on the exchange this path already has.
+
+The reference shards parameters, gradients and optimizer state of every `LlamaDecoderLayer` over the ranks (ZeRO-3) because
+a 7 B replica with fp32 Adam state does not fit an 80 GB GPU.  On MI355X the bf16 replica (13.5 GB) and its fp32 gradients
+fit easily; what dominates is the fp32 master + Adam moments (12 B/param = 81 GB).  So this module shards exactly that
+(ZeRO-1/2 style) and keeps compute unsharded -- no parameter all-gather inside the forward/backward, i.e. no collective on
+the data path:
+
+    backward      gradients are copied into flat fp32 buckets as they are produced (reverse registration order); a full
+                  bucket is REDUCE-SCATTERED at once on the communication stream -> every rank owns 1/world of the
+                  averaged gradient of every bucket
+    norm          each rank sums the squares of ITS shards (g4r_multi_sumsq), one 8-byte all-reduce gives the global
+                  gradient norm for clip_grad_norm_; the value stays on the device
+    update        AdamW (g4r_multi_adamw_f32) on the owned shards only: fp32 master, exp_avg, exp_avg_sq exist only for
+                  the shard (12 B/param / world); the kernel writes the updated values straight into the rank's slice of
+                  the flat PARAMETER bucket (bf16 for the decoder matrices, fp32 for norms / region module / projector)
+    all-gather    every bucket's parameter slice is all-gathered IN PLACE: the live tensors the kernels read are views
+                  into those flat buckets, so the gathered bytes are the new weights -- no copy
+
+Traffic per step and rank: reduce-scatter of S fp32 gradient bytes + all-gather of S/2 (bf16) parameter bytes, against
+2 S for the plain gradient all-reduce; both phases use all 7 xGMI links (1/world of a bucket per peer).
+Backend agnostic (RCCL on the node; gloo in tests/test_sharded_gloo.py, which injects a torch AdamW as `update_fn` because
+the HIP kernels need a GPU -- the product default is the fused kernels and raises without them).
+"""
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+
+
+class _ShardBucket:
+    def __init__(self, entries, live_dtype, device, world, rank):
+        self.entries = entries                                   # [(name, live tensor)] in bucket order
+        self.live_dtype = live_dtype
+        self.numel = sum(t.numel() for _, t in entries)
+        pad = (-self.numel) % world
+        self.padded = self.numel + pad
+        self.shard = self.padded // world
+        self.lo = rank * self.shard
+        self.grad = torch.zeros(self.padded, dtype=torch.float32, device=device)
+        self.param = torch.zeros(self.padded, dtype=live_dtype, device=device)
+        self.gviews, self.pviews, off = [], [], 0
+        for _, t in entries:
+            n = t.numel()
+            self.gviews.append(self.grad[off:off + n].view(t.shape))
+            pv = self.param[off:off + n].view(t.shape)
+            pv.copy_(t)
+            self.pviews.append(pv)
+            off += n
+        mine_p = self.param[self.lo:self.lo + self.shard]
+        # fp32 master of the owned slice: the parameter slice itself when the live tensors are fp32
+        self.master = mine_p if live_dtype == torch.float32 else mine_p.float()
+        self.exp_avg = torch.zeros(self.shard, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(self.shard, dtype=torch.float32, device=device)
+        self.pending = len(entries)
+        self.event = None
+
+    @property
+    def grad_shard(self):
+        return self.grad[self.lo:self.lo + self.shard]
+
+    @property
+    def param_shard(self):
+        return self.param[self.lo:self.lo + self.shard]
+
+
+class ShardedAdamW:
+    """entries: [(name, live_tensor)] in REGISTRATION order (the reverse of the order the backward produces gradients).
+    `rebind(name, view)` is called once per entry with the view of the flat parameter bucket that replaces the live
+    tensor (same shape / dtype / values)."""
+
+    def __init__(self, entries, rebind, bucket_bytes=256 << 20, group=None, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, update_fn=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.update_fn = update_fn
+        self.steps = 0
+        device = entries[0][1].device
+        self.device = device
+        self.buckets, self.where = [], {}
+        for dtype in (torch.bfloat16, torch.float32):             # one dtype per bucket: the all-gather target IS the weights
+            cur, cur_bytes = [], 0
+            for name, t in reversed(entries):
+                if t.dtype != dtype:
+                    continue
+                cur.append((name, t))
+                cur_bytes += t.numel() * 4
+                if cur_bytes >= bucket_bytes:
+                    self.buckets.append(_ShardBucket(cur, dtype, device, self.world, self.rank))
+                    cur, cur_bytes = [], 0
+            if cur:
+                self.buckets.append(_ShardBucket(cur, dtype, device, self.world, self.rank))
+        assert sum(len(b.entries) for b in self.buckets) == len(entries), "bf16 / fp32 tensors only"
+        for b in self.buckets:
+            for i, (name, _) in enumerate(b.entries):
+                self.where[name] = (b, i)
+                rebind(name, b.pviews[i])
+        self.comm_stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+        self.total_sq = torch.zeros(1, dtype=torch.float64, device=device)
+        self._fused = None
+
+    # ---- memory accounting (what the sharding buys) ----------------------------------------------------------
+    def state_bytes(self):
+        """(optimizer-state bytes held by THIS rank, bytes an unsharded fp32 master + Adam state would take)."""
+        own = sum((0 if b.live_dtype == torch.float32 else b.shard * 4) + b.shard * 8 for b in self.buckets)
+        full = sum((0 if b.live_dtype == torch.float32 else b.numel * 4) + b.numel * 8 for b in self.buckets)
+        return own, full
+
+    # ---- gradient side ---------------------------------------------------------------------------------------------
+    def reset(self):
+        for b in self.buckets:
+            b.pending, b.event = len(b.entries), None
+
+    def ready(self, name, grad):
+        b, i = self.where[name]
+        b.gviews[i].copy_(grad.reshape(b.gviews[i].shape))
+        b.pending -= 1
+        if b.pending == 0 and self.world > 1:
+            self._async(lambda: self._reduce_scatter(b), b)
+        return True                                             # the gradient now lives in the bucket
+
+    def _async(self, fn, b):
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                fn()
+                b.event = torch.cuda.Event()
+                b.event.record()
+        else:
+            fn()
+
+    def _reduce_scatter(self, b):
+        dist.reduce_scatter_tensor(b.grad_shard, b.grad, op=dist.ReduceOp.SUM, group=self.group)
+        b.grad_shard.div_(self.world)
+
+    def _wait(self):
+        for b in self.buckets:
+            if b.pending != 0:
+                raise RuntimeError(f"{b.pending} gradients of a bucket were never reported ready")
+            if b.event is not None:
+                torch.cuda.current_stream(self.device).wait_event(b.event)
+                b.event = None
+
+    # ---- update ----------------------------------------------------------------------------------------------------
+    def step(self, lr, max_grad_norm=None):
+        """Global-norm clip + AdamW on the owned shards, then the in-place all-gather of every parameter bucket.
+        Returns the device tensor holding the squared global gradient norm (or None without clipping)."""
+        self._wait()
+        self.steps += 1
+        clip = max_grad_norm is not None and max_grad_norm > 0
+        shards_g = [b.grad_shard for b in self.buckets]
+        if self.update_fn is not None:                         # tests only: a torch restatement stands in for the kernels
+            total = None
+            if clip:
+                self.total_sq.copy_(sum((g.double() ** 2).sum() for g in shards_g).reshape(1))
+                if self.world > 1:
+                    dist.all_reduce(self.total_sq, group=self.group)
+                total = self.total_sq
+            for b in self.buckets:
+                self.update_fn(b, lr, self.steps, self.betas, self.eps, self.weight_decay, total, max_grad_norm)
+        else:
+            if self._fused is None:
+                self._fused = K.MultiTensorAdamW([b.master for b in self.buckets],
+                                                 [(b.param_shard if b.live_dtype == torch.bfloat16 else None)
+                                                  for b in self.buckets], self.betas, self.eps, self.weight_decay)
+                for b, m, v in zip(self.buckets, self._fused.exp_avg, self._fused.exp_avg_sq):
+                    m.copy_(b.exp_avg)
+                    v.copy_(b.exp_avg_sq)
+                    b.exp_avg, b.exp_avg_sq = m, v               # one copy of the moments, owned by the fused optimizer
+                self._fused.steps = self.steps - 1
+            f = self._fused
+            total = None
+            if clip:
+                total = f.grad_norm_sq(shards_g)                # sum over THIS rank's shards, on the device
+                if self.world > 1:
+                    dist.all_reduce(total, group=self.group)    # -> the global squared norm (8 bytes)
+            f.step(shards_g, lr, max_grad_norm if clip else None, total_sq=total)
+        if self.world > 1:
+            for b in self.buckets:
+                self._async(lambda b=b: dist.all_gather_into_tensor(b.param, b.param_shard, group=self.group), b)
+            self._wait()
+        return total if clip else None

@@ -20,6 +20,7 @@ import torch
 import torch.distributed as dist
 
 from . import kernels as K
+from .sharded import ShardedAdamW
 from .grad_reduce import GradBucketReducer
 from .layers import PreparedBoxes
 
@@ -228,3 +229,81 @@ class FullTrainer(RegionTrainer):
         self.last_grad_norm = total_sq.sqrt() if total_sq is not None else None
         self.model.prepare()
         self.model.llama.refresh_transposes()
+
+
+class ShardedFullTrainer(FullTrainer):
+    """Stage 2 with the optimizer state sharded over the data-parallel ranks (gpt4roi_amd/sharded.py; SURVEY.md 8f-3,
+    the role of `--fsdp "full_shard auto_wrap"` in train_stage2.sh:51-52).  Same forward/backward as FullTrainer; the
+    exchange is reduce-scatter(gradients) -> clip + AdamW on the owned 1/world slice -> in-place all-gather(parameters),
+    and the fp32 master / exp_avg / exp_avg_sq exist only for that slice: 81 GB -> 81/world GB for the 7B model, which is
+    what lets the per-GPU batch of config 4 grow instead of the optimizer state filling the HBM."""
+
+    def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
+                 bucket_bytes=256 << 20, update_fn=None):
+        RegionTrainer.__init__(self, model, lr, betas, eps, weight_decay, max_grad_norm, train_projector=True, group=group,
+                               bucket_bytes=bucket_bytes, _build_reducer=False)
+        self.opt = None                                     # (the stage-1 optimizer the base class built)
+        dec = model.llama
+        dec.prepare_training(train_weights=True)
+        entries = [(k, p.data) for k, p in self.params.items()]
+        entries += [(f"llama.{k}", v) for k, v in dec.trainable_tensors().items()]
+        self.reducer = None
+
+        def rebind(name, view):
+            if name.startswith("llama."):
+                dec.rebind_tensor(name[len("llama."):], view)
+            else:
+                self.params[name].data = view
+
+        self.sharded = ShardedAdamW(entries, rebind, bucket_bytes=bucket_bytes, group=group, betas=betas, eps=eps,
+                                    weight_decay=weight_decay, update_fn=update_fn)
+        self.world = self.sharded.world
+        model.prepare()
+        dec.refresh_transposes()
+
+    @torch.no_grad()
+    def loss_and_grads(self, input_ids, images, bboxes, labels, exchange=True):
+        """Forward + backward; every gradient goes straight into its flat bucket (`ShardedAdamW.ready`), full buckets are
+        reduce-scattered on the communication stream while the backward continues.  Returns (loss, None): the gradients
+        live in the buckets, `apply()` consumes them."""
+        m = self.model
+        logits, ctx = m.forward_train(input_ids, images, bboxes)
+        loss, dlogits = m.llama.loss_and_dlogits(logits, labels)
+        self.sharded.reset()
+        grads = m.backward(ctx, dlogits, train_projector=True, on_grad=self.sharded.ready)
+        self._d_emb = m._d_emb
+        self._last_input_ids = input_ids
+        self._extra_grads(grads, self.sharded.ready)
+        m.llama.grads = {}                                  # the buckets hold them now
+        return loss, None
+
+    @torch.no_grad()
+    def apply(self, grads=None, lr=None, exchanged=True):
+        self.steps += 1
+        total_sq = self.sharded.step(self.lr if lr is None else lr, self.max_grad_norm)
+        self.last_grad_norm = total_sq.sqrt() if total_sq is not None else None
+        self.model.prepare()
+        self.model.llama.refresh_transposes()
+
+    def step(self, input_ids, images, bboxes, labels, lr=None):
+        loss, _ = self.loss_and_grads(input_ids, images, bboxes, labels)
+        self.apply(None, lr)
+        return loss
+
+    def state_dict(self):
+        """THIS rank's shard of the optimizer state (per bucket: fp32 master slice + moments), as FSDP's sharded state
+        dict does; the weights themselves are whole on every rank (`save_pretrained`)."""
+        return {"step": self.steps, "rank": self.sharded.rank, "world": self.sharded.world,
+                "buckets": [dict(names=[n for n, _ in b.entries], master=b.master.clone(), exp_avg=b.exp_avg.clone(),
+                                 exp_avg_sq=b.exp_avg_sq.clone()) for b in self.sharded.buckets]}
+
+    def load_state_dict(self, sd):
+        assert sd["world"] == self.sharded.world and sd["rank"] == self.sharded.rank, "sharded state is per (rank, world)"
+        self.steps = self.sharded.steps = int(sd["step"])
+        if self.sharded._fused is not None:
+            self.sharded._fused.steps = self.steps
+        for b, s in zip(self.sharded.buckets, sd["buckets"]):
+            assert [n for n, _ in b.entries] == s["names"]
+            b.master.copy_(s["master"])
+            b.exp_avg.copy_(s["exp_avg"])
+            b.exp_avg_sq.copy_(s["exp_avg_sq"])
