@@ -8,8 +8,8 @@
 // 257-270 and llava/model/llava.py:52):
 //   AMODE 0  dense A [M, lda]
 //   AMODE 1  implicit GEMM of a 3x3 / pad 1 / stride 1 convolution over NHWC activations:
-//            row m = pixel (b, y, x), K index = ((group * 9 + tap) * Cin + c); out-of-image taps
-//            read a zero line.  `groups` > 1 sums several convolutions in one accumulator
+//            row m = pixel (b, y, x), K index = ((group * 9 + tap) * Cin + c), walked taps-fastest;
+//            out-of-image taps read a zero line.  `groups` > 1 sums several convolutions in one accumulator
 //            (the "sum_l pconv_l(roi_feats[l])" of layers.py:321-324).
 //
 // Machine mapping (MI355X_MICROARCH.md / cdna_hip_programming.md section 5):
@@ -419,20 +419,29 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
   auto stage = [&](int t, int buf) {
     char* sa = smem + buf * STAGE_BYTES;
     char* sb = sa + A_BYTES;
-    const int k0 = t * BKT;
+    int k0 = t * BKT;
     // A operand
     long a_off;
     int dy = 0, dx = 0;
     if (AMODE == 0) {
       a_off = k0;
     } else {
-      const int per_tap = p.Cin / BKT;          // K tiles per tap
-      const int tap_lin = t / per_tap;          // group * 9 + tap
-      const int c0 = (t - tap_lin * per_tap) * BKT;
+      // K tiles walk the taps FASTEST (channel slice outer): the nine shifted reads of one channel slice follow each
+      // other within ~9 K tiles, so eight of them hit the L2 instead of HBM (the weights keep the [tap][Cin] layout)
+      const int n_taps = 9 * p.groups;
+      int ct = t / n_taps;
+      int tap_lin = t - ct * n_taps;            // group * 9 + tap
+      if (p.dbg == 7) {                         // A/B probe (tools only): taps outermost, the round-1 order
+        const int per_tap = p.Cin / BKT;
+        tap_lin = t / per_tap;
+        ct = t - tap_lin * per_tap;
+      }
+      const int c0 = ct * BKT;
       const int grp = tap_lin / 9, tap = tap_lin - grp * 9;
       dy = tap / 3 - 1;
       dx = tap - (tap / 3) * 3 - 1;
       a_off = (long)grp * p.a_group_stride + ((long)dy * p.Wd + dx) * p.lda + c0;
+      k0 = tap_lin * p.Cin + c0;
     }
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
@@ -777,13 +786,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     ts.a_off = ts.k0;
     ts.dy = ts.dx = 0;
     if (AMODE == 1) {
-      const int per_tap = p.Cin / BKT;
-      const int tap_lin = t / per_tap;
-      const int c0 = (t - tap_lin * per_tap) * BKT;
+      const int n_taps = 9 * p.groups;          // taps fastest, channel slice outer (see gemm_bf16_nt_kernel)
+      int ct = t / n_taps;
+      int tap_lin = t - ct * n_taps;
+      if (p.dbg == 7) {                         // A/B probe (tools only): taps outermost, the round-1 order
+        const int per_tap = p.Cin / BKT;
+        tap_lin = t / per_tap;
+        ct = t - tap_lin * per_tap;
+      }
+      const int c0 = ct * BKT;
       const int g = tap_lin / 9, tap = tap_lin - g * 9;
       ts.dy = tap / 3 - 1;
       ts.dx = tap - (tap / 3) * 3 - 1;
       ts.a_off = (long)g * p.a_group_stride + ((long)ts.dy * p.Wd + ts.dx) * p.lda + c0;
+      ts.k0 = tap_lin * p.Cin + c0;
     }
     return ts;
   };
@@ -1021,13 +1037,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     ts.a_off = ts.k0;
     ts.dy = ts.dx = 0;
     if (AMODE == 1) {
-      const int per_tap = p.Cin / BKT;
-      const int tap_lin = t / per_tap;
-      const int c0 = (t - tap_lin * per_tap) * BKT;
+      const int n_taps = 9 * p.groups;          // taps fastest, channel slice outer (see gemm_bf16_nt_kernel)
+      int ct = t / n_taps;
+      int tap_lin = t - ct * n_taps;
+      if (p.dbg == 7) {                         // A/B probe (tools only): taps outermost, the round-1 order
+        const int per_tap = p.Cin / BKT;
+        tap_lin = t / per_tap;
+        ct = t - tap_lin * per_tap;
+      }
+      const int c0 = ct * BKT;
       const int g = tap_lin / 9, tap = tap_lin - g * 9;
       ts.dy = tap / 3 - 1;
       ts.dx = tap - (tap / 3) * 3 - 1;
       ts.a_off = (long)g * p.a_group_stride + ((long)ts.dy * p.Wd + ts.dx) * p.lda + c0;
+      ts.k0 = tap_lin * p.Cin + c0;
     }
     return ts;
   };
@@ -1227,13 +1250,20 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
     ts.a_off = ts.k0;
     ts.dy = ts.dx = 0;
     if (AMODE == 1) {
-      const int per_tap = p.Cin / BKT;
-      const int tap_lin = t / per_tap;
-      const int c0 = (t - tap_lin * per_tap) * BKT;
+      const int n_taps = 9 * p.groups;          // taps fastest, channel slice outer (see gemm_bf16_nt_kernel)
+      int ct = t / n_taps;
+      int tap_lin = t - ct * n_taps;
+      if (p.dbg == 7) {                         // A/B probe (tools only): taps outermost, the round-1 order
+        const int per_tap = p.Cin / BKT;
+        tap_lin = t / per_tap;
+        ct = t - tap_lin * per_tap;
+      }
+      const int c0 = ct * BKT;
       const int g = tap_lin / 9, tap = tap_lin - g * 9;
       ts.dy = tap / 3 - 1;
       ts.dx = tap - (tap / 3) * 3 - 1;
       ts.a_off = (long)g * p.a_group_stride + ((long)ts.dy * p.Wd + ts.dx) * p.lda + c0;
+      ts.k0 = tap_lin * p.Cin + c0;
     }
     return ts;
   };

@@ -5,7 +5,7 @@
 //         -Wl,-rpath,'$ORIGIN/../../gpt4roi_amd/lib' -o tools/probe/gemm_bench
 //   tools/probe/gemm_bench [--rounds R] [--fill u|z|n] case...
 //     case = g:M,N,K,tile,splits[,act[,f32]]      dense C = A W^T through g4r_gemm_bf16_nt
-//            c:B,H,W,C,tile,splits               3x3 conv through g4r_conv3x3_nhwc_bf16 (Cin = Cout = C)
+//            c:B,H,W,C,tile,splits[,dbg]         3x3 conv through g4r_conv3x3_nhwc_bf16 (Cin = Cout = C); dbg 7 = taps-outermost K order
 //
 // Every case is checked on 8192 sampled outputs against an fp32 dot product computed by a trivial kernel, then timed
 // with HIP events around each launch; cases are interleaved round-robin (rule "perf deltas come from within-probe
@@ -28,6 +28,7 @@ int g4r_conv3x3_nhwc_bf16(const void* X, const void* W, void* Y, const float* bi
                           int batch, int H, int Wd, int Cin, int Cout, int groups, long x_group_stride, int act,
                           int out_f32, int splits, int tile_cfg, void* stream);
 const char* g4r_last_error(void);
+void g4r_gemm_debug_mode(int mode);
 }
 
 #define CK(x)                                                                                  \
@@ -68,7 +69,7 @@ __global__ void fill_kernel(uint16_t* p, size_t n, uint32_t seed, float scale, i
 struct Case {
   char kind;  // 'g' or 'c'
   int M, N, K, tile, splits, act, f32;
-  int B, H, W, C;
+  int B, H, W, C, dbg;
   uint16_t *A, *Wt, *zeros;
   void* Cout;
   float* ws;
@@ -109,6 +110,7 @@ __global__ void ref_conv_kernel(const uint16_t* X, const uint16_t* W, int B, int
 }
 
 static int launch(Case& c, hipStream_t st) {
+  g4r_gemm_debug_mode(c.dbg);
   if (c.kind == 'g')
     return g4r_gemm_bf16_nt(c.A, c.Wt, c.Cout, nullptr, nullptr, c.ws, c.M, c.N, c.K, c.K, c.K,
                             c.act == 4 ? c.N / 2 : c.N, 0, c.act, c.f32, c.splits, c.tile, st);
@@ -132,7 +134,7 @@ int main(int argc, char** argv) {
       c.M = v[0]; c.N = v[1]; c.K = v[2]; c.tile = v[3]; c.splits = v[4] < 1 ? 1 : v[4]; c.act = v[5]; c.f32 = v[6];
       c.flops = 2.0 * c.M * c.N * c.K;
     } else if (c.kind == 'c') {
-      c.B = v[0]; c.H = v[1]; c.W = v[2]; c.C = v[3]; c.tile = v[4]; c.splits = v[5] < 1 ? 1 : v[5];
+      c.B = v[0]; c.H = v[1]; c.W = v[2]; c.C = v[3]; c.tile = v[4]; c.splits = v[5] < 1 ? 1 : v[5]; c.dbg = v[6];
       c.M = c.B * c.H * c.W; c.N = c.C; c.K = 9 * c.C;
       c.flops = 2.0 * c.M * c.N * c.K;
     } else {
