@@ -247,6 +247,230 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Single-query attention over the KV cache: the decode step of row a17 (one new token attends the
+// `*kv_len_dev + 1` cached positions).  HBM/L2-bound: 2 * Tk * H * D bf16 of K/V per layer and token,
+// 16 flops per byte -- no MFMA.  The tiled kernel above runs this case with ONE workgroup per head
+// (32 workgroups, 25 us at 800 keys); here the keys of a head are split over S workgroups (flash-decoding):
+//   grid (S, H), 4 waves; a wave takes 4 keys per step: 16 lanes x 16 B cover one 256-B K (and V) row of the
+//   head, so every load instruction moves 1 KiB of whole rows; q . k is reduced over the 16 lanes with 4 DPP
+//   shuffles; each 16-lane group keeps its own online-softmax state (m, l, o[8 dims per lane]) in fp32.
+//   The 16 states of a workgroup are merged through LDS into one un-normalised partial (m, l, o[D]).
+//   Partials meet through `ws`; the LAST workgroup of a head to arrive (agent-scope acq_rel counter, the
+//   protocol of cdna_hip_programming.md section 6 G16) merges the S partials, writes the bf16 output and
+//   re-arms the counter, so there is no second launch and no memset node in the captured graph.  (First version: an
+//   acq_rel counter -- correct, but every workgroup then pays an L2 write-back + invalidate; see the hand-off below.)
+// p is kept in fp32 for the PV product (the tiled kernel rounds it to bf16 for the MFMA).
+// ---------------------------------------------------------------------------------------------
+struct DecodeAttnArgs {
+  const bf16_t* Q;     // [H * D] (already rotated), or null when `qkv` is given
+  const bf16_t* qkv;   // optional raw projection row [3 * H * D] (q | k | v) of the new token: RoPE is applied here, the
+                       // rotated k and the v are appended to the caches at row Tk - 1 (what g4r_rope_qkv_bf16 would do)
+  const float* cs;     // cos / sin tables [maxT][D / 2] (with qkv)
+  const float* sn;
+  bf16_t* K;           // [Tmax][k_row]
+  bf16_t* V;
+  bf16_t* O;           // [H * D]
+  float* ws;           // [H][S][D + 2]
+  unsigned* cnt;       // [H], zero before the first call; left zero by every call
+  long k_row, v_row;
+  int Tk, S, H;
+  float scale;
+  const int* kv_len_dev;
+  int defer;           // 1: leave the S partials in ws for the consumer (g4r_gemv_attn_merge_bf16); O and cnt unused
+};
+
+__device__ __forceinline__ void unpack8(const uint4v& r, float* f) {
+  f[0] = bf16lo(r.x); f[1] = bf16hi(r.x); f[2] = bf16lo(r.y); f[3] = bf16hi(r.y);
+  f[4] = bf16lo(r.z); f[5] = bf16hi(r.z); f[6] = bf16lo(r.w); f[7] = bf16hi(r.w);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_decode_kernel(DecodeAttnArgs p) {
+  constexpr int LPK = D / 8;        // lanes per key (16 B each)
+  constexpr int KPW = 64 / LPK;     // keys per wave and step
+  constexpr int NST = 4 * KPW;      // online-softmax states per workgroup = keys per workgroup step
+  constexpr int NB = 8;             // steps whose loads are issued together (2 * NB 16-B loads in flight per lane)
+  constexpr int SLD = D + 2;
+  __shared__ float st[NST][SLD];
+  __shared__ float wgt[64];
+  __shared__ unsigned arrival;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane % LPK, ks = lane / LPK;
+  const int s = blockIdx.x, h = blockIdx.y, S = p.S;
+  const int Tk = p.kv_len_dev ? *p.kv_len_dev + 1 : p.Tk;
+  int chunk = (Tk + S - 1) / S;
+  chunk = (chunk + NST - 1) / NST * NST;
+  const int j_begin = s * chunk;
+  const int j_end = j_begin + chunk < Tk ? j_begin + chunk : Tk;
+  const float sc2 = p.scale * 1.4426950408889634f;
+  const bf16_t* Kb = p.K + (size_t)h * D + sub * 8;
+  const bf16_t* Vb = p.V + (size_t)h * D + sub * 8;
+  uint4v kv[NB], vv[NB];
+  auto load_block = [&](int j0) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int j = j0 + u * NST + ks;
+      int jc = j < j_end ? j : j_end - 1;
+      if (jc < 0) jc = 0;
+      kv[u] = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(Kb + (size_t)jc * p.k_row));
+      vv[u] = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(Vb + (size_t)jc * p.v_row));
+    }
+  };
+  const int j_first = j_begin + wave * KPW;
+  load_block(j_first);                 // in flight while q (and the new k) are being rotated below
+  float q[8];
+  uint4v k_new = {0u, 0u, 0u, 0u}, v_new = {0u, 0u, 0u, 0u};
+  const bool fused = p.qkv != nullptr;
+  if (fused) {
+    // RoPE of this head's q and k rows at position Tk - 1, rotate_half convention, same expressions and bf16
+    // roundings as rope_qkv_kernel (elementwise.hip); lane `sub` holds 8 dims, its partner half is lane sub ^ (LPK/2)
+    constexpr int HL = LPK / 2;
+    const int pos = Tk - 1, v8 = (sub & (HL - 1)) * 8;
+    const bool second = sub >= HL;
+    const size_t own = (size_t)h * D + sub * 8, oth = (size_t)h * D + (sub ^ HL) * 8;
+    const size_t HD = (size_t)p.H * D;
+    float c[8], sn[8], a[8], b[8];
+    {
+      const float4v c0 = *reinterpret_cast<const float4v*>(p.cs + (size_t)pos * (D / 2) + v8);
+      const float4v c1 = *reinterpret_cast<const float4v*>(p.cs + (size_t)pos * (D / 2) + v8 + 4);
+      const float4v s0 = *reinterpret_cast<const float4v*>(p.sn + (size_t)pos * (D / 2) + v8);
+      const float4v s1 = *reinterpret_cast<const float4v*>(p.sn + (size_t)pos * (D / 2) + v8 + 4);
+      c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+      sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+    }
+    float o[8];
+    unpack8(*reinterpret_cast<const uint4v*>(p.qkv + own), a);
+    unpack8(*reinterpret_cast<const uint4v*>(p.qkv + oth), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = second ? a[e] * c[e] + b[e] * sn[e] : a[e] * c[e] - b[e] * sn[e];
+    {
+      const uint4v qr = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+      unpack8(qr, q);
+    }
+    unpack8(*reinterpret_cast<const uint4v*>(p.qkv + HD + own), a);
+    unpack8(*reinterpret_cast<const uint4v*>(p.qkv + HD + oth), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = second ? a[e] * c[e] + b[e] * sn[e] : a[e] * c[e] - b[e] * sn[e];
+    k_new = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+    v_new = *reinterpret_cast<const uint4v*>(p.qkv + 2 * HD + own);
+    if (s == 0 && wave == 0 && ks == 0) {                      // append the new row for the tokens to come
+      *reinterpret_cast<uint4v*>(p.K + (size_t)pos * p.k_row + own) = k_new;
+      *reinterpret_cast<uint4v*>(p.V + (size_t)pos * p.v_row + own) = v_new;
+    }
+  } else {
+    unpack8(*reinterpret_cast<const uint4v*>(p.Q + (size_t)h * D + sub * 8), q);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) q[e] *= sc2;
+  float m = -INFINITY, l = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j0 = j_first; j0 < j_end; j0 += NST * NB) {
+    if (j0 != j_first) load_block(j0);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int j = j0 + u * NST + ks;
+      if (fused && j == Tk - 1) { kv[u] = k_new; vv[u] = v_new; }   // the row being appended: from registers
+      float kf[8], vf[8];
+      unpack8(kv[u], kf);
+      unpack8(vv[u], vf);
+      float sdot = q[0] * kf[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) sdot = fmaf(q[e], kf[e], sdot);
+#pragma unroll
+      for (int x = 1; x < LPK; x <<= 1) sdot += __shfl_xor(sdot, x);
+      if (j < j_end) {
+        const float mn = fmaxf(m, sdot);
+        const float alpha = exp2f(m - mn), pj = exp2f(sdot - mn);
+        l = l * alpha + pj;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * alpha + pj * vf[e];
+        m = mn;
+      }
+    }
+  }
+  // ---- merge the NST states of this workgroup ----
+  {
+    float* row = st[wave * KPW + ks];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) row[sub * 8 + e] = o[e];
+    if (sub == 0) { row[D] = m; row[D + 1] = l; }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float mm = -INFINITY;
+    for (int i = 0; i < NST; ++i) mm = fmaxf(mm, st[i][D]);
+    float w = 0.f;
+    if (tid < NST) w = st[tid][D] == -INFINITY ? 0.f : exp2f(st[tid][D] - mm);
+    wgt[tid] = w;
+  }
+  __syncthreads();
+  float M = -INFINITY, L = 0.f, acc = 0.f;
+  if (tid < D) {
+    for (int i = 0; i < NST; ++i) {
+      M = fmaxf(M, st[i][D]);
+      L += wgt[i] * st[i][D + 1];
+      acc += wgt[i] * st[i][tid];
+    }
+  }
+  if (S == 1 && !p.defer) {
+    if (tid < D) p.O[(size_t)h * D + tid] = f32_to_bf16(acc / L);
+    return;
+  }
+  if (p.defer) {                      // the consumer merges: plain stores, the kernel boundary publishes them
+    float* mine = p.ws + ((size_t)h * S + s) * SLD;
+    if (tid < D) {
+      mine[tid] = acc;
+      if (tid == 0) { mine[D] = M; mine[D + 1] = L; }
+    }
+    return;
+  }
+  // ---- hand-off without fences (cdna_hip_programming.md section 6 G16, write-through variant): the partial is stored with
+  // agent-scope relaxed atomics (sc1 write-through: it bypasses this XCD's non-coherent L2), drained (vmcnt(0)) before the
+  // arrival counter is bumped; the last workgroup to arrive reads the partials with agent-scope relaxed loads (sc1).  An
+  // acq_rel counter instead costs an L2 write-back + invalidate per workgroup: 20-30 us per launch measured. ----
+  float* mine = p.ws + ((size_t)h * S + s) * SLD;
+  if (tid < D) {
+    __hip_atomic_store(mine + tid, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      __hip_atomic_store(mine + D, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + D + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) arrival = __hip_atomic_fetch_add(p.cnt + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (arrival != (unsigned)(S - 1)) return;
+  float* part = p.ws + (size_t)h * S * SLD;
+  if (tid < 64) wgt[tid] = tid < S ? __hip_atomic_load(part + tid * SLD + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+  __syncthreads();
+  float mm = -INFINITY;
+  for (int i = 0; i < S; ++i) mm = fmaxf(mm, wgt[i]);
+  if (tid < D) {
+    float Lt = 0.f, a2 = 0.f;
+    for (int i0 = 0; i0 < S; i0 += 16) {
+      float pl[16], po[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {       // all loads of a batch issued before the first use
+        const int i = i0 + u < S ? i0 + u : S - 1;
+        pl[u] = __hip_atomic_load(part + i * SLD + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        po[u] = __hip_atomic_load(part + i * SLD + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        if (i0 + u < S) {
+          const float mi = wgt[i0 + u];
+          const float w = mi == -INFINITY ? 0.f : exp2f(mi - mm);
+          Lt += w * pl[u];
+          a2 += w * po[u];
+        }
+      }
+    }
+    p.O[(size_t)h * D + tid] = f32_to_bf16(a2 / Lt);
+  }
+  if (tid == 0) __hip_atomic_store(p.cnt + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace
 
 extern "C" {
@@ -278,6 +502,37 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
     hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
   }
   G4R_CHECK_LAUNCH("flash_attn_fwd");
+  return G4R_OK;
+}
+
+// One query row (the token being decoded) against the first Tk = *kv_len_dev + 1 (or `Tk` when kv_len_dev is null) rows
+// of a KV cache: Q/O [H*D] bf16, K/V rows `k_row`/`v_row` elements apart.  `splits` workgroups per head share the keys;
+// workspace = H*splits*(D+2) floats, counters = H uint32 that are zero before the first call (every call leaves them zero).
+// With `qkv` (the raw q|k|v projection row of the new token, [3*H*D]) the call also does what g4r_rope_qkv_bf16 does for
+// that token: q and k are rotated with cos/sin row Tk-1, k and v are appended to the caches at row Tk-1 (Q is ignored).
+// defer_merge: the S partials (un-normalised o, max, sum per split) stay in the workspace and the consumer assembles the
+// output (g4r_gemv_attn_merge_bf16, the o_proj of the decode step) -- no hand-off inside this launch; O/counters unused.
+// Replaces the Tq = 1 case of g4r_flash_attn_fwd_bf16 in the decode loop the reference reaches through HF generate()
+// (gpt4roi/app.py:293-300 -> transformers LlamaAttention with past_key_values).
+int g4r_attn_decode_bf16(const void* Q, const void* qkv, const float* cos_tab, const float* sin_tab, void* K, void* V,
+                         void* O, float* workspace, unsigned* counters, int H, int head_dim, int Tk, long k_row,
+                         long v_row, float scale, int splits, const int* kv_len_dev, int defer_merge, void* stream) {
+  G4R_REQUIRE(H > 0 && (Tk > 0 || kv_len_dev), "attn_decode: bad shape");
+  G4R_REQUIRE(head_dim == 64 || head_dim == 128, "attn_decode: head_dim must be 64 or 128");
+  G4R_REQUIRE((Q || qkv) && K && V && (O || defer_merge), "attn_decode: null pointer");
+  G4R_REQUIRE(!defer_merge || workspace, "attn_decode: defer_merge needs the workspace");
+  G4R_REQUIRE(!qkv || (cos_tab && sin_tab), "attn_decode: the fused RoPE needs the cos/sin tables");
+  G4R_REQUIRE(splits >= 1 && splits <= 64, "attn_decode: splits must be in [1, 64]");
+  G4R_REQUIRE(splits == 1 || defer_merge || (workspace && counters), "attn_decode: split keys need workspace and counters");
+  G4R_REQUIRE(k_row % 8 == 0 && v_row % 8 == 0, "attn_decode: strides must keep 16-byte alignment");
+  DecodeAttnArgs a = {(const bf16_t*)Q, (const bf16_t*)qkv, cos_tab, sin_tab, (bf16_t*)K, (bf16_t*)V, (bf16_t*)O,
+                      workspace, counters, k_row, v_row, Tk, splits, H, scale, kv_len_dev, defer_merge};
+  dim3 grid(splits, H);
+  if (head_dim == 64)
+    hipLaunchKernelGGL((attn_decode_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((attn_decode_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  G4R_CHECK_LAUNCH("attn_decode");
   return G4R_OK;
 }
 

@@ -51,6 +51,7 @@ struct GemmArgs {
 };
 
 constexpr int BK = 64;
+static int g_gemm_dbg = 0;   // tools only: ablation / A-B probe modes (g4r_gemm_debug_mode)
 
 // waves per SIMD the kernel is allowed to assume = workgroups that fit the 160 KB LDS (<= 3)
 constexpr int gemm_waves_per_eu(int bm, int bn, int nw, int stages, int bk) {
@@ -651,25 +652,124 @@ __device__ __forceinline__ float dot8_bf16(const uint4v& a, const uint4v& b, flo
   return acc;
 }
 
-__global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
-                                                        void* __restrict__ C, const float* __restrict__ bias,
+// x is staged ONCE per workgroup in LDS (the 4 waves of a workgroup would otherwise each re-read it from L2: K*2 B per
+// wave against R*K*2 B of weights).  NORM fuses the RMSNorm that precedes the q|k|v, gate|up and lm_head projections
+// (HF LlamaRMSNorm; same staging pattern, summation order and roundings as rmsnorm_bf16_kernel in norm.hip, so the
+// normalised vector is bit-identical to the separate launch it replaces).  A wave owns R consecutive W rows and keeps
+// R*U 16-byte loads in flight per lane (U K-steps of 1 KiB per row); shipped: R = 2, U = 8.
+// XMODE 0: x as it is; 1: fused RMSNorm (gamma, eps); 2: x = the attention output assembled from the per-split partials
+// the decode attention leaves behind (attention.hip, attn_decode_kernel with defer_merge): `gamma` then points at
+// ws [H][S][D + 2] (un-normalised o, running max m, sum l per split), mS = S, mD = D.  Doing the merge in the consumer's
+// staging loop replaces a cross-workgroup hand-off inside the attention launch (sc1 write-through, arrival counter, sc1
+// read-back: ~6 us of serial memory round trips per layer) by a kernel boundary that is there anyway.
+template <int R, int U, int XMODE, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                        float eps, int mS, int mD, const bf16_t* __restrict__ W,
+                                                        void* __restrict__ C,
+                                                        const float* __restrict__ bias,
                                                         const bf16_t* __restrict__ residual, int N, int K, int ldw,
                                                         int act, int out_f32) {
-  constexpr int R = 4;
-  const int lane = threadIdx.x & 63;
-  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
-  if (n0 >= N) return;
-  float acc[R] = {0.f, 0.f, 0.f, 0.f};
+  extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
+  uint4v* xs = reinterpret_cast<uint4v*>(gemv_smem);
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nvec = K >> 3;
+  const int n0 = (blockIdx.x * NWV + wave) * R;
   const bf16_t* wrow[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) wrow[r] = W + (size_t)(n0 + r < N ? n0 + r : N - 1) * ldw;
-  for (int k0 = lane * 8; k0 < K; k0 += 512) {
-    const uint4v xv = *reinterpret_cast<const uint4v*>(x + k0);
-    uint4v wv[R];
+  uint4v wv[U][R];
+  auto load_w = [&](int vb) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(wrow[r] + k0));
+    for (int u = 0; u < U; ++u) {
+      const int idx = vb + 64 * u < nvec ? vb + 64 * u : nvec - 1;
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = dot8_bf16(xv, wv[r], acc[r]);
+      for (int r = 0; r < R; ++r)
+        wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(wrow[r] + (size_t)idx * 8));
+    }
+  };
+  // (Issuing the first weight loads before x is staged does not help: vector memory returns in order, so the small x
+  // loads then queue behind R*U HBM loads -- measured 5-8 % slower.)
+  if (XMODE == 1) {
+    // the first 4 waves stage and normalise x exactly as rmsnorm_bf16_kernel's 256 threads do (same element -> thread
+    // map and summation order: bit-identical rstd); further waves of a wide workgroup only wait at the barriers
+    constexpr int MAXV = 4;  // K <= 8192 (checked by the launcher)
+    float f[MAXV][8];
+    float s2 = 0.f;
+    const bool stager = tid < 256;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = tid + i * 256;
+      if (stager && v < nvec) {
+        const uint4v r = *reinterpret_cast<const uint4v*>(x + v * 8);
+        f[i][0] = bf16lo(r.x); f[i][1] = bf16hi(r.x); f[i][2] = bf16lo(r.y); f[i][3] = bf16hi(r.y);
+        f[i][4] = bf16lo(r.z); f[i][5] = bf16hi(r.z); f[i][6] = bf16lo(r.w); f[i][7] = bf16hi(r.w);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s2 += f[i][k] * f[i][k];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+    __syncthreads();
+    if (lane == 0 && stager) red[wave] = s2;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = tid + i * 256;
+      if (stager && v < nvec) {
+        const float4v g0 = *reinterpret_cast<const float4v*>(gamma + v * 8);
+        const float4v g1 = *reinterpret_cast<const float4v*>(gamma + v * 8 + 4);
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = bf16_to_f32(f32_to_bf16(f[i][k] * rstd)) * g[k];
+        uint4v w;
+        w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
+        w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+        xs[v] = w;
+      }
+    }
+  } else if (XMODE == 2) {
+    const int SLD = mD + 2;
+    for (int v = tid; v < nvec; v += NWV * 64) {
+      const int h = (v * 8) / mD, d0 = (v * 8) - h * mD;
+      const float* part = gamma + (size_t)h * mS * SLD;
+      float mm = -INFINITY;
+      for (int i = 0; i < mS; ++i) mm = fmaxf(mm, part[i * SLD + mD]);
+      float Lt = 0.f, a2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < mS; ++i) {
+        const float mi = part[i * SLD + mD];
+        const float w = mi == -INFINITY ? 0.f : exp2f(mi - mm);
+        Lt += w * part[i * SLD + mD + 1];
+        const float4v o0 = *reinterpret_cast<const float4v*>(part + i * SLD + d0);
+        const float4v o1 = *reinterpret_cast<const float4v*>(part + i * SLD + d0 + 4);
+        a2[0] += w * o0.x; a2[1] += w * o0.y; a2[2] += w * o0.z; a2[3] += w * o0.w;
+        a2[4] += w * o1.x; a2[5] += w * o1.y; a2[6] += w * o1.z; a2[7] += w * o1.w;
+      }
+      uint4v w8;
+      w8.x = pack_bf16x2(a2[0] / Lt, a2[1] / Lt); w8.y = pack_bf16x2(a2[2] / Lt, a2[3] / Lt);
+      w8.z = pack_bf16x2(a2[4] / Lt, a2[5] / Lt); w8.w = pack_bf16x2(a2[6] / Lt, a2[7] / Lt);
+      xs[v] = w8;
+    }
+  } else {
+    for (int v = tid; v < nvec; v += NWV * 64) xs[v] = *reinterpret_cast<const uint4v*>(x + v * 8);
+  }
+  __syncthreads();
+  if (n0 >= N) return;
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  for (int vb = lane; vb < nvec; vb += 64 * U) {
+    load_w(vb);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (vb + 64 * u < nvec) {
+        const uint4v xv = xs[vb + 64 * u];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = dot8_bf16(xv, wv[u][r], acc[r]);
+      }
+    }
   }
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -691,15 +791,53 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
   for (int r = 0; r < R; ++r) {
     const int n = n0 + r;
     if (n >= N) break;
-    float v = acc[r];
-    if (bias) v += bias[n];
-    v = apply_act(v, act);
-    if (residual) v += bf16_to_f32(residual[n]);
+    float vv = acc[r];
+    if (bias) vv += bias[n];
+    vv = apply_act(vv, act);
+    if (residual) vv += bf16_to_f32(residual[n]);
     if (out_f32)
-      reinterpret_cast<float*>(C)[n] = v;
+      reinterpret_cast<float*>(C)[n] = vv;
     else
-      reinterpret_cast<bf16_t*>(C)[n] = f32_to_bf16(v);
+      reinterpret_cast<bf16_t*>(C)[n] = f32_to_bf16(vv);
   }
+}
+
+template <int R, int U, int NWV>
+static void launch_gemv(int xmode, const bf16_t* x, const float* gamma, float eps, int mS, int mD, const bf16_t* W, void* C,
+                        const float* bias, const bf16_t* residual, int N, int K, int ldw, int act, int out_f32,
+                        hipStream_t stream) {
+  const int waves = g4r_ceil_div(N, R);
+  const dim3 grid(g4r_ceil_div(waves, NWV)), block(NWV * 64);
+  const size_t lds = (size_t)K * 2;
+  if (xmode == 1)
+    hipLaunchKernelGGL((gemv_bf16_kernel<R, U, 1, NWV>), grid, block, lds, stream, x, gamma, eps, mS, mD, W, C, bias,
+                       residual, N, K, ldw, act, out_f32);
+  else if (xmode == 2)
+    hipLaunchKernelGGL((gemv_bf16_kernel<R, U, 2, NWV>), grid, block, lds, stream, x, gamma, eps, mS, mD, W, C, bias,
+                       residual, N, K, ldw, act, out_f32);
+  else
+    hipLaunchKernelGGL((gemv_bf16_kernel<R, U, 0, NWV>), grid, block, lds, stream, x, gamma, eps, mS, mD, W, C, bias,
+                       residual, N, K, ldw, act, out_f32);
+}
+
+// (R rows per wave, U K-steps in flight, waves per workgroup); variant >= 0: A/B probe (tools/gemm_bench.cpp v: cases)
+static void gemv_dispatch(int variant, int xmode, const bf16_t* x, const float* gamma, float eps, int mS, int mD,
+                          const bf16_t* W, void* C, const float* bias, const bf16_t* residual, int N, int K, int ldw,
+                          int act, int out_f32, hipStream_t st) {
+  if (variant < 0) variant = 2;   // R = 2, U = 4, 8 waves: best or within noise of the best on all five LLaMA-7B projections (profiles/r02_gemv_variants.txt)
+#define G4R_GEMV_CASE(v, R_, U_, NW_) \
+  case v: launch_gemv<R_, U_, NW_>(xmode, x, gamma, eps, mS, mD, W, C, bias, residual, N, K, ldw, act, out_f32, st); break;
+  switch (variant) {
+    G4R_GEMV_CASE(0, 4, 2, 4)
+    G4R_GEMV_CASE(1, 2, 4, 4)
+    G4R_GEMV_CASE(2, 2, 4, 8)
+    G4R_GEMV_CASE(3, 2, 4, 16)
+    G4R_GEMV_CASE(4, 2, 8, 4)
+    G4R_GEMV_CASE(5, 2, 8, 8)
+    G4R_GEMV_CASE(6, 4, 2, 8)
+    default: launch_gemv<4, 4, 8>(xmode, x, gamma, eps, mS, mD, W, C, bias, residual, N, K, ldw, act, out_f32, st); break;
+  }
+#undef G4R_GEMV_CASE
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1569,7 +1707,6 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
 
 }  // namespace
 
-static int g_gemm_dbg = 0;
 
 extern "C" {
 
@@ -1586,11 +1723,10 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
   G4R_REQUIRE(act >= 0 && act <= 4, "gemm: act must be 0..4");
   G4R_REQUIRE(act != 4 || (N % 4 == 0 && ldc % 2 == 0 && !residual && !bias && !out_f32 && K % BK == 0),
               "gemm: swiglu epilogue needs N % 4 == 0, bf16 output, no bias/residual");
-  if (M == 1 && K % 8 == 0 && (ldw % 8) == 0 && splits == 1 && K >= 512 && (act != 4 || N % 4 == 0)) {
+  if (M == 1 && K % 8 == 0 && (ldw % 8) == 0 && splits == 1 && K >= 512 && K <= 32768 && (act != 4 || N % 4 == 0)) {
     // single-token decode: weight-streaming GEMV
-    const int waves = g4r_ceil_div(N, 4);
-    hipLaunchKernelGGL(gemv_bf16_kernel, dim3(g4r_ceil_div(waves, 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)A, (const bf16_t*)W, C, bias, (const bf16_t*)residual, N, K, ldw, act, out_f32);
+    gemv_dispatch(g_gemm_dbg >= 100 ? g_gemm_dbg - 100 : -1, 0, (const bf16_t*)A, nullptr, 0.f, 0, 0, (const bf16_t*)W, C,
+                  bias, (const bf16_t*)residual, N, K, ldw, act, out_f32, (hipStream_t)stream);
     G4R_CHECK_LAUNCH("gemv_bf16");
     return G4R_OK;
   }
@@ -1615,6 +1751,35 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
   p.n_fastest = (long)M * 1 > (long)N * 2;
   p.splits = splits;
   return launch_gemm<0>(p, tile_cfg, (hipStream_t)stream);
+}
+
+// y [N] = act(W [N, K] . rmsnorm(x; gamma, eps) + bias) + residual for ONE activation row: the projections of the decode
+// step with the RMSNorm in front of them fused in (gamma null = no norm).  See g4r_kernels.h.
+int g4r_gemv_rmsnorm_bf16(const void* x, const float* gamma, float eps, const void* W, void* C, const float* bias,
+                          const void* residual, int N, int K, int ldw, int act, int out_f32, void* stream) {
+  G4R_REQUIRE(N > 0 && K >= 512 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K, "gemv: K >= 512, K and ldw multiples of 8");
+  G4R_REQUIRE(x && W && C, "gemv: null pointer");
+  G4R_REQUIRE(act >= 0 && act <= 4, "gemv: act must be 0..4");
+  G4R_REQUIRE(act != 4 || (N % 4 == 0 && !residual && !bias && !out_f32), "gemv: swiglu needs N % 4 == 0, bf16 output");
+  G4R_REQUIRE(K <= (gamma ? 8192 : 32768), "gemv: K <= 8192 with the fused norm, <= 32768 without");
+  gemv_dispatch(g_gemm_dbg >= 100 ? g_gemm_dbg - 100 : -1, gamma ? 1 : 0, (const bf16_t*)x, gamma, eps, 0, 0,
+                (const bf16_t*)W, C, bias, (const bf16_t*)residual, N, K, ldw, act, out_f32, (hipStream_t)stream);
+  G4R_CHECK_LAUNCH("gemv_rmsnorm_bf16");
+  return G4R_OK;
+}
+
+// C [N] = W [N, K] . a + bias + residual, where a [K = H * head_dim] is the decode-attention output assembled on the fly
+// from the per-split partials g4r_attn_decode_bf16 wrote with defer_merge (partials [H][splits][head_dim + 2] fp32).
+int g4r_gemv_attn_merge_bf16(const float* partials, int splits, int head_dim, const void* W, void* C, const float* bias,
+                             const void* residual, int N, int K, int ldw, int out_f32, void* stream) {
+  G4R_REQUIRE(N > 0 && K >= 512 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K && K <= 32768, "gemv_attn_merge: bad shape");
+  G4R_REQUIRE(partials && W && C, "gemv_attn_merge: null pointer");
+  G4R_REQUIRE(splits >= 1 && splits <= 64 && (head_dim == 64 || head_dim == 128) && K % head_dim == 0,
+              "gemv_attn_merge: splits in [1, 64], head_dim 64 or 128 dividing K");
+  gemv_dispatch(-1, 2, nullptr, partials, 0.f, splits, head_dim, (const bf16_t*)W, C, bias, (const bf16_t*)residual, N, K,
+                ldw, 0, out_f32, (hipStream_t)stream);
+  G4R_CHECK_LAUNCH("gemv_attn_merge_bf16");
+  return G4R_OK;
 }
 
 int g4r_conv3x3_nhwc_bf16(const void* X, const void* W, void* Y, const float* bias, const void* zeros,

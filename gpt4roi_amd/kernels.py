@@ -19,6 +19,9 @@ _SIGS = {
                               c_int, c_int, c_int, P],
     "g4r_flash_attn_fwd_bf16": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long,
                                 c_long, c_long, c_long, c_long, c_float, c_int, P, P, P],
+    "g4r_gemv_rmsnorm_bf16": [P, P, c_float, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "g4r_attn_decode_bf16": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_long, c_long, c_float, c_int, P, c_int, P],
+    "g4r_gemv_attn_merge_bf16": [P, c_int, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "g4r_flash_attn_bwd_bf16": [P] * 10 + [c_int] * 5 + [c_long] * 16 + [c_float, c_int, P],
     "g4r_rmsnorm_bwd_bf16": [P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_long, c_long, c_float, P],
     "g4r_layernorm_bwd_bf16": [P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_long, c_float, c_int, P],
@@ -274,6 +277,26 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
     return out
 
 
+def gemv(x, w, norm_weight=None, eps=1e-6, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfloat16):
+    """out[N] = act(w[N,K] . rmsnorm(x; norm_weight, eps) + bias) + residual for ONE row x [K] (any shape with K
+    elements); norm_weight None = no norm.  The decode-step projections: weight streaming, x staged in LDS, the
+    preceding RMSNorm fused in (bit-identical to rmsnorm() followed by gemm())."""
+    _bf16(x, w, residual)
+    _f32(bias, norm_weight)
+    N, K = w.shape
+    assert x.numel() == K and x.is_contiguous() and w.stride(1) == 1
+    n_out = N // 2 if act == "swiglu" else N
+    if out is None:
+        out = torch.empty((1, n_out), dtype=out_dtype, device=x.device)
+    assert out.numel() == n_out and out.is_contiguous()
+    if residual is not None:
+        assert residual.numel() == N and residual.is_contiguous()
+    _launch("g4r_gemv_rmsnorm_bf16", (_p(x), _p(norm_weight), float(eps), _p(w), _p(out), _p(bias), _p(residual), N, K,
+                                      w.stride(0), ACT[act], 1 if out.dtype == torch.float32 else 0, _stream(x),),
+            tag="gemv_bf16", flops=2.0 * N * K, nbytes=2.0 * (K + N * K) + out.element_size() * n_out)
+    return out
+
+
 def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=torch.bfloat16, splits=1, tile_cfg=None,
             workspace=None):
     """x [groups?, B, H, W, Cin] NHWC bf16 (groups dim present iff groups > 1);
@@ -331,6 +354,59 @@ def flash_attn(q, k, v, heads, scale, causal=False, out=None, kv_len_dev=None, l
         _p(lse), _stream(q),),
         tag=f"flash_attn<{D}>", flops=4.0 * B * heads * Tq * Tk * D * (0.5 if causal and Tq == Tk else 1.0),
         nbytes=2.0 * B * HD * (2 * Tq + 2 * Tk))
+    return out
+
+
+class DecodeAttnWorkspace:
+    """Partials + arrival counters of attn_decode (one per decoder: the layers run back to back on one stream)."""
+
+    def __init__(self, heads, head_dim, device, splits=8):
+        self.splits = splits
+        self.ws = torch.empty(heads * splits * (head_dim + 2), dtype=torch.float32, device=device)
+        self.cnt = torch.zeros(heads, dtype=torch.int32, device=device)      # every call leaves it zero again
+
+
+def attn_decode(q, k, v, heads, scale, work, kv_len_dev=None, kv_len=None, out=None, qkv=None, cos=None, sin=None,
+                defer_merge=False):
+    """One query row against a KV cache: q [heads*D] (any shape with that many elements), k/v [T_max, heads*D]
+    row-strided views; attends the first *kv_len_dev + 1 (or kv_len) rows.  -> [heads*D] bf16.
+    qkv (instead of q): the raw q|k|v projection row [3*heads*D] of the new token -- RoPE (cos/sin tables) and the cache
+    append at row kv_len - 1 happen inside the launch (rope_qkv + attention in one).
+    defer_merge: returns None; the per-split partials stay in work.ws for gemv_attn_merge (the o_proj of the step)."""
+    _bf16(q, k, v, qkv)
+    HD = k.size(1)
+    D = HD // heads
+    assert k.dim() == 2 and k.stride(1) == 1 and v.stride(1) == 1
+    assert (q is None) != (qkv is None)
+    if q is not None:
+        assert q.numel() == HD and q.is_contiguous()
+    else:
+        _f32(cos, sin)
+        assert qkv.numel() == 3 * HD and qkv.is_contiguous() and cos.size(1) == D // 2 and cos.is_contiguous()
+    assert kv_len_dev is not None or kv_len is not None
+    if out is None and not defer_merge:
+        out = torch.empty(HD, dtype=torch.bfloat16, device=k.device)
+    _launch("g4r_attn_decode_bf16", (_p(q), _p(qkv), _p(cos), _p(sin), _p(k), _p(v), _p(out), _p(work.ws), _p(work.cnt),
+                                     heads, D, int(kv_len or 0), k.stride(0), v.stride(0), float(scale), work.splits,
+                                     _p(kv_len_dev), int(bool(defer_merge)), _stream(k),), tag=f"attn_decode<{D}>")
+    return out
+
+
+def gemv_attn_merge(work, heads, head_dim, w, bias=None, residual=None, out=None, out_dtype=torch.bfloat16):
+    """out[N] = w[N, heads*head_dim] . (attention output assembled from work.ws) + bias + residual: the o_proj of the decode
+    step after attn_decode(..., defer_merge=True)."""
+    _bf16(w, residual)
+    _f32(bias)
+    N, K = w.shape
+    assert K == heads * head_dim and w.stride(1) == 1
+    if out is None:
+        out = torch.empty((1, N), dtype=out_dtype, device=w.device)
+    assert out.numel() == N and out.is_contiguous()
+    if residual is not None:
+        assert residual.numel() == N and residual.is_contiguous()
+    _launch("g4r_gemv_attn_merge_bf16", (_p(work.ws), work.splits, head_dim, _p(w), _p(out), _p(bias), _p(residual), N, K,
+                                         w.stride(0), 1 if out.dtype == torch.float32 else 0, _stream(w),),
+            tag="gemv_bf16", flops=2.0 * N * K, nbytes=2.0 * N * K)
     return out
 
 

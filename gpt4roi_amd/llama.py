@@ -80,9 +80,15 @@ class LlamaDecoder:
         for li, L in enumerate(self.layers):
             h = K.rmsnorm(x, L['n1'], self.eps)
             qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
-            for b in range(B):
-                K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, pos0)
-            a = K.flash_attn(q, self.kc[li, :B, :pos0 + T], self.vc[li, :B, :pos0 + T], H, scale, True)
+            if T == 1:                                       # decode step: RoPE + cache append + split-key attention
+                a = torch.empty_like(q)
+                for b in range(B):
+                    K.attn_decode(None, self.kc[li, b], self.vc[li, b], H, scale, self._attn_work(), kv_len=pos0 + 1,
+                                  out=a[b].view(-1), qkv=qkv[b].view(-1), cos=self.cos, sin=self.sin)
+            else:
+                for b in range(B):
+                    K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, pos0)
+                a = K.flash_attn(q, self.kc[li, :B, :pos0 + T], self.vc[li, :B, :pos0 + T], H, scale, True)
             x = K.gemm(a.view(B * T, C), L['wo'], residual=x)
             h = K.rmsnorm(x, L['n2'], self.eps)
             f = K.gemm(h, L['wgu'], act="swiglu")            # gate|up GEMM with the SiLU*up epilogue
@@ -282,6 +288,13 @@ class LlamaDecoder:
                     u=torch.zeros(n, dtype=torch.float32, device=dev),
                     out=torch.zeros(n, dtype=torch.int64, device=dev), graphs={})
 
+    def _attn_work(self):
+        w = getattr(self, "_attn_ws", None)
+        if w is None:
+            with torch.inference_mode(False):
+                w = self._attn_ws = K.DecodeAttnWorkspace(self.heads, self.head_dim, self.device, splits=8)
+        return w
+
     def _advance(self, logits_row, st, sampler):
         """Token selection on the device: argmax (generate(do_sample=False)) or one temperature / top-k / top-p draw
         (do_sample=True, app.py:293-300); sampler = (temperature, top_k, top_p)."""
@@ -299,18 +312,18 @@ class LlamaDecoder:
         x, _ = K.splice_embed(st["tok"], self.embed, None, None, None, 0, -1, -1, -1, -1)
         x = x.view(1, C)
         scale = 1.0 / math.sqrt(D)
-        q = torch.empty((1, 1, C), dtype=torch.bfloat16, device=x.device)
+        work = self._attn_work()
+        # 5 launches per layer: the two RMSNorms ride in the prologue of the GEMVs they feed; RoPE and the cache append
+        # ride in the attention launch, which splits the cached keys of a head over 8 workgroups (the tiled prefill
+        # kernel would run this case with one workgroup per head); their partials are merged by the o_proj's staging
         for li, L in enumerate(self.layers):
-            h = K.rmsnorm(x, L['n1'], self.eps)
-            qkv = K.gemm(h, L['wqkv'])
-            K.rope_qkv(qkv, self.cos, self.sin, q[0], self.kc[li, 0], self.vc[li, 0], H, D, 0, pos_dev=st["pos"])
-            a = K.flash_attn(q, self.kc[li, :1], self.vc[li, :1], H, scale, True, kv_len_dev=st["pos"])
-            x = K.gemm(a.view(1, C), L['wo'], residual=x)
-            h = K.rmsnorm(x, L['n2'], self.eps)
-            f = K.gemm(h, L['wgu'], act="swiglu")
-            x = K.gemm(f, L['wd'], residual=x)
-        xn = K.rmsnorm(x, self.norm, self.eps)
-        logits = K.gemm(xn, self.lm_head, out_dtype=torch.float32)
+            qkv = K.gemv(x, L['wqkv'], norm_weight=L['n1'], eps=self.eps)
+            K.attn_decode(None, self.kc[li, 0], self.vc[li, 0], H, scale, work, kv_len_dev=st["pos"], qkv=qkv,
+                          cos=self.cos, sin=self.sin, defer_merge=True)
+            x = K.gemv_attn_merge(work, H, D, L['wo'], residual=x)
+            f = K.gemv(x, L['wgu'], norm_weight=L['n2'], eps=self.eps, act="swiglu")
+            x = K.gemv(f, L['wd'], residual=x)
+        logits = K.gemv(x, self.lm_head, norm_weight=self.norm, eps=self.eps, out_dtype=torch.float32)
         self._advance(logits.view(-1), st, sampler)
 
     @torch.no_grad()

@@ -222,6 +222,8 @@ class SPILlavaLlamaModel(nn.Module):
         other = copy.copy(self)                      # nn.Module shallow copy: parameters are shared
         other.llama = copy.copy(self.llama)
         other.llama._alloc_cache(self.llama.kc.size(1))
+        other.llama._attn_ws = None                  # per-context decode workspaces (the contexts run on different streams)
+        other.llama._dstate = None
         other.last_status = None
         return other
 

@@ -65,6 +65,43 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
                             long q_batch, long k_batch, long v_batch, long o_batch, float scale,
                             int causal, const int* kv_len_dev, float* lse, void* stream);
 
+/*
+ * One activation row through a projection, with the RMSNorm in front of it fused in: the per-token form of
+ * `LlamaRMSNorm` + `nn.Linear` that the decode loop of gpt4roi/app.py:293-300 runs 4x per layer (HF LlamaDecoderLayer).
+ *   C [N] = act(W [N, K] . h + bias) + residual,  h = gamma ? bf16(bf16(x * rsqrt(mean(x^2) + eps)) * gamma) : x
+ * x [K] bf16, gamma fp32 [K] or null, W bf16 rows `ldw` elements apart, C bf16 (or fp32 with out_f32), act as in
+ * g4r_gemm_bf16_nt (4 = SwiGLU over interleaved (gate, up) rows: C has N/2 entries).  K >= 512, K % 8 == 0,
+ * K <= 8192 with gamma (<= 32768 without).  h is bit-identical to g4r_rmsnorm_bf16's output.
+ */
+int g4r_gemv_rmsnorm_bf16(const void* x, const float* gamma, float eps, const void* W, void* C, const float* bias,
+                          const void* residual, int N, int K, int ldw, int act, int out_f32, void* stream);
+
+/*
+ * Single-query attention over a KV cache: the per-token step of the decode loop the reference reaches through HF
+ * `generate()` (gpt4roi/app.py:293-300 -> LlamaAttention with past_key_values).  Q/O [H*head_dim] bf16; K/V cache rows
+ * `k_row`/`v_row` elements apart; the first Tk rows are attended, Tk = *kv_len_dev + 1 when kv_len_dev is given (read on
+ * the device: the call is replayed from a hipGraph).  The keys of a head are split over `splits` workgroups that merge
+ * inside the launch: workspace = H*splits*(head_dim+2) floats, counters = H uint32, zero before the first call (each call
+ * leaves them zero).  Same result as g4r_flash_attn_fwd_bf16 with Tq = 1, causal, up to fp32 summation order.
+ * qkv (nullable): the raw q|k|v projection row [3*H*head_dim] of the new token.  When given, Q is ignored and the call
+ * also performs g4r_rope_qkv_bf16 for that token: q and k are rotated with row Tk-1 of the cos/sin tables
+ * ([maxT, head_dim/2] fp32), the rotated k and v are written to row Tk-1 of the caches (LlamaAttention's
+ * apply_rotary_pos_emb + cache append).
+ * defer_merge: leave the per-split partials in `workspace` for g4r_gemv_attn_merge_bf16 (O and counters unused).
+ */
+int g4r_attn_decode_bf16(const void* Q, const void* qkv, const float* cos_tab, const float* sin_tab, void* K, void* V,
+                         void* O, float* workspace, unsigned* counters, int H, int head_dim, int Tk, long k_row,
+                         long v_row, float scale, int splits, const int* kv_len_dev, int defer_merge, void* stream);
+
+/*
+ * o_proj of the decode step with the merge of the attention partials fused into its input staging:
+ * C [N] = W [N, K] . a + bias + residual, a [K = H*head_dim] = the attention output assembled from
+ * `partials` [H][splits][head_dim + 2] fp32 as written by g4r_attn_decode_bf16(..., defer_merge = 1).  Bit-identical to
+ * g4r_attn_decode_bf16(defer_merge = 0) followed by g4r_gemv_rmsnorm_bf16(gamma = null).
+ */
+int g4r_gemv_attn_merge_bf16(const float* partials, int splits, int head_dim, const void* W, void* C, const float* bias,
+                             const void* residual, int N, int K, int ldw, int out_f32, void* stream);
+
 /* LayerNorm over the last dim (CLIP pre_layrnorm / layer_norm1,2; pos_embedd LayerNorms
  * gpt4roi/models/layers.py:260-267).  gamma/beta fp32.  relu_in: apply ReLU to x first. */
 int g4r_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, int rows, int cols,

@@ -179,3 +179,75 @@ def test_from_pretrained_directory_round_trip_on_the_gpu(tmp_path):
                        back.generate(prompt, images=img, bboxes=boxes, max_new_tokens=6))
     info = back.model.initialize_vision_modules(clip, mm_vision_select_layer=-2)
     assert info["image_token_len"] == 64 and info["vision_config"].mm_hidden_size == 512
+
+
+class _BotTok:
+    """Word-level tokenizer with both call styles the bot's collaborators use: HF batch call (prompt.py) and the plain
+    call + batch_decode of KeywordsStoppingCriteria.  Special tokens carry the model's configured ids."""
+
+    def __init__(self, ids, model_max_length=2048):
+        self.special = {"<im_patch>": ids.im_patch_token, "<bbox>": ids.bbox_token, "<point>": ids.point_token,
+                        "<im_start>": ids.im_start_token, "<im_end>": ids.im_end_token}
+        self.vocab = {"<pad>": 0, "<s>": 1, "###": 5}
+        self.pad_token_id, self.model_max_length = 0, model_max_length
+
+    def _ids(self, text):
+        import re
+        out = []
+        for piece in re.split("(" + "|".join(re.escape(t) for t in self.special) + ")", text):
+            if piece in self.special:
+                out.append(self.special[piece])
+            else:
+                out += [self.vocab.setdefault(w, 10 + len(self.vocab)) for w in piece.split()]
+        return out
+
+    def __call__(self, text, return_tensors=None, padding=None, max_length=None, truncation=None):
+        from types import SimpleNamespace
+        if return_tensors is None:
+            return SimpleNamespace(input_ids=self._ids(text))
+        rows = [[1] + self._ids(t) for t in ([text] if isinstance(text, str) else text)]
+        n = max(len(r) for r in rows)
+        return SimpleNamespace(input_ids=torch.tensor([r + [0] * (n - len(r)) for r in rows], dtype=torch.int64))
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        inv = {v: k for k, v in self.vocab.items()}
+        return [" ".join(inv.get(t, f"t{t}") for t in row if not (skip_special_tokens and t in self.special.values()))
+                for row in ids.tolist()]
+
+
+def test_headless_conversation_bot_rounds():
+    """serve.ConversationBot.run (gpt4roi/app.py:243-328 without the UI): check -> prompt assembly -> image kernel ->
+    partial-bound forward -> sampling generate with the '###' criterion -> answer + history; a fixed seed reproduces the
+    answer, greedy equals a direct generate() on the same inputs, a second round reuses the boxes of the first."""
+    from gpt4roi_amd.serve import ConversationBot
+    lm, ids, _, _, _ = _mini_lm()
+    tok = _BotTok(ids)
+    bot = ConversationBot(lm, tok, image_size=112)
+    g = torch.Generator().manual_seed(5)
+    picture = torch.randint(0, 256, (300, 400, 3), generator=g, dtype=torch.uint8).numpy()
+    image = {"image": picture, "boxes": [[20, 30, 220, 260], [100, 10, 390, 200]]}
+    ans1, err, hist1 = bot.run("What is <region1> doing next to <region2> ?", image, [], max_new_tokens=10, seed=3)
+    ans2, _, _ = bot.run("What is <region1> doing next to <region2> ?", image, [], max_new_tokens=10, seed=3)
+    assert err is None and isinstance(ans1, str) and ans1 == ans2 and len(ans1) > 0
+    conv = hist1[-1]["sources"]["conversations"]
+    assert [t["from"] for t in conv] == ["human", "gpt"] and conv[1]["value"] == ans1.replace("Assistant: ", "")
+    assert hist1[-1]["bboxes"].shape == (2, 4) and float(hist1[-1]["bboxes"].max()) <= 1.0
+    assert lm.forward == lm.orig_forward                                   # the partial binding was undone
+    # greedy through the bot == generate() called directly with the bot's own inputs
+    hist = []
+    data, hist = bot.init_inputs(image, "What is <region1> doing next to <region2> ?", hist)
+    T = data["input_ids"].numel()
+    assert int((data["input_ids"] == ids.bbox_token).sum()) == 2 and int((data["input_ids"] == ids.im_patch_token).sum()) == 64
+    direct = lm.generate(data["input_ids"][None].to(DEV), images=data["image"][None], bboxes=[data["bboxes"].to(DEV)],
+                         do_sample=False, max_new_tokens=6)
+    ans_g, _, hist_g = bot.run("What is <region1> doing next to <region2> ?", image, [], do_sample=False, max_new_tokens=6)
+    want = tok.batch_decode(direct[:, T:])[0].strip()
+    want = want[:-3].strip() if want.endswith("###") else want
+    assert ans_g == want
+    # second round: no new box, an old region mentioned again -> same two boxes, longer prompt
+    ans3, err3, hist3 = bot.run("And what colour is <region2> ?", {"image": picture, "boxes": []}, hist_g, do_sample=False,
+                                max_new_tokens=4)
+    assert err3 is None and len(hist3[-1]["sources"]["conversations"]) == 4 and hist3[-1]["bboxes"].shape == (2, 4)
+    # malformed round: a region mentioned without a box
+    none, err4, _ = bot.run("What about <region7> ?", {"image": picture, "boxes": []}, hist3)
+    assert none is None and "region" in err4

@@ -510,3 +510,105 @@ def test_splice_embed():
     bad[0, 5 + NP] = 7                      # missing <im_end>
     _, st = K.splice_embed(bad, embed, img, spi, off, NP, PATCH, BBOX, IMS, IME)
     assert st[1].item() & 2 and st[0].item() & 8
+
+
+# ------------------------------------------------------------------------------------------ decode step (row a17)
+@pytest.mark.parametrize("N,Kd,act,res,f32", [(12288, 4096, None, False, False), (4096, 4096, None, True, False),
+                                             (22016, 4096, "swiglu", False, False), (4096, 11008, None, True, False),
+                                             (32006, 4096, None, False, True), (1000, 512, None, False, False),
+                                             (36, 1088, "swiglu", False, False)])
+def test_gemv_with_fused_rmsnorm_is_bit_identical_to_the_two_launches(N, Kd, act, res, f32):
+    """g4r_gemv_rmsnorm_bf16 (the decode-step projections): the fused RMSNorm reproduces g4r_rmsnorm_bf16 bit for bit, so
+    fused == rmsnorm() -> gemm(M = 1); both within bf16 tolerance of an fp32 statement.  LLaMA-7B shapes + ragged ones."""
+    x = rnd(1, Kd, seed=1)
+    w = rnd(N, Kd, scale=Kd ** -0.5, seed=2)
+    gamma = (1 + 0.1 * torch.randn(Kd, generator=torch.Generator().manual_seed(3))).to(DEV)
+    r = rnd(1, N, seed=4) if res else None
+    od = torch.float32 if f32 else torch.bfloat16
+    h = K.rmsnorm(x, gamma, 1e-6) if Kd <= 8192 else x           # (down_proj has no norm in front of it)
+    two = K.gemm(h, w, residual=r, act=act, out_dtype=od)
+    plain = K.gemv(h, w, residual=r, act=act, out_dtype=od)              # no norm: x staged as it is
+    assert plain.shape == two.shape and torch.equal(plain, two)
+    one = K.gemv(x, w, norm_weight=gamma, eps=1e-6, residual=r, act=act, out_dtype=od) if Kd <= 8192 else plain
+    assert torch.equal(one, two)
+    ref = h.float() @ w.float().t()
+    if act == "swiglu":
+        g, u = ref[:, 0::2], ref[:, 1::2]
+        ref = (F.silu(g).to(torch.bfloat16).float() * u)
+    if res:
+        ref = ref + r.float()
+    close(one, ref, 2e-2, 2 ** -6, f"gemv {N}x{Kd}")
+
+
+@pytest.mark.parametrize("H,D,kv,splits", [(32, 128, 768, 8), (32, 128, 1, 8), (32, 128, 5, 8), (32, 128, 100, 13),
+                                           (32, 128, 2047, 8), (32, 128, 333, 1), (16, 64, 577, 8), (4, 64, 40, 3)])
+def test_attn_decode_split_keys(H, D, kv, splits):
+    """g4r_attn_decode_bf16: one query over `kv` cached rows, keys split over `splits` workgroups that merge in-launch.
+    Against fp32 softmax(q K^T) V and against the tiled kernel (Tq = 1); repeated calls re-arm the arrival counters;
+    the device-side length (graph replay) gives the same bits as the host-side one."""
+    T_max = 2048
+    q = rnd(H * D, seed=5)
+    kc = rnd(T_max, H * D, seed=6)
+    vc = rnd(T_max, H * D, seed=7)
+    scale = D ** -0.5
+    work = K.DecodeAttnWorkspace(H, D, DEV, splits=splits)
+    out = K.attn_decode(q, kc, vc, H, scale, work, kv_len=kv)
+    qh, kh, vh = q.float().view(H, 1, D), kc[:kv].float().view(kv, H, D).transpose(0, 1), vc[:kv].float().view(kv, H, D).transpose(0, 1)
+    ref = (torch.softmax(qh @ kh.transpose(1, 2) * scale, -1) @ vh).reshape(-1)
+    close(out, ref, 2e-3, 2 ** -7, "attn_decode vs fp32")
+    tiled = K.flash_attn(q.view(1, 1, -1), kc[None, :kv], vc[None, :kv], H, scale, True).view(-1)
+    close(out, tiled, 4e-3, 2 ** -6, "attn_decode vs tiled kernel")
+    assert int(work.cnt.abs().sum()) == 0
+    pos = torch.tensor([kv - 1], dtype=torch.int32, device=DEV)
+    for _ in range(3):
+        again = K.attn_decode(q, kc, vc, H, scale, work, kv_len_dev=pos)
+        assert torch.equal(again, out)
+    # a strided cache view (one batch slot of [L, B, T, C]) and a peaked row
+    big = torch.zeros(2, T_max, H * D, dtype=torch.bfloat16, device=DEV)
+    big[1].copy_(kc)
+    kq = big[1]
+    kq[min(3, kv - 1)] = (q.float() * 4).to(torch.bfloat16)
+    out2 = K.attn_decode(q, kq, vc, H, scale, work, kv_len=kv)
+    kh2 = kq[:kv].float().view(kv, H, D).transpose(0, 1)
+    ref2 = (torch.softmax(qh @ kh2.transpose(1, 2) * scale, -1) @ vh).reshape(-1)
+    close(out2, ref2, 2e-3, 2 ** -7, "attn_decode peaked")
+
+
+@pytest.mark.parametrize("H,D,pos", [(32, 128, 767), (32, 128, 0), (32, 128, 17), (16, 64, 300)])
+def test_attn_decode_with_fused_rope_and_cache_append(H, D, pos):
+    """qkv= form of g4r_attn_decode_bf16: RoPE of q and k at row `pos`, cache append and attention in one launch ==
+    g4r_rope_qkv_bf16 followed by the q= form, bit for bit (output and the appended cache rows)."""
+    T_max, C = 1024, H * D
+    qkv = rnd(1, 3 * C, seed=11)
+    kc, vc = rnd(T_max, C, seed=12), rnd(T_max, C, seed=13)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(T_max).float()[:, None] * inv[None]
+    cos, sin = ang.cos().contiguous().to(DEV), ang.sin().contiguous().to(DEV)
+    scale = D ** -0.5
+    k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+    q = torch.empty(1, C, dtype=torch.bfloat16, device=DEV)
+    K.rope_qkv(qkv, cos, sin, q, k1, v1, H, D, pos)
+    work = K.DecodeAttnWorkspace(H, D, DEV)
+    want = K.attn_decode(q.view(-1), k1, v1, H, scale, work, kv_len=pos + 1)
+    pos_dev = torch.tensor([pos], dtype=torch.int32, device=DEV)
+    got = K.attn_decode(None, k2, v2, H, scale, work, kv_len_dev=pos_dev, qkv=qkv.view(-1), cos=cos, sin=sin)
+    assert torch.equal(got, want)
+    assert torch.equal(k2, k1) and torch.equal(v2, v1)               # row `pos` appended, nothing else touched
+    assert not torch.equal(k2[pos], kc[pos])
+
+
+@pytest.mark.parametrize("H,D,kv,splits", [(32, 128, 800, 8), (32, 128, 3, 8), (32, 128, 2047, 4), (16, 64, 577, 5)])
+def test_attn_partials_merged_by_the_o_proj_gemv(H, D, kv, splits):
+    """defer_merge: the attention leaves its per-split partials in the workspace and g4r_gemv_attn_merge_bf16 assembles
+    the attention output while staging its input -- bit-identical to the in-launch merge followed by the plain GEMV."""
+    C = H * D
+    q, kc, vc = rnd(C, seed=21), rnd(2048, C, seed=22), rnd(2048, C, seed=23)
+    wo, res = rnd(C, C, scale=C ** -0.5, seed=24), rnd(1, C, seed=25)
+    scale = D ** -0.5
+    work = K.DecodeAttnWorkspace(H, D, DEV, splits=splits)
+    a = K.attn_decode(q, kc, vc, H, scale, work, kv_len=kv)
+    want = K.gemv(a, wo, residual=res)
+    assert K.attn_decode(q, kc, vc, H, scale, work, kv_len=kv, defer_merge=True) is None
+    got = K.gemv_attn_merge(work, H, D, wo, residual=res)
+    assert torch.equal(got, want)
+    close(got, a.float()[None] @ wo.float().t() + res.float(), 2e-2, 2 ** -6, "o_proj of merged partials")

@@ -1,0 +1,49 @@
+"""tools/decode_bench.py -- the KV-cache decode step of row a17 in isolation (LLaMA-7B shapes, synthetic weights, batch 1):
+ms per token of the captured hipGraph, and the weight-streaming rate it corresponds to.  Run under
+`rocprofv3 --kernel-trace --stats` for the per-kernel split (tools/gpu_run10.sh).
+    python tools/decode_bench.py [--tokens 64] [--prompt 767] [--layers 32] [--sample]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tokens", type=int, default=64)
+    ap.add_argument("--prompt", type=int, default=767)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--sample", action="store_true")
+    a = ap.parse_args()
+    from gpt4roi_amd import synthetic as syn
+    from gpt4roi_amd.llama import LlamaDecoder
+    torch.set_grad_enabled(False)
+    dev = torch.device("cuda:0")
+    l = syn.LLAMA_7B
+    lsd = syn.llama_state(l["hidden"], l["inter"], a.layers, 32006, seed=1, device=dev, dtype=torch.bfloat16)
+    dec = LlamaDecoder(lsd, heads=l["heads"], max_positions=2048, device=dev)
+    del lsd
+    emb = (torch.randn(1, a.prompt, l["hidden"], device=dev) * 0.02).to(torch.bfloat16)
+    sampler = (0.2, 50, 1.0) if a.sample else None
+    dec.decode_graph(emb, 8, sampler=sampler, seed=1)
+    torch.cuda.synchronize()
+
+    def timed(n):
+        t0 = time.perf_counter()
+        dec.decode_graph(emb, n, sampler=sampler, seed=1)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    timed(4)
+    t_long, t_short = min(timed(a.tokens + 2) for _ in range(3)), min(timed(2) for _ in range(3))
+    dt = (t_long - t_short) / a.tokens
+    wbytes = sum(L[k].numel() * 2 for L in dec.layers for k in ("wqkv", "wo", "wgu", "wd")) + dec.lm_head.numel() * 2
+    print({"ms_per_token": round(1e3 * dt, 3), "tokens_per_s": round(1 / dt, 1), "weight_GB": round(wbytes / 1e9, 2),
+           "weight_stream_GBps": round(wbytes / dt / 1e9, 1), "layers": a.layers, "prompt": a.prompt, "sampled": a.sample})
+
+
+if __name__ == "__main__":
+    main()

@@ -4,7 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O2 tools/gemm_bench.cpp -Lgpt4roi_amd/lib -lgpt4roi_hip \
 //         -Wl,-rpath,'$ORIGIN/../../gpt4roi_amd/lib' -o tools/probe/gemm_bench
 //   tools/probe/gemm_bench [--rounds R] [--fill u|z|n] case...
-//     case = g:M,N,K,tile,splits[,act[,f32]]      dense C = A W^T through g4r_gemm_bf16_nt
+//     case = g:M,N,K,tile,splits[,act[,f32[,dbg]]] dense C = A W^T through g4r_gemm_bf16_nt (M = 1: dbg 100+v picks GEMV variant v)
 //            c:B,H,W,C,tile,splits[,dbg]         3x3 conv through g4r_conv3x3_nhwc_bf16 (Cin = Cout = C); dbg 7 = taps-outermost K order
 //
 // Every case is checked on 8192 sampled outputs against an fp32 dot product computed by a trivial kernel, then timed
@@ -27,6 +27,8 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
 int g4r_conv3x3_nhwc_bf16(const void* X, const void* W, void* Y, const float* bias, const void* zeros, float* workspace,
                           int batch, int H, int Wd, int Cin, int Cout, int groups, long x_group_stride, int act,
                           int out_f32, int splits, int tile_cfg, void* stream);
+int g4r_gemv_rmsnorm_bf16(const void* x, const float* gamma, float eps, const void* W, void* C, const float* bias,
+                          const void* residual, int N, int K, int ldw, int act, int out_f32, void* stream);
 const char* g4r_last_error(void);
 void g4r_gemm_debug_mode(int mode);
 }
@@ -111,6 +113,8 @@ __global__ void ref_conv_kernel(const uint16_t* X, const uint16_t* W, int B, int
 
 static int launch(Case& c, hipStream_t st) {
   g4r_gemm_debug_mode(c.dbg);
+  if (c.kind == 'v')   // decode-step GEMV with the fused RMSNorm (gamma = the fp32 buffer in c.ws)
+    return g4r_gemv_rmsnorm_bf16(c.A, c.ws, 1e-6f, c.Wt, c.Cout, nullptr, nullptr, c.N, c.K, c.K, 0, 0, st);
   if (c.kind == 'g')
     return g4r_gemm_bf16_nt(c.A, c.Wt, c.Cout, nullptr, nullptr, c.ws, c.M, c.N, c.K, c.K, c.K,
                             c.act == 4 ? c.N / 2 : c.N, 0, c.act, c.f32, c.splits, c.tile, st);
@@ -131,8 +135,11 @@ int main(int argc, char** argv) {
     int n = 0;
     for (char* tok = strtok(argv[i] + 2, ","); tok && n < 8; tok = strtok(nullptr, ",")) v[n++] = atoi(tok);
     if (c.kind == 'g') {
-      c.M = v[0]; c.N = v[1]; c.K = v[2]; c.tile = v[3]; c.splits = v[4] < 1 ? 1 : v[4]; c.act = v[5]; c.f32 = v[6];
+      c.M = v[0]; c.N = v[1]; c.K = v[2]; c.tile = v[3]; c.splits = v[4] < 1 ? 1 : v[4]; c.act = v[5]; c.f32 = v[6]; c.dbg = v[7];
       c.flops = 2.0 * c.M * c.N * c.K;
+    } else if (c.kind == 'v') {   // v:N,K,variant  (timing only: the pytest suite checks the values)
+      c.M = 1; c.N = v[0]; c.K = v[1]; c.dbg = 100 + v[2]; c.splits = 1; c.act = 1;
+      c.flops = 2.0 * c.N * c.K;
     } else if (c.kind == 'c') {
       c.B = v[0]; c.H = v[1]; c.W = v[2]; c.C = v[3]; c.tile = v[4]; c.splits = v[5] < 1 ? 1 : v[5]; c.dbg = v[6];
       c.M = c.B * c.H * c.W; c.N = c.C; c.K = 9 * c.C;
@@ -152,7 +159,7 @@ int main(int argc, char** argv) {
   std::vector<float> h_ref(NS);
   std::vector<int> h_mn(2 * NS);
   for (auto& c : cases) {
-    const size_t na = c.kind == 'g' ? (size_t)c.M * c.K : (size_t)c.M * c.C, nw = (size_t)c.N * c.K;
+    const size_t na = c.kind != 'c' ? (size_t)c.M * c.K : (size_t)c.M * c.C, nw = (size_t)c.N * c.K;
     const size_t ncols = c.act == 4 ? c.N / 2 : c.N;
     const size_t nc = (size_t)c.M * ncols * (c.f32 ? 4 : 2);
     CK(hipMalloc(&c.A, na * 2));
@@ -162,6 +169,11 @@ int main(int argc, char** argv) {
     CK(hipMemset(c.zeros, 0, 512));
     c.ws = nullptr;
     if (c.splits > 1) CK(hipMalloc(&c.ws, (size_t)c.splits * c.M * c.N * 4));
+    if (c.kind == 'v') {
+      CK(hipMalloc(&c.ws, (size_t)c.K * 4));
+      std::vector<float> ones(c.K, 1.0f);
+      CK(hipMemcpy(c.ws, ones.data(), (size_t)c.K * 4, hipMemcpyHostToDevice));
+    }
     fill_kernel<<<2048, 256, 0, st>>>(c.A, na, 11u, 1.0f, fill);
     fill_kernel<<<2048, 256, 0, st>>>(c.Wt, nw, 23u, 1.0f / sqrtf((float)c.K / 3.f), fill);
     CK(hipMemsetAsync(c.Cout, 0xff, nc, st));
