@@ -52,7 +52,7 @@ def parse():
                     help="extra (not part of `value`): timed stage-1 training steps (SURVEY.md 8d config 3: batch 8 per GPU, "
                          "region module + projector trainable, gradient exchange over RCCL when N > 1); 0 = skip")
     ap.add_argument("--train-batch", type=int, default=8)
-    ap.add_argument("--decode-tokens", type=int, default=16,
+    ap.add_argument("--decode-tokens", type=int, default=32,
                     help="extra (not part of `value`): greedy KV-cache decode steps timed after the prefill")
     return ap.parse_args()
 
@@ -334,8 +334,8 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_report.json")))
         except Exception:
             pass
-        PMC_NAME = {"gemm_bf16_nt<256x256pp32>": "void gemm_bf16_pp32_kernel<0, false>",
-                    "conv3x3_igemm<256x256pp32>": "void gemm_bf16_pp32_kernel<1, false>",
+        PMC_NAME = {"gemm_bf16_nt<256x256pp32>": "void gemm_bf16_pp32_kernel<0, false, 256, 256>",
+                    "conv3x3_igemm<256x256pp32>": "void gemm_bf16_pp32_kernel<1, false, 256, 256>",
                     "gemm_bf16_nt<128x128w8s4>": "void gemm_bf16_nt_kernel<128, 128, 2, 4, 0, true, 4, 64, 0>",
                     "roi_align_mlvl_nhwc": "void roi_align_mlvl_nhwc_kernel<unsigned short, true>"}
         rec = pmc.get(PMC_NAME.get(dom, ""), {})
@@ -347,6 +347,16 @@ def main():
         if rec.get("mfma_util") is not None:
             roofline["pmc"] = {"mfma_util": rec["mfma_util"], "clock_GHz": rec["clock_GHz"],
                                "source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), clock = GRBM_GUI_ACTIVE / 8 / duration"}
+        cv = agg.get("conv3x3_igemm<256x256pp32>")
+        if cv and cv.get("flops"):
+            crec = pmc.get(PMC_NAME["conv3x3_igemm<256x256pp32>"], {})
+            tf = cv["flops"] / (cv["ms"] * 1e-3) / 1e12
+            roofline["conv"] = {"kernel": "conv3x3_igemm<256x256pp32>", "bound": "mfma", "achieved": round(tf, 1),
+                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                                "avg_launch_us": round(1e3 * cv["ms"] / cv["calls"], 2),
+                                "algorithmic_bytes_per_launch": int(cv["bytes"] / cv["calls"]),
+                                "traffic": (crec["hbm_read_bytes"] + crec.get("hbm_write_bytes", 0)) if "hbm_read_bytes" in crec else None,
+                                "pmc": ({"mfma_util": crec["mfma_util"], "clock_GHz": crec["clock_GHz"]} if crec.get("mfma_util") is not None else None)}
         ra = agg.get("roi_align_mlvl_nhwc")
         if ra:
             gbs = ra["bytes"] / (ra["ms"] * 1e-3) / 1e9
@@ -372,8 +382,15 @@ def main():
         torch.cuda.synchronize()
         dtd = (t_all - (time.perf_counter() - t0)) / args.decode_tokens
         wbytes = sum(L[k].numel() * 2 for L in model.llama.layers for k in ("wqkv", "wo", "wgu", "wd")) + model.llama.lm_head.numel() * 2
+        kvbytes = 2 * 2 * model.llama.hidden * len(model.llama.layers) * (prompt.size(1) + args.decode_tokens // 2)
         decode = {"ms_per_token": round(1e3 * dtd, 3), "tokens_per_s": round(1.0 / dtd, 1),
-                  "weight_stream_GBps": round(wbytes / dtd / 1e9, 1), "note": "batch 1, KV cache, one hipGraph replay per token (token id and position stay on the device)"}
+                  "weight_stream_GBps": round(wbytes / dtd / 1e9, 1),
+                  "roofline": {"bound": "hbm", "achieved": round((wbytes + kvbytes) / dtd / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round((wbytes + kvbytes) / dtd / 8e12, 4),
+                               "algorithmic_bytes_per_token": int(wbytes + kvbytes),
+                               "what": "whole decode step (161 launches: 4 GEMVs + 1 attention per layer, lm_head, token selection); "
+                                       "bytes = every bf16 weight once + the K/V rows attended"},
+                  "note": "batch 1, KV cache, one hipGraph replay per token (token id and position stay on the device)"}
 
     vit = None
     if rank == 0 and not args.no_roofline:

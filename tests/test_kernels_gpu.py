@@ -612,3 +612,24 @@ def test_attn_partials_merged_by_the_o_proj_gemv(H, D, kv, splits):
     got = K.gemv_attn_merge(work, H, D, wo, residual=res)
     assert torch.equal(got, want)
     close(got, a.float()[None] @ wo.float().t() + res.float(), 2e-2, 2 ** -6, "o_proj of merged partials")
+
+
+@pytest.mark.parametrize("N", [32006, 1000, 7, 4096])
+def test_greedy_advance_is_argmax_with_lowest_index_ties(N):
+    """g4r_greedy_advance (device-side token selection of generate(do_sample=False)): argmax with torch's tie rule,
+    output slot / step / position counters advanced on the device."""
+    g = torch.Generator().manual_seed(N)
+    lg = torch.randn(N, generator=g).to(DEV)
+    hi = float(lg.max()) + 1.0
+    for plant in ([], [N - 1], [N // 2, N // 2 + 1, N - 1], [0, N - 1]):
+        row = lg.clone()
+        for i in plant:
+            row[i] = hi
+        tok = torch.zeros((1, 1), dtype=torch.int64, device=DEV)
+        out = torch.full((8,), -1, dtype=torch.int64, device=DEV)
+        step = torch.tensor([2], dtype=torch.int32, device=DEV)
+        pos = torch.tensor([40], dtype=torch.int32, device=DEV)
+        K.greedy_advance(row, tok, out, step, pos)
+        want = int(row.argmax())
+        assert int(tok) == want and out.tolist() == [-1, -1, want, -1, -1, -1, -1, -1]
+        assert int(step) == 3 and int(pos) == 41
