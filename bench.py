@@ -410,10 +410,9 @@ def main():
             last["graph_error"] = graph_error
             torch.cuda.empty_cache()
             train = train_leg(args, model, ids, device, rank, world, dist, device if backend == "nccl" else "cpu")
-        except Exception as ex:                                      # never lose the headline
-            train = {"error": repr(ex)}
-            if dist is not None:
-                raise
+        except Exception as ex:                                      # never lose the headline: every rank carries on to the
+            train = {"error": repr(ex)}                              # end and exits 0 (no collective follows this leg); a
+            #                                                          rank left waiting in one gets the group's timeout here
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

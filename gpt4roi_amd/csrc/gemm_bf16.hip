@@ -45,6 +45,9 @@ struct GemmArgs {
   int out_f32;
   int splits, tiles_per_split;  // K tiles (of 64) per z slice
   int H, Wd, Cin, groups;      // AMODE 1 geometry
+  int lvl_start[5];            // AMODE 2: first row of each level's maps (lvl_start[n_lvl] = M), levels stacked [level][b][y][x]
+  int lvl_h[4], lvl_w[4];      // AMODE 2: map size per level
+  int n_lvl;
   int tiles_m, tiles_n;
   int n_fastest;  // tile order: 1 = consecutive workgroups walk N first (share the A / activation tile)
   int dbg;  // ablation probe (tools only): 1 = skip the loads after the first tile, 2 = skip the MFMAs
@@ -1142,6 +1145,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
 
   const bf16_t* a_src[NA];
   int a_y[NA], a_x[NA];
+  int a_h[NA], a_w[NA];                    // AMODE 2: the row's own map size (rows of several pyramid levels in one GEMM)
   const bf16_t* b_src[NB];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
@@ -1152,6 +1156,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     if (gm > p.M - 1) gm = p.M - 1;
     a_src[j] = p.A + (size_t)gm * p.lda + kslot * 8;
     a_y[j] = a_x[j] = 0;
+    a_h[j] = p.H; a_w[j] = p.Wd;
+    if (AMODE == 2) {
+      int lv = 0;
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (q < p.n_lvl && gm >= p.lvl_start[q]) lv = q;
+      a_h[j] = p.lvl_h[lv]; a_w[j] = p.lvl_w[lv];
+      const int local = gm - p.lvl_start[lv];
+      const int hw = a_h[j] * a_w[j];
+      const int rem = local - (local / hw) * hw;
+      a_y[j] = rem / a_w[j];
+      a_x[j] = rem - a_y[j] * a_w[j];
+    }
     if (AMODE == 1) {
       const int hw = p.H * p.Wd;
       const int b = gm / hw, rem = gm - b * hw;
@@ -1174,7 +1191,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     ts.k0 = t * BKT;
     ts.a_off = ts.k0;
     ts.dy = ts.dx = 0;
-    if (AMODE == 1) {
+    if (AMODE >= 1) {
       const int n_taps = 9 * p.groups;          // taps fastest, channel slice outer (see gemm_bf16_nt_kernel)
       int ct = t / n_taps;
       int tap_lin = t - ct * n_taps;
@@ -1188,6 +1205,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
       ts.dy = tap / 3 - 1;
       ts.dx = tap - (tap / 3) * 3 - 1;
       ts.a_off = (long)g * p.a_group_stride + ((long)ts.dy * p.Wd + ts.dx) * p.lda + c0;
+      if (AMODE == 2) ts.a_off = c0;            // the pixel shift depends on the row's own map width: added per piece
       ts.k0 = tap_lin * p.Cin + c0;
     }
     return ts;
@@ -1197,9 +1215,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     char* sa = smem + buf * STAGE_BYTES;
     if (j < NA) {
       const bf16_t* src = a_src[j] + ts.a_off;
-      if (AMODE == 1) {
+      if (AMODE == 2) src += (long)(ts.dy * a_w[j] + ts.dx) * p.lda;
+      if (AMODE >= 1) {
         const int yy = a_y[j] + ts.dy, xx = a_x[j] + ts.dx;
-        if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.Wd) src = p.zeros + (lane & 3) * 8;
+        if (yy < 0 || yy >= a_h[j] || xx < 0 || xx >= a_w[j]) src = p.zeros + (lane & 3) * 8;
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sa + (j * NW + wave) * 1024), 16, 0, 0);
@@ -1802,6 +1821,37 @@ int g4r_conv3x3_nhwc_bf16(const void* X, const void* W, void* Y, const float* bi
   p.n_fastest = 1; p.dbg = g_gemm_dbg;
   p.splits = splits;
   return launch_gemm<1>(p, tile_cfg, (hipStream_t)stream);
+}
+
+// The 3x3 convolutions of ONE fuse round over all pyramid levels as a single implicit GEMM (gpt4roi/models/layers.py:218-236
+// applies the SAME ConvModule to every level): X / Y hold the levels' NHWC maps stacked [level][b][y][x][C]; row m decodes
+// to (level, b, y, x) and shifts inside its own map.  For the 336^2 pyramid (192^2 + 96^2 + 48^2 + 24^2 = 48960 rows) the
+// launch has 192 x 4 = 768 tiles of 256 x 256 = exactly three waves of the 256 CUs, where the four separate launches leave
+// the chip partly idle in each of their tails (and the two small maps latency-bound on split-K tiles).
+int g4r_conv3x3_mlvl_nhwc_bf16(const void* X, const void* W, void* Y, const float* bias, const void* zeros, int n_levels,
+                               const int* level_h, const int* level_w, int batch, int Cin, int Cout, int act,
+                               void* stream) {
+  G4R_REQUIRE(n_levels >= 1 && n_levels <= 4 && batch >= 1 && Cin > 0 && Cout > 0, "conv3x3_mlvl: 1..4 levels");
+  G4R_REQUIRE(X && W && Y && zeros && level_h && level_w, "conv3x3_mlvl: null pointer");
+  G4R_REQUIRE((Cin % BK) == 0, "conv3x3_mlvl: Cin must be a multiple of 64");
+  G4R_REQUIRE(act >= 0 && act <= 3, "conv3x3_mlvl: act must be 0..3");
+  GemmArgs p = {};
+  long rows = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    G4R_REQUIRE(level_h[l] > 0 && level_w[l] > 0, "conv3x3_mlvl: bad map size");
+    p.lvl_start[l] = (int)rows;
+    p.lvl_h[l] = level_h[l]; p.lvl_w[l] = level_w[l];
+    rows += (long)batch * level_h[l] * level_w[l];
+  }
+  G4R_REQUIRE(rows < (1L << 31), "conv3x3_mlvl: too many rows");
+  for (int l = n_levels; l <= 4; ++l) p.lvl_start[l] = (int)rows;
+  p.n_lvl = n_levels;
+  p.A = (const bf16_t*)X; p.W = (const bf16_t*)W; p.C = Y; p.bias = bias; p.zeros = (const bf16_t*)zeros;
+  p.M = (int)rows; p.N = Cout; p.K = 9 * Cin;
+  p.lda = Cin; p.ldw = p.K; p.ldc = Cout;
+  p.act = act; p.H = level_h[0]; p.Wd = level_w[0]; p.Cin = Cin; p.groups = 1;
+  p.n_fastest = 1; p.dbg = g_gemm_dbg; p.splits = 1;
+  return launch_pp32<2>(p, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -19,6 +19,7 @@ _SIGS = {
                               c_int, c_int, c_int, P],
     "g4r_flash_attn_fwd_bf16": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long,
                                 c_long, c_long, c_long, c_long, c_float, c_int, P, P, P],
+    "g4r_conv3x3_mlvl_nhwc_bf16": [P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P],
     "g4r_gemv_rmsnorm_bf16": [P, P, c_float, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "g4r_attn_decode_bf16": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_long, c_long, c_float, c_int, P, c_int, P],
     "g4r_gemv_attn_merge_bf16": [P, c_int, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P],
@@ -327,6 +328,42 @@ def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=torch.bfloa
         gstride, ACT[act], 1 if out.dtype == torch.float32 else 0, splits, tile_cfg, _stream(x),),
         tag=f"conv3x3_igemm<{TILE_NAMES.get(tile_cfg, tile_cfg)}>", flops=2.0 * B * H * W * Cout * groups * 9 * Cin,
         nbytes=2.0 * (groups * B * H * W * Cin + Cout * groups * 9 * Cin + B * H * W * Cout))
+    return out
+
+
+class MlvlMaps:
+    """The NHWC maps of all pyramid levels in ONE buffer, stacked [level][b][y][x][C], with per-level views: the layout
+    conv3x3_mlvl reads and writes (one implicit GEMM over every level of a fuse round)."""
+
+    def __init__(self, B, sizes, C, device, dtype=torch.bfloat16):
+        self.B, self.sizes, self.C = B, [(int(h), int(w)) for h, w in sizes], C
+        rows = [B * h * w for h, w in self.sizes]
+        self.flat = torch.empty((sum(rows), C), dtype=dtype, device=device)
+        self.levels, off = [], 0
+        for (h, w), n in zip(self.sizes, rows):
+            self.levels.append(self.flat[off:off + n].view(B, h, w, C))
+            off += n
+        self._hw = (ctypes.c_int * len(self.sizes))(*[h for h, _ in self.sizes]), \
+            (ctypes.c_int * len(self.sizes))(*[w for _, w in self.sizes])
+
+
+def conv3x3_mlvl(x, w, bias=None, act=None, out=None):
+    """One 3x3 / pad 1 convolution with the SAME weights over every level of a pyramid (MlvlMaps in, MlvlMaps out): the
+    fuse round of gpt4roi/models/layers.py:218-236 as a single implicit GEMM launch."""
+    assert isinstance(x, MlvlMaps)
+    _bf16(x.flat, w)
+    _f32(bias)
+    Cout = w.size(0)
+    assert w.size(1) == 9 * x.C and w.is_contiguous() and len(x.sizes) <= 4
+    if out is None:
+        out = MlvlMaps(x.B, x.sizes, Cout, x.flat.device)
+    assert out.sizes == x.sizes and out.B == x.B and out.C == Cout
+    M = x.flat.size(0)
+    _launch("g4r_conv3x3_mlvl_nhwc_bf16", (
+        _p(x.flat), _p(w), _p(out.flat), _p(bias), _p(zeros_line(x.flat.device)), len(x.sizes), x._hw[0], x._hw[1], x.B,
+        x.C, Cout, ACT[act], _stream(x.flat),),
+        tag="conv3x3_igemm<256x256pp32>", flops=2.0 * M * Cout * 9 * x.C,
+        nbytes=2.0 * (M * x.C + Cout * 9 * x.C + M * Cout))
     return out
 
 

@@ -116,15 +116,19 @@ class MLVLFuseModule(nn.Module):
             x = K.upsample_coord(tok, P, P, H, H, self.cpad)
             y = K.gemm(x.view(B * H * H, self.cpad), r['w_in'][lvl], bias=r['b_in'][lvl])
             maps.append(y.view(B, H, H, self.embed_dims))
+        # One implicit-GEMM launch per round over ALL levels (the reference applies the same ConvModule to every level):
+        # the levels' maps live stacked in one buffer, 192 x 4 = 768 tiles = three full waves of the 256 CUs for the 336^2
+        # pyramid, instead of four launches that each leave a partly idle tail (1219 -> ~740 us per round).
+        hw = [(m.size(1), m.size(2)) for m in maps]
+        dev = maps[0].device
         for rnd in range(self.num_fuse):
             g, bt, groups, eps = r['gn'][rnd]
-            new_maps, new_affs = [], []
+            inp = K.MlvlMaps(B, hw, self.embed_dims, dev)
             for tar, top, dow in self.fuse_lvl_list:
-                inp = K.fuse_shuffle(maps[tar], maps[top], maps[dow], affs[tar], affs[top], affs[dow])
-                z = K.conv3x3(inp, r['w_f'][rnd])
-                new_maps.append(z)
-                new_affs.append(K.groupnorm_affine(z, g, bt, groups, eps))
-            maps, affs = new_maps, new_affs
+                K.fuse_shuffle(maps[tar], maps[top], maps[dow], affs[tar], affs[top], affs[dow], out=inp.levels[tar])
+            z = K.conv3x3_mlvl(inp, r['w_f'][rnd])
+            maps = z.levels
+            affs = [K.groupnorm_affine(m, g, bt, groups, eps) for m in maps]
         return maps, affs
 
 
@@ -144,17 +148,17 @@ class MLVLFuseModule(nn.Module):
             xs.append(x)
             maps.append(y.view(B, H, H, self.embed_dims))
         all_maps, all_affs = [maps], [[None] * self.num_levels]
+        hw = [(m.size(1), m.size(2)) for m in maps]
+        dev = maps[0].device
         for rnd in range(self.num_fuse):
             g, bt, groups, eps = r['gn'][rnd]
-            new_maps, new_affs = [], []
+            inp = K.MlvlMaps(B, hw, self.embed_dims, dev)          # all levels in one buffer: one conv launch per round
             for tar, top, dow in self.fuse_lvl_list:
-                inp = K.fuse_shuffle(all_maps[-1][tar], all_maps[-1][top], all_maps[-1][dow], all_affs[-1][tar],
-                                     all_affs[-1][top], all_affs[-1][dow])
-                z = K.conv3x3(inp, r['w_f'][rnd])
-                new_maps.append(z)
-                new_affs.append(K.groupnorm_affine(z, g, bt, groups, eps))
+                K.fuse_shuffle(all_maps[-1][tar], all_maps[-1][top], all_maps[-1][dow], all_affs[-1][tar],
+                               all_affs[-1][top], all_affs[-1][dow], out=inp.levels[tar])
+            new_maps = K.conv3x3_mlvl(inp, r['w_f'][rnd]).levels
             all_maps.append(new_maps)
-            all_affs.append(new_affs)
+            all_affs.append([K.groupnorm_affine(m, g, bt, groups, eps) for m in new_maps])
         return all_maps[-1], all_affs[-1], dict(xs=xs, maps=all_maps, affs=all_affs, B=B)
 
     def backward(self, ctx, d_y, on_grad=None):

@@ -48,6 +48,16 @@ int g4r_conv3x3_nhwc_bf16(const void* X, const void* W, void* Y, const float* bi
                           void* stream);
 
 /*
+ * The 3x3 / pad 1 convolutions of one MLVLFuseModule round over ALL pyramid levels in one implicit GEMM
+ * (gpt4roi/models/layers.py:218-236 runs the same ConvModule on every level): X and Y hold the levels' NHWC maps stacked
+ * [level][batch][y][x][C] (level l has level_h[l] x level_w[l] pixels), W as for g4r_conv3x3_nhwc_bf16 (groups = 1),
+ * bias nullable.  Same arithmetic per output pixel as one g4r_conv3x3_nhwc_bf16 call per level.
+ */
+int g4r_conv3x3_mlvl_nhwc_bf16(const void* X, const void* W, void* Y, const float* bias, const void* zeros, int n_levels,
+                               const int* level_h, const int* level_w, int batch, int Cin, int Cout, int act,
+                               void* stream);
+
+/*
  * softmax(Q K^T * scale [+ causal mask]) V, bf16, head_dim 64 (CLIP ViT-L/14) or 128 (LLaMA-7B).
  * Replaces the attention inside HF CLIPAttention / LlamaAttention (called from
  * spi_llava.py:66-67, 198-205) and the flash-attn patch

@@ -633,3 +633,28 @@ def test_greedy_advance_is_argmax_with_lowest_index_ties(N):
         want = int(row.argmax())
         assert int(tok) == want and out.tolist() == [-1, -1, want, -1, -1, -1, -1, -1]
         assert int(step) == 3 and int(pos) == 41
+
+
+@pytest.mark.parametrize("B,C,sizes", [(2, 128, [(20, 20), (10, 10), (5, 5), (3, 2)]), (1, 64, [(17, 9)]),
+                                       (1, 1024, [(192, 192), (96, 96), (48, 48), (24, 24)]), (3, 64, [(8, 8), (4, 4)])])
+def test_conv3x3_over_all_pyramid_levels_in_one_launch(B, C, sizes):
+    """g4r_conv3x3_mlvl_nhwc_bf16: the levels' maps stacked in one buffer, one implicit GEMM; rows of a 256-row tile may
+    belong to different levels (and images).  Bit-identical to one g4r_conv3x3_nhwc_bf16 launch per level on the same
+    tile, and within bf16 tolerance of F.conv2d."""
+    w4 = rnd(C, C, 3, 3, scale=(9 * C) ** -0.5, seed=31)
+    w = K.prep_conv3x3_weight(w4)
+    x = K.MlvlMaps(B, sizes, C, DEV)
+    x.flat.copy_(rnd(x.flat.size(0), C, seed=32))
+    y = K.conv3x3_mlvl(x, w)
+    assert [tuple(m.shape) for m in y.levels] == [(B, h, ww, C) for h, ww in sizes]
+    for xl, yl in zip(x.levels, y.levels):
+        one = K.conv3x3(xl, w, tile_cfg=24, splits=1)
+        assert torch.equal(yl, one)
+        if C <= 128:
+            ref = F.conv2d(xl.float().permute(0, 3, 1, 2), w4.float(), padding=1).permute(0, 2, 3, 1)
+            close(yl, ref, 2e-2, 2 ** -6, "conv3x3_mlvl")
+    # with bias + ReLU
+    bias = rnd(C, seed=33, dtype=torch.float32)
+    y2 = K.conv3x3_mlvl(x, w, bias=bias, act="relu")
+    for xl, yl in zip(x.levels, y2.levels):
+        assert torch.equal(yl, K.conv3x3(xl, w, bias=bias, act="relu", tile_cfg=24, splits=1))
