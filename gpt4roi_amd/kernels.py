@@ -201,7 +201,12 @@ def pick_conv_tile(M, Cout, K):
     address work; the 256x128 two-stage kernel serves the K = 4*9*C pconv, and small maps want 64x128 tiles +
     split-K to cover the 256 CUs.  Returns (tile_cfg, splits)."""
     if K >= 18432:
-        return 1, 1
+        # the K = 4*9*C pconv (6272 x 1024 x 36864 for 32 RoIs: 100 tiles of 256 x 256): K-slices on the ring ping-pong
+        # kernel so that tiles x slices stays within one wave of the 256 CUs.  (The one-wave-per-SIMD kernel wins the dense
+        # proxy of this shape, 452 vs 492 us, but loses the real implicit conv -- 841 us: a lone wave per SIMD has nobody to
+        # hide the per-piece halo / bounds arithmetic behind.)
+        t256 = -(-M // 256) * -(-Cout // 256)
+        return 24, max(1, min(5, 256 // t256))
     if M >= 8192:
         return 24, 1
     blocks = -(-M // 64) * -(-Cout // 128)
@@ -952,14 +957,15 @@ def groupnorm_stats(z, groups, eps=1e-5):
     return stats
 
 
-def gn_relu_bwd(z, dy, affine, gamma, stats, dgamma, dbeta, groups):
+def gn_relu_bwd(z, dy, affine, gamma, stats, dgamma, dbeta, groups, out=None):
     """y = relu(GN(z)): dy fp32 [B,H,W,C] -> dz bf16; dgamma / dbeta (fp32 [C]) accumulated."""
     _bf16(z)
     _f32(dy, affine, gamma, stats, dgamma, dbeta)
     B, H, W, C = z.shape
     assert dy.shape == z.shape and dy.is_contiguous() and z.is_contiguous()
     gsum = torch.empty((B, groups, 2), dtype=torch.float32, device=z.device)
-    dz = torch.empty_like(z)
+    dz = torch.empty_like(z) if out is None else out
+    assert dz.shape == z.shape and dz.is_contiguous() and dz.dtype == torch.bfloat16
     _launch("g4r_gn_relu_bwd_nhwc_bf16", (_p(z), _p(dy), _p(affine), _p(gamma), _p(stats), _p(dgamma), _p(dbeta),
                                           _p(gsum), _p(dz), B, H * W, C, groups, _stream(z),),
             tag="g4r_gn_relu_bwd_nhwc_bf16", nbytes=float(z.numel() * (2 * 2 + 2 * 4 + 2)))

@@ -179,14 +179,15 @@ class MLVLFuseModule(nn.Module):
             dgamma = torch.zeros(C, dtype=torch.float32, device=dev)
             dbeta = torch.zeros(C, dtype=torch.float32, device=dev)
             wt = K.conv3x3_dgrad_weight(self.fuse_convs[rnd].conv.weight.detach())
-            dW, dinps = None, []
+            dW = None
+            dzs = K.MlvlMaps(B, [(m.size(1), m.size(2)) for m in z_r], C, dev)
             for tar, top, dow in self.fuse_lvl_list:
                 stats = K.groupnorm_stats(z_r[tar], groups, eps)
-                dz = K.gn_relu_bwd(z_r[tar], d_y[tar], aff_r[tar], g, stats, dgamma, dbeta, groups)
+                dz = K.gn_relu_bwd(z_r[tar], d_y[tar], aff_r[tar], g, stats, dgamma, dbeta, groups, out=dzs.levels[tar])
                 inp = K.fuse_shuffle(prev[tar], prev[top], prev[dow], paff[tar], paff[top], paff[dow])
                 w = self._wgrad_plans[tar].wgrad(inp, dz)
                 dW = w if dW is None else dW + w
-                dinps.append(K.conv3x3(dz, wt))
+            dinps = K.conv3x3_mlvl(dzs, wt).levels          # the input gradients of every level: one implicit GEMM
             grads[f'fuse_convs.{rnd}.conv.weight'] = dW
             grads[f'fuse_convs.{rnd}.gn.weight'] = dgamma
             grads[f'fuse_convs.{rnd}.gn.bias'] = dbeta
