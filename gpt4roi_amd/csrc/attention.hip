@@ -473,7 +473,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeAttnArgs p) {
 
 }  // namespace
 
+static int g_attn_variant = 0;   // tools only: 1 = force the 4-wave head_dim-128 kernel, 2 = force the 2-wave one
+
 extern "C" {
+
+void g4r_attn_debug_variant(int v) { g_attn_variant = v; }
 
 // Q [B][Tq][H*D-strided rows], K/V [B][Tk][...], O [B][Tq][...]; all bf16; row/batch strides in
 // elements (multiples of 8).  head_dim 64 or 128.  causal: query i attends keys <= i + (Tk - Tq).
@@ -497,9 +501,18 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
     dim3 grid(g4r_ceil_div(Tq, 64), H, B);
     hipLaunchKernelGGL((flash_attn_fwd_kernel<64, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
   } else {
-    // head_dim 128: 4 waves share the staging registers of a tile (2 waves would spill)
-    dim3 grid(g4r_ceil_div(Tq, 128), H, B);
-    hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    // head_dim 128: 4 waves (128 query rows) share the staging registers of a tile.  The 2-wave form (64 rows: twice the
+    // workgroups -- LLaMA prefill at T = 767 has only 6 x 32 = 192 of them for 256 CUs) spills 72 B per lane and pays the
+    // K/V staging twice per query row: 66.0 vs 38.6 us at T = 767, 175 vs 104 at T = 2048 (tools/attn_probe.py), so it
+    // is a probe variant only.
+    const bool two = g_attn_variant == 2;
+    if (two) {
+      dim3 grid(g4r_ceil_div(Tq, 64), H, B);
+      hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
+    } else {
+      dim3 grid(g4r_ceil_div(Tq, 128), H, B);
+      hipLaunchKernelGGL((flash_attn_fwd_kernel<128, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
   }
   G4R_CHECK_LAUNCH("flash_attn_fwd");
   return G4R_OK;
