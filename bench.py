@@ -335,7 +335,7 @@ def main():
         except Exception:
             pass
         PMC_NAME = {"gemm_bf16_nt<256x256pp32>": "void gemm_bf16_pp32_kernel<0, false, 256, 256>",
-                    "conv3x3_igemm<256x256pp32>": "void gemm_bf16_pp32_kernel<1, false, 256, 256>",
+                    "conv3x3_igemm<256x256pp32>": "void gemm_bf16_pp32_kernel<2, false, 256, 256>",   # the one-launch-per-round form
                     "gemm_bf16_nt<128x128w8s4>": "void gemm_bf16_nt_kernel<128, 128, 2, 4, 0, true, 4, 64, 0>",
                     "roi_align_mlvl_nhwc": "void roi_align_mlvl_nhwc_kernel<unsigned short, true>"}
         rec = pmc.get(PMC_NAME.get(dom, ""), {})
