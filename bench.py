@@ -52,6 +52,7 @@ def parse():
                     help="extra (not part of `value`): timed stage-1 training steps (SURVEY.md 8d config 3: batch 8 per GPU, "
                          "region module + projector trainable, gradient exchange over RCCL when N > 1); 0 = skip")
     ap.add_argument("--train-batch", type=int, default=8)
+    ap.add_argument("--decode-batch", type=int, default=8, help="extra: batched greedy decode of this many sequences (<= 1 skips it)")
     ap.add_argument("--decode-tokens", type=int, default=32,
                     help="extra (not part of `value`): greedy KV-cache decode steps timed after the prefill")
     return ap.parse_args()
@@ -391,6 +392,27 @@ def main():
                                "what": "whole decode step (161 launches: 4 GEMVs + 1 attention per layer, lm_head, token selection); "
                                        "bytes = every bf16 weight once + the K/V rows attended"},
                   "note": "batch 1, KV cache, one hipGraph replay per token (token id and position stay on the device)"}
+
+    if decode is not None and args.decode_batch > 1:
+        # the same step for B equal-length sequences sharing one weight stream (SURVEY.md 8d config 5 decodes batches)
+        try:
+            Bd, nd = args.decode_batch, args.decode_tokens
+            embB = emb.expand(Bd, -1, -1).contiguous()
+            model.llama.decode_graph_batch(embB, nd + 2)                      # warm-up + graph capture
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.llama.decode_graph_batch(embB, nd + 2)
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            model.llama.decode_graph_batch(embB, 2)
+            torch.cuda.synchronize()
+            dtb = (t_all - (time.perf_counter() - t0)) / nd
+            decode["batched"] = {"batch": Bd, "ms_per_step": round(1e3 * dtb, 3), "tokens_per_s": round(Bd / dtb, 1),
+                                 "note": "B equal-length sequences, one hipGraph replay per step for the whole batch"}
+            del embB
+        except Exception as ex:
+            decode["batched"] = {"error": repr(ex)}
 
     vit = None
     if rank == 0 and not args.no_roofline:

@@ -277,7 +277,8 @@ struct DecodeAttnArgs {
   int Tk, S, H;
   float scale;
   const int* kv_len_dev;
-  int defer;           // 1: leave the S partials in ws for the consumer (g4r_gemv_attn_merge_bf16); O and cnt unused
+  int defer;
+  long q_batch, k_batch, v_batch, o_batch;   // elements between the sequences of a batch (blockIdx.z); all share Tk           // 1: leave the S partials in ws for the consumer (g4r_gemv_attn_merge_bf16); O and cnt unused
 };
 
 __device__ __forceinline__ void unpack8(const uint4v& r, float* f) {
@@ -298,6 +299,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeAttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPK, ks = lane / LPK;
   const int s = blockIdx.x, h = blockIdx.y, S = p.S;
+  {
+    const size_t bz = blockIdx.z;              // sequence of the batch: its own q / qkv row, cache slot, output row, partials
+    if (p.Q) p.Q += bz * p.q_batch;
+    if (p.qkv) p.qkv += bz * p.q_batch;
+    p.K += bz * p.k_batch;
+    p.V += bz * p.v_batch;
+    if (p.O) p.O += bz * p.o_batch;
+    if (p.ws) p.ws += bz * (size_t)p.H * S * (D + 2);
+    if (p.cnt) p.cnt += bz * p.H;
+  }
   const int Tk = p.kv_len_dev ? *p.kv_len_dev + 1 : p.Tk;
   int chunk = (Tk + S - 1) / S;
   chunk = (chunk + NST - 1) / NST * NST;
@@ -523,24 +534,29 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
 // workspace = H*splits*(D+2) floats, counters = H uint32 that are zero before the first call (every call leaves them zero).
 // With `qkv` (the raw q|k|v projection row of the new token, [3*H*D]) the call also does what g4r_rope_qkv_bf16 does for
 // that token: q and k are rotated with cos/sin row Tk-1, k and v are appended to the caches at row Tk-1 (Q is ignored).
+// batch > 1: `batch` sequences of equal length in one launch (grid z): sequence b reads Q/qkv + b*q_batch, the cache slot
+// K/V + b*k_batch / v_batch, writes O + b*o_batch; workspace / counters hold `batch` consecutive sets.
 // defer_merge: the S partials (un-normalised o, max, sum per split) stay in the workspace and the consumer assembles the
 // output (g4r_gemv_attn_merge_bf16, the o_proj of the decode step) -- no hand-off inside this launch; O/counters unused.
 // Replaces the Tq = 1 case of g4r_flash_attn_fwd_bf16 in the decode loop the reference reaches through HF generate()
 // (gpt4roi/app.py:293-300 -> transformers LlamaAttention with past_key_values).
 int g4r_attn_decode_bf16(const void* Q, const void* qkv, const float* cos_tab, const float* sin_tab, void* K, void* V,
                          void* O, float* workspace, unsigned* counters, int H, int head_dim, int Tk, long k_row,
-                         long v_row, float scale, int splits, const int* kv_len_dev, int defer_merge, void* stream) {
-  G4R_REQUIRE(H > 0 && (Tk > 0 || kv_len_dev), "attn_decode: bad shape");
+                         long v_row, float scale, int splits, const int* kv_len_dev, int defer_merge, int batch,
+                         long q_batch, long k_batch, long v_batch, long o_batch, void* stream) {
+  G4R_REQUIRE(H > 0 && (Tk > 0 || kv_len_dev) && batch >= 1 && batch <= 65535, "attn_decode: bad shape");
   G4R_REQUIRE(head_dim == 64 || head_dim == 128, "attn_decode: head_dim must be 64 or 128");
   G4R_REQUIRE((Q || qkv) && K && V && (O || defer_merge), "attn_decode: null pointer");
   G4R_REQUIRE(!defer_merge || workspace, "attn_decode: defer_merge needs the workspace");
   G4R_REQUIRE(!qkv || (cos_tab && sin_tab), "attn_decode: the fused RoPE needs the cos/sin tables");
   G4R_REQUIRE(splits >= 1 && splits <= 64, "attn_decode: splits must be in [1, 64]");
   G4R_REQUIRE(splits == 1 || defer_merge || (workspace && counters), "attn_decode: split keys need workspace and counters");
-  G4R_REQUIRE(k_row % 8 == 0 && v_row % 8 == 0, "attn_decode: strides must keep 16-byte alignment");
+  G4R_REQUIRE(k_row % 8 == 0 && v_row % 8 == 0 && q_batch % 8 == 0 && k_batch % 8 == 0 && v_batch % 8 == 0 &&
+                  o_batch % 8 == 0, "attn_decode: strides must keep 16-byte alignment");
   DecodeAttnArgs a = {(const bf16_t*)Q, (const bf16_t*)qkv, cos_tab, sin_tab, (bf16_t*)K, (bf16_t*)V, (bf16_t*)O,
-                      workspace, counters, k_row, v_row, Tk, splits, H, scale, kv_len_dev, defer_merge};
-  dim3 grid(splits, H);
+                      workspace, counters, k_row, v_row, Tk, splits, H, scale, kv_len_dev, defer_merge,
+                      q_batch, k_batch, v_batch, o_batch};
+  dim3 grid(splits, H, batch);
   if (head_dim == 64)
     hipLaunchKernelGGL((attn_decode_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else

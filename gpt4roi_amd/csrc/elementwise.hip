@@ -481,6 +481,26 @@ __global__ __launch_bounds__(1024) void greedy_advance_kernel(const float* __res
   }
 }
 
+// Batched form of the device-side greedy step: nxt [B] = the argmax of each sequence's logits row (g4r_argmax_rows_f32);
+// tok / tok32 [B] receive it (int64 for the caller, int32 for the embedding gather), out_ids [B][max_steps] its slot
+// *step; the shared counters advance once.  One block: nobody reads *step after it moved.
+__global__ __launch_bounds__(64) void batch_advance_kernel(const long* __restrict__ nxt, int B, long* __restrict__ tok,
+                                                           int* __restrict__ tok32, long* __restrict__ out_ids,
+                                                           int* __restrict__ step, int* __restrict__ pos, int max_steps) {
+  const int st = *step;
+  for (int b = threadIdx.x; b < B; b += 64) {
+    const long t = nxt[b];
+    tok[b] = t;
+    tok32[b] = (int)t;
+    if (st < max_steps) out_ids[(size_t)b * max_steps + st] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *step = st + 1;
+    *pos = *pos + 1;
+  }
+}
+
 // y[i] = a[i] + b[row(i) % brows]  (bf16; used for "+ pos_embedd" style adds), C % 8 == 0
 __global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ a,
                                                        const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
@@ -663,6 +683,16 @@ int g4r_greedy_advance_f32(const float* logits, int N, long* tok, long* out_ids,
   hipLaunchKernelGGL(greedy_advance_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, N, tok, out_ids,
                      step, pos, max_steps);
   G4R_CHECK_LAUNCH("greedy_advance");
+  return G4R_OK;
+}
+
+int g4r_batch_advance(const long* nxt, int B, long* tok, int* tok32, long* out_ids, int* step, int* pos, int max_steps,
+                      void* stream) {
+  G4R_REQUIRE(B > 0 && max_steps >= 0, "batch_advance: bad shape");
+  G4R_REQUIRE(nxt && tok && tok32 && out_ids && step && pos, "batch_advance: null pointer");
+  hipLaunchKernelGGL(batch_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, nxt, B, tok, tok32, out_ids, step,
+                     pos, max_steps);
+  G4R_CHECK_LAUNCH("batch_advance");
   return G4R_OK;
 }
 

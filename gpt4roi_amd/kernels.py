@@ -20,8 +20,10 @@ _SIGS = {
     "g4r_flash_attn_fwd_bf16": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long,
                                 c_long, c_long, c_long, c_long, c_float, c_int, P, P, P],
     "g4r_conv3x3_mlvl_nhwc_bf16": [P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P],
+    "g4r_batch_advance": [P, c_int, P, P, P, P, P, c_int, P],
     "g4r_gemv_rmsnorm_bf16": [P, P, c_float, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
-    "g4r_attn_decode_bf16": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_long, c_long, c_float, c_int, P, c_int, P],
+    "g4r_attn_decode_bf16": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_long, c_long, c_float, c_int, P, c_int,
+                             c_int, c_long, c_long, c_long, c_long, P],
     "g4r_gemv_attn_merge_bf16": [P, c_int, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "g4r_flash_attn_bwd_bf16": [P] * 10 + [c_int] * 5 + [c_long] * 16 + [c_float, c_int, P],
     "g4r_rmsnorm_bwd_bf16": [P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_long, c_long, c_float, P],
@@ -191,6 +193,11 @@ def pick_tile(M, N, K=0):
     if K % 64 == 0 and K >= 512 and M > 64:
         t64 = -(-M // 64) * -(-N // 64)
         return 14 if t64 <= 512 else 13
+    # 1 < M <= 64: the decode step of a small batch of sequences -- still weight streaming, one 64-row tile in M.  Ring-4
+    # 64x64 tiles up to N = 16 k (qkv 8x12288x4096: 25.4 us = 4.0 TB/s vs 58.2 on the two-stage 64x128), ring-3 64x128
+    # beyond (gate|up 8x22016x4096: 40.1 us = 4.5 TB/s); `gemm` adds K slices when N is small (profiles/r02_gemm_small_m.txt)
+    if K % 64 == 0 and K >= 512 and M > 1:
+        return 14 if N <= 16384 else 13
     return 4
 
 
@@ -271,6 +278,8 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
                 splits = max(1, min(4, 256 // tiles, K // 1024))
         if splits == 1 and tile_cfg == 14 and K >= 4096 and -(-M // 64) * -(-N // 64) <= 256:
             splits = 2                 # ViT fc2 577x1024x4096: 24.2 us vs 27.1 unsplit (29.4 before: 64x128 x 3 splits)
+            if M <= 64:                # batched decode: o_proj / down_proj want 4 slices (8x4096x4096: 13.4 vs 23.6 us;
+                splits = 4 if N <= 4096 else 1   # x11008: 24.9 vs 54.8), the wide projections none (measured unsplit)
     if splits > 1 and workspace is None:
         workspace = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
     _launch("g4r_gemm_bf16_nt", (
@@ -402,35 +411,43 @@ def flash_attn(q, k, v, heads, scale, causal=False, out=None, kv_len_dev=None, l
 class DecodeAttnWorkspace:
     """Partials + arrival counters of attn_decode (one per decoder: the layers run back to back on one stream)."""
 
-    def __init__(self, heads, head_dim, device, splits=8):
-        self.splits = splits
-        self.ws = torch.empty(heads * splits * (head_dim + 2), dtype=torch.float32, device=device)
-        self.cnt = torch.zeros(heads, dtype=torch.int32, device=device)      # every call leaves it zero again
+    def __init__(self, heads, head_dim, device, splits=8, batch=1):
+        self.splits, self.batch = splits, batch
+        self.ws = torch.empty(batch * heads * splits * (head_dim + 2), dtype=torch.float32, device=device)
+        self.cnt = torch.zeros(batch * heads, dtype=torch.int32, device=device)      # every call leaves it zero again
 
 
 def attn_decode(q, k, v, heads, scale, work, kv_len_dev=None, kv_len=None, out=None, qkv=None, cos=None, sin=None,
                 defer_merge=False):
-    """One query row against a KV cache: q [heads*D] (any shape with that many elements), k/v [T_max, heads*D]
-    row-strided views; attends the first *kv_len_dev + 1 (or kv_len) rows.  -> [heads*D] bf16.
-    qkv (instead of q): the raw q|k|v projection row [3*heads*D] of the new token -- RoPE (cos/sin tables) and the cache
-    append at row kv_len - 1 happen inside the launch (rope_qkv + attention in one).
-    defer_merge: returns None; the per-split partials stay in work.ws for gemv_attn_merge (the o_proj of the step)."""
+    """One query row per sequence against its KV cache.  Single sequence: q [heads*D] (any shape with that many elements),
+    k/v [T_max, heads*D] row-strided views.  Batch of B equal-length sequences: q [B, heads*D] (or qkv [B, 3*heads*D]),
+    k/v [B, T_max, heads*D] views -> out [B, heads*D].  Attends the first *kv_len_dev + 1 (or kv_len) rows.
+    qkv (instead of q): the raw q|k|v projection rows of the new tokens -- RoPE (cos/sin tables) and the cache append at row
+    kv_len - 1 happen inside the launch (rope_qkv + attention in one).
+    defer_merge (single sequence): returns None; the per-split partials stay in work.ws for gemv_attn_merge (the o_proj)."""
     _bf16(q, k, v, qkv)
-    HD = k.size(1)
+    batched = k.dim() == 3
+    B = k.size(0) if batched else 1
+    HD = k.size(-1)
     D = HD // heads
-    assert k.dim() == 2 and k.stride(1) == 1 and v.stride(1) == 1
-    assert (q is None) != (qkv is None)
-    if q is not None:
-        assert q.numel() == HD and q.is_contiguous()
-    else:
+    assert k.stride(-1) == 1 and v.stride(-1) == 1 and v.dim() == k.dim()
+    assert (q is None) != (qkv is None) and work.batch >= B
+    src = q if q is not None else qkv
+    assert src.numel() == B * (HD if q is not None else 3 * HD) and src.is_contiguous()
+    if qkv is not None:
         _f32(cos, sin)
-        assert qkv.numel() == 3 * HD and qkv.is_contiguous() and cos.size(1) == D // 2 and cos.is_contiguous()
+        assert cos.size(1) == D // 2 and cos.is_contiguous()
     assert kv_len_dev is not None or kv_len is not None
+    assert not (defer_merge and batched)
     if out is None and not defer_merge:
-        out = torch.empty(HD, dtype=torch.bfloat16, device=k.device)
+        out = torch.empty((B, HD) if batched else HD, dtype=torch.bfloat16, device=k.device)
+    if out is not None:
+        assert out.numel() == B * HD and out.is_contiguous()
     _launch("g4r_attn_decode_bf16", (_p(q), _p(qkv), _p(cos), _p(sin), _p(k), _p(v), _p(out), _p(work.ws), _p(work.cnt),
-                                     heads, D, int(kv_len or 0), k.stride(0), v.stride(0), float(scale), work.splits,
-                                     _p(kv_len_dev), int(bool(defer_merge)), _stream(k),), tag=f"attn_decode<{D}>")
+                                     heads, D, int(kv_len or 0), k.stride(-2), v.stride(-2), float(scale), work.splits,
+                                     _p(kv_len_dev), int(bool(defer_merge)), B, src.numel() // B,
+                                     k.stride(0) if batched else 0, v.stride(0) if batched else 0, HD, _stream(k),),
+            tag=f"attn_decode<{D}>")
     return out
 
 
@@ -584,6 +601,15 @@ def greedy_advance(logits_row, tok, out_ids, step, pos):
     assert tok.dtype == torch.int64 and out_ids.dtype == torch.int64 and step.dtype == torch.int32 and pos.dtype == torch.int32
     _launch("g4r_greedy_advance_f32", (_p(logits_row), logits_row.numel(), _p(tok), _p(out_ids), _p(step), _p(pos),
                                        out_ids.numel(), _stream(logits_row),))
+
+
+def batch_advance(nxt, tok, tok32, out_ids, step, pos):
+    """tok[b] = tok32[b] = nxt[b]; out_ids[b, step[0]] = nxt[b]; step += 1; pos += 1 -- the batched greedy step."""
+    B = nxt.numel()
+    assert nxt.dtype == torch.int64 and tok.dtype == torch.int64 and tok32.dtype == torch.int32 and out_ids.dtype == torch.int64
+    assert tok.numel() == B and tok32.numel() == B and out_ids.dim() == 2 and out_ids.size(0) == B and out_ids.is_contiguous()
+    _launch("g4r_batch_advance", (_p(nxt), B, _p(tok), _p(tok32), _p(out_ids), _p(step), _p(pos), out_ids.size(1),
+                                  _stream(nxt),))
 
 
 def sample_advance(logits_row, tok, out_ids, step, pos, seed, temperature=1.0, top_k=50, top_p=1.0, u_out=None):

@@ -58,6 +58,7 @@ class LlamaDecoder:
         self.vc = torch.zeros_like(self.kc)
         self.pos = 0
         self._dstate = None            # a captured decode graph points into the old cache
+        self._bstate = None
 
     def reset(self, batch=1):
         if self.kc.size(1) < batch:
@@ -80,11 +81,10 @@ class LlamaDecoder:
         for li, L in enumerate(self.layers):
             h = K.rmsnorm(x, L['n1'], self.eps)
             qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
-            if T == 1:                                       # decode step: RoPE + cache append + split-key attention
-                a = torch.empty_like(q)
-                for b in range(B):
-                    K.attn_decode(None, self.kc[li, b], self.vc[li, b], H, scale, self._attn_work(), kv_len=pos0 + 1,
-                                  out=a[b].view(-1), qkv=qkv[b].view(-1), cos=self.cos, sin=self.sin)
+            if T == 1:                                       # decode step: RoPE + cache append + split-key attention,
+                a = torch.empty_like(q)                      # one launch for the B sequences of the batch
+                K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, self._attn_work(B), kv_len=pos0 + 1,
+                              out=a.view(B, C), qkv=qkv.view(B, 3 * C), cos=self.cos, sin=self.sin)
             else:
                 for b in range(B):
                     K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, pos0)
@@ -288,12 +288,16 @@ class LlamaDecoder:
                     u=torch.zeros(n, dtype=torch.float32, device=dev),
                     out=torch.zeros(n, dtype=torch.int64, device=dev), graphs={})
 
-    def _attn_work(self):
-        w = getattr(self, "_attn_ws", None)
-        if w is None:
+    def _attn_work(self, batch=1):
+        """Decode-attention workspace for `batch` sequences; one per batch size, never freed (captured decode graphs hold
+        its addresses)."""
+        pool = getattr(self, "_attn_ws", None)
+        if pool is None:
+            pool = self._attn_ws = {}
+        if batch not in pool:
             with torch.inference_mode(False):
-                w = self._attn_ws = K.DecodeAttnWorkspace(self.heads, self.head_dim, self.device, splits=8)
-        return w
+                pool[batch] = K.DecodeAttnWorkspace(self.heads, self.head_dim, self.device, splits=8, batch=batch)
+        return pool[batch]
 
     def _advance(self, logits_row, st, sampler):
         """Token selection on the device: argmax (generate(do_sample=False)) or one temperature / top-k / top-p draw
@@ -391,6 +395,75 @@ class LlamaDecoder:
     def greedy_graph(self, inputs_embeds, max_new_tokens, stop_ids=(), check_every=32, use_graph=True):
         """generate(do_sample=False): decode_graph without a sampler."""
         return self.decode_graph(inputs_embeds, max_new_tokens, stop_ids, check_every, use_graph)
+
+    def _decode_step_batch(self, st):
+        """One token for each of B equal-length sequences: the weight stream of the step is shared by the batch (small-M
+        GEMM tiles, profiles/r02_gemm_small_m.txt), RoPE + cache append + attention of all sequences in one launch."""
+        B, C, H, D = st["tok32"].numel(), self.hidden, self.heads, self.head_dim
+        scale = 1.0 / math.sqrt(D)
+        work = self._attn_work(B)
+        x = K.gather_rows(self.embed, st["tok32"])
+        for li, L in enumerate(self.layers):
+            h = K.rmsnorm(x, L['n1'], self.eps)
+            qkv = K.gemm(h, L['wqkv'])
+            a = K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, work, kv_len_dev=st["pos"], qkv=qkv,
+                              cos=self.cos, sin=self.sin)
+            x = K.gemm(a, L['wo'], residual=x)
+            h = K.rmsnorm(x, L['n2'], self.eps)
+            f = K.gemm(h, L['wgu'], act="swiglu")
+            x = K.gemm(f, L['wd'], residual=x)
+        logits = K.gemm(K.rmsnorm(x, self.norm, self.eps), self.lm_head, out_dtype=torch.float32)
+        K.batch_advance(K.argmax_rows(logits), st["tok"], st["tok32"], st["out"], st["step"], st["pos"])
+
+    @torch.no_grad()
+    def decode_graph_batch(self, inputs_embeds, max_new_tokens, stop_ids=(), use_graph=True):
+        """generate(do_sample=False) for B sequences with prompts of EQUAL length, per-token loop on the device: prefill
+        eagerly, then one captured hipGraph replay per step for the whole batch (token ids, position and output slots stay
+        in device memory).  The 13.2 GB weight stream of a step is shared by the B sequences -- the throughput mode of
+        SURVEY.md 8d config 5.  Sequences that hit a stop id keep running; their later tokens are cut from the result.
+        Returns a list of B id lists (same ids as greedy_batch, the host-loop form)."""
+        B = inputs_embeds.size(0)
+        self.reset(B)
+        logits = self.forward(inputs_embeds, all_logits=False)
+        T = self.pos
+        assert T + max_new_tokens <= self.max_positions
+        dev = inputs_embeds.device
+        bs = getattr(self, "_bstate", None)
+        if bs is None or bs["B"] != B or bs["out"].size(1) < max_new_tokens:
+            cap = max(64, 1 << (max_new_tokens - 1).bit_length())      # output slots: the captured graph knows this stride
+            with torch.inference_mode(False):
+                bs = self._bstate = dict(B=B, tok=torch.zeros(B, dtype=torch.int64, device=dev),
+                                         tok32=torch.zeros(B, dtype=torch.int32, device=dev),
+                                         out=torch.zeros((B, cap), dtype=torch.int64, device=dev),
+                                         pos=torch.zeros(1, dtype=torch.int32, device=dev),
+                                         step=torch.zeros(1, dtype=torch.int32, device=dev), graph=None)
+        st = bs
+        st["pos"].fill_(T - 1)
+        st["step"].zero_()
+        K.batch_advance(K.argmax_rows(logits.view(B, -1)), st["tok"], st["tok32"], st["out"], st["step"], st["pos"])
+        done = 1
+        if max_new_tokens > 1:
+            self._decode_step_batch(st)                                  # token 2 (also warms up)
+            done = 2
+        if use_graph and st["graph"] is None and max_new_tokens > 2:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.inference_mode(False), torch.no_grad():
+                with torch.cuda.graph(g):                                # (recorded, not executed: the state does not move)
+                    self._decode_step_batch(st)
+            st["graph"] = g
+        while done < max_new_tokens:
+            if st["graph"] is not None:
+                st["graph"].replay()
+            else:
+                self._decode_step_batch(st)
+            done += 1
+        self.pos = T + max_new_tokens - 1
+        res = []
+        for row in st["out"][:, :max_new_tokens].tolist():
+            hit = [i for i, t in enumerate(row) if t in stop_ids]
+            res.append(row[:hit[0] + 1] if hit else row)
+        return res
 
     @torch.no_grad()
     def greedy_batch(self, inputs_embeds, max_new_tokens, stop_ids=()):

@@ -224,6 +224,7 @@ class SPILlavaLlamaModel(nn.Module):
         other.llama._alloc_cache(self.llama.kc.size(1))
         other.llama._attn_ws = None                  # per-context decode workspaces (the contexts run on different streams)
         other.llama._dstate = None
+        other.llama._bstate = None
         other.last_status = None
         return other
 
@@ -385,6 +386,7 @@ class SPILlavaMPTForCausalLM(nn.Module):
         if hasattr(dec, "lm_head_t"):
             dec.prepare_training(train_weights=getattr(dec, "train_weights", False))
         dec._dstate = None
+        dec._bstate = None
         self.config.vocab_size = new_num_tokens
         return self.get_input_embeddings()
 

@@ -98,10 +98,14 @@ int g4r_gemv_rmsnorm_bf16(const void* x, const float* gamma, float eps, const vo
  * ([maxT, head_dim/2] fp32), the rotated k and v are written to row Tk-1 of the caches (LlamaAttention's
  * apply_rotary_pos_emb + cache append).
  * defer_merge: leave the per-split partials in `workspace` for g4r_gemv_attn_merge_bf16 (O and counters unused).
+ * batch: number of equal-length sequences served by the launch (decode of B requests sharing one weight stream, SURVEY.md
+ * 8d config 5); sequence b uses Q/qkv + b*q_batch, K + b*k_batch, V + b*v_batch, O + b*o_batch (elements) and the b-th set
+ * of workspace (H*splits*(head_dim+2) floats) and counters (H).
  */
 int g4r_attn_decode_bf16(const void* Q, const void* qkv, const float* cos_tab, const float* sin_tab, void* K, void* V,
                          void* O, float* workspace, unsigned* counters, int H, int head_dim, int Tk, long k_row,
-                         long v_row, float scale, int splits, const int* kv_len_dev, int defer_merge, void* stream);
+                         long v_row, float scale, int splits, const int* kv_len_dev, int defer_merge, int batch,
+                         long q_batch, long k_batch, long v_batch, long o_batch, void* stream);
 
 /*
  * o_proj of the decode step with the merge of the attention partials fused into its input staging:
@@ -185,6 +189,11 @@ int g4r_splice_embed_bf16(const long* ids, const void* embed, const void* img, c
  * with sampling off -- can be replayed from a hipGraph). */
 int g4r_greedy_advance_f32(const float* logits, int N, long* tok, long* out_ids, int* step, int* pos,
                            int max_steps, void* stream);
+
+/* Batched greedy step (B equal-length sequences decoded together): tok[b] = tok32[b] = nxt[b] (the per-row argmax from
+ * g4r_argmax_rows_f32), out_ids[b][*step] = nxt[b] (row stride max_steps), then ++*step, ++*pos -- all on the device. */
+int g4r_batch_advance(const long* nxt, int B, long* tok, int* tok32, long* out_ids, int* step, int* pos, int max_steps,
+                      void* stream);
 /* greedy decode: out[r] = argmax(logits[r, :N]) (lowest index on ties). */
 int g4r_argmax_rows_f32(const float* logits, long ld, int rows, int N, long* out, void* stream);
 /* y = a + b[row % brows]  ("fuse_roi_feats + pos_embedd", layers.py:328). */

@@ -658,3 +658,25 @@ def test_conv3x3_over_all_pyramid_levels_in_one_launch(B, C, sizes):
     y2 = K.conv3x3_mlvl(x, w, bias=bias, act="relu")
     for xl, yl in zip(x.levels, y2.levels):
         assert torch.equal(yl, K.conv3x3(xl, w, bias=bias, act="relu", tile_cfg=24, splits=1))
+
+
+@pytest.mark.parametrize("B,H,D,kv", [(3, 32, 128, 300), (8, 32, 128, 21), (2, 16, 64, 577)])
+def test_attn_decode_batch_of_sequences_in_one_launch(B, H, D, kv):
+    """batch > 1: grid z = the sequence; each has its own qkv row, cache slot, output row, partials and counters.
+    Bit-identical to one launch per sequence; the appended cache rows too."""
+    T_max, C = 1024, H * D
+    qkv = rnd(B, 3 * C, seed=41)
+    kbig, vbig = rnd(B, 2, T_max, C, seed=42), rnd(B, 2, T_max, C, seed=43)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(T_max).float()[:, None] * inv[None]
+    cos, sin = ang.cos().contiguous().to(DEV), ang.sin().contiguous().to(DEV)
+    scale = D ** -0.5
+    k1, v1, k2, v2 = (t.clone()[:, 1] for t in (kbig, vbig, kbig, vbig))          # batch stride 2 * T_max * C
+    w1 = K.DecodeAttnWorkspace(H, D, DEV, splits=8)
+    want = torch.stack([K.attn_decode(None, k1[b], v1[b], H, scale, w1, kv_len=kv, qkv=qkv[b], cos=cos, sin=sin)
+                        for b in range(B)])
+    wB = K.DecodeAttnWorkspace(H, D, DEV, splits=8, batch=B)
+    pos = torch.tensor([kv - 1], dtype=torch.int32, device=DEV)
+    got = K.attn_decode(None, k2, v2, H, scale, wB, kv_len_dev=pos, qkv=qkv, cos=cos, sin=sin)
+    assert got.shape == (B, C) and torch.equal(got, want)
+    assert torch.equal(k2, k1) and torch.equal(v2, v1) and int(wB.cnt.abs().sum()) == 0

@@ -394,3 +394,30 @@ def test_malformed_prompt_raises_like_the_reference():
     model.embed_inputs(prompt.to(DEV), img, None)
     with pytest.raises(ValueError):
         model.check_status()
+
+
+def test_batched_device_resident_decode_matches_host_loop():
+    """decode_graph_batch (one hipGraph replay per step for B sequences, ids / position on the device, one attention
+    launch for the batch with RoPE + cache append fused) emits exactly the ids of greedy_batch, the host-loop form over
+    the same kernels; a second call reuses the captured graph; stop ids cut the rows."""
+    sd, dec = _mini_llama(layers=2)
+    B, T0, n_new = 3, 19, 9
+    g = torch.Generator().manual_seed(71)
+    emb_w = bf(sd["model.embed_tokens.weight"])
+    prompts = emb_w[torch.randint(0, 1000, (B, T0), generator=g)].to(DEV).to(torch.bfloat16)
+    want = dec.greedy_batch(prompts, n_new)
+    got = dec.decode_graph_batch(prompts, n_new)
+    assert got == want
+    assert dec._bstate["graph"] is not None
+    again = dec.decode_graph_batch(prompts, n_new)
+    assert again == want
+    short = dec.decode_graph_batch(prompts, 4)
+    assert short == [r[:4] for r in want]
+    eager = dec.decode_graph_batch(prompts, n_new, use_graph=False)
+    assert eager == want
+    stop = want[2][3]
+    cut = dec.decode_graph_batch(prompts, n_new, stop_ids=(stop,))
+    assert cut[2] == want[2][:want[2].index(stop) + 1]
+    # the single-sequence device loop is not disturbed by the batch state (separate workspaces / graphs)
+    one = dec.decode_graph(prompts[1:2], n_new)
+    assert one == dec.greedy(prompts[1:2], n_new)

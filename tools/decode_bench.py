@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--prompt", type=int, default=767)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--sample", action="store_true")
+    ap.add_argument("--batch", type=int, default=1, help="B equal-length sequences decoded together (greedy)")
     a = ap.parse_args()
     from gpt4roi_amd import synthetic as syn
     from gpt4roi_amd.llama import LlamaDecoder
@@ -27,21 +28,27 @@ def main():
     lsd = syn.llama_state(l["hidden"], l["inter"], a.layers, 32006, seed=1, device=dev, dtype=torch.bfloat16)
     dec = LlamaDecoder(lsd, heads=l["heads"], max_positions=2048, device=dev)
     del lsd
-    emb = (torch.randn(1, a.prompt, l["hidden"], device=dev) * 0.02).to(torch.bfloat16)
+    emb = (torch.randn(a.batch, a.prompt, l["hidden"], device=dev) * 0.02).to(torch.bfloat16)
     sampler = (0.2, 50, 1.0) if a.sample else None
-    dec.decode_graph(emb, 8, sampler=sampler, seed=1)
+
+    def run(n):
+        if a.batch > 1:
+            return dec.decode_graph_batch(emb, n)
+        return dec.decode_graph(emb, n, sampler=sampler, seed=1)
+    run(a.tokens + 2)                                  # warm-up + graph capture (the batched graph is keyed by length)
     torch.cuda.synchronize()
 
     def timed(n):
         t0 = time.perf_counter()
-        dec.decode_graph(emb, n, sampler=sampler, seed=1)
+        run(n)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
     timed(4)
     t_long, t_short = min(timed(a.tokens + 2) for _ in range(3)), min(timed(2) for _ in range(3))
     dt = (t_long - t_short) / a.tokens
     wbytes = sum(L[k].numel() * 2 for L in dec.layers for k in ("wqkv", "wo", "wgu", "wd")) + dec.lm_head.numel() * 2
-    print({"ms_per_token": round(1e3 * dt, 3), "tokens_per_s": round(1 / dt, 1), "weight_GB": round(wbytes / 1e9, 2),
+    print({"batch": a.batch, "ms_per_step": round(1e3 * dt, 3), "tokens_per_s_all_sequences": round(a.batch / dt, 1),
+           "ms_per_token": round(1e3 * dt, 3), "tokens_per_s": round(1 / dt, 1), "weight_GB": round(wbytes / 1e9, 2),
            "weight_stream_GBps": round(wbytes / dt / 1e9, 1), "layers": a.layers, "prompt": a.prompt, "sampled": a.sample})
 
 
