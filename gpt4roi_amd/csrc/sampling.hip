@@ -33,27 +33,38 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 constexpr int LIST_CAP = 1024;
 
-// One workgroup of 256 threads.  top_k in [1, LIST_CAP]: list path (kept tokens gathered into LDS, everything else by
+// One workgroup of 1024 threads.  top_k in [1, LIST_CAP]: list path (kept tokens gathered into LDS, everything else by
 // thread 0 on <= ~top_k entries).  top_k == 0: every token kept, chunked inverse CDF (top_p must be 1).
-__global__ __launch_bounds__(256) void sample_advance_kernel(const float* __restrict__ logits, int N, float inv_temp,
+// The logits row is staged ONCE in LDS (`in_lds`: N * 4 B of dynamic LDS, 128 KB for the 32 006-token vocabulary) and the
+// six passes over it (max, four radix-select passes, gather) read it from there; the first version walked the row in
+// global memory with 256 threads, ~140 us per token.
+constexpr int SNT = 1024;
+__global__ __launch_bounds__(SNT) void sample_advance_kernel(const float* __restrict__ glogits, int N, int in_lds, float inv_temp,
                                                              int top_k, float top_p,
                                                              const unsigned long long* __restrict__ seed,
                                                              long* __restrict__ tok, long* __restrict__ out_ids,
                                                              int* __restrict__ step, int* __restrict__ pos,
                                                              int max_steps, float* __restrict__ u_out) {
-  __shared__ float red[256];
+  extern __shared__ __attribute__((aligned(16))) float staged[];
+  __shared__ float red[SNT];
   __shared__ unsigned hist[256];
   __shared__ unsigned sel_prefix, sel_mask, sel_k, list_n;
   __shared__ int list_idx[LIST_CAP];
   __shared__ float list_e[LIST_CAP];
   __shared__ double chunk_sum[256];
   const int tid = threadIdx.x;
+  const float* logits = glogits;
+  if (in_lds) {
+    for (int i = tid; i < N; i += SNT) staged[i] = glogits[i];
+    __syncthreads();
+    logits = staged;
+  }
   // ---- max logit ----
   float m = -INFINITY;
-  for (int i = tid; i < N; i += 256) m = fmaxf(m, logits[i]);
+  for (int i = tid; i < N; i += SNT) m = fmaxf(m, logits[i]);
   red[tid] = m;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = SNT / 2; s > 0; s >>= 1) {
     if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
     __syncthreads();
   }
@@ -74,11 +85,11 @@ __global__ __launch_bounds__(256) void sample_advance_kernel(const float* __rest
     //      HF's TopKLogitsWarper does: scores < kth are removed) ----
     if (tid == 0) { sel_prefix = 0; sel_mask = 0; sel_k = (unsigned)k_eff; }
     for (int pass = 3; pass >= 0; --pass) {
-      hist[tid] = 0;
+      if (tid < 256) hist[tid] = 0;
       __syncthreads();
       const unsigned pre = sel_prefix, msk = sel_mask;
       const int sh = pass * 8;
-      for (int i = tid; i < N; i += 256) {
+      for (int i = tid; i < N; i += SNT) {
         const uint32_t k = order_key(logits[i]);
         if ((k & msk) == pre) atomicAdd(&hist[(k >> sh) & 255u], 1u);
       }
@@ -99,7 +110,7 @@ __global__ __launch_bounds__(256) void sample_advance_kernel(const float* __rest
     kth = sel_prefix;
     if (tid == 0) list_n = 0;
     __syncthreads();
-    for (int i = tid; i < N; i += 256) {
+    for (int i = tid; i < N; i += SNT) {
       const float l = logits[i];
       if (order_key(l) >= kth) {
         const unsigned slot = atomicAdd(&list_n, 1u);
@@ -113,17 +124,23 @@ __global__ __launch_bounds__(256) void sample_advance_kernel(const float* __rest
     // more than LIST_CAP tokens tie at the k-th logit (degenerate rows, e.g. constant logits): the kept set does not
     // fit the list -> chunked draw over the tokens with key >= kth below (top_p is not applied in that case)
     use_list = list_n <= (unsigned)LIST_CAP;
+    if (use_list) {
+      // ascending vocabulary order by rank: entry a goes to slot #{b : idx[b] < idx[a]} (the indices are distinct); one
+      // thread per entry instead of thread 0's insertion sort (~30 us at top_k = 50)
+      const int n = (int)list_n;
+      int my_i = 0, rank = 0;
+      float my_e = 0.f;
+      if (tid < n) {
+        my_i = list_idx[tid];
+        my_e = list_e[tid];
+        for (int b = 0; b < n; ++b) rank += list_idx[b] < my_i;
+      }
+      __syncthreads();
+      if (tid < n) { list_idx[rank] = my_i; list_e[rank] = my_e; }
+      __syncthreads();
+    }
     if (use_list && tid == 0) {
       int n = (int)list_n;
-      // ascending vocabulary order (insertion sort: n ~ top_k)
-      for (int a = 1; a < n; ++a) {
-        const int ii = list_idx[a];
-        const float ee = list_e[a];
-        int b = a - 1;
-        for (; b >= 0 && list_idx[b] > ii; --b) { list_idx[b + 1] = list_idx[b]; list_e[b + 1] = list_e[b]; }
-        list_idx[b + 1] = ii;
-        list_e[b + 1] = ee;
-      }
       double Z = 0.0;
       for (int a = 0; a < n; ++a) Z += (double)list_e[a];
       if (top_p < 1.0f) {
@@ -155,11 +172,13 @@ __global__ __launch_bounds__(256) void sample_advance_kernel(const float* __rest
   if (!use_list) {
     // ---- chunked inverse CDF in ascending vocabulary order over the tokens with key >= kth (kth = 0: all) ----
     const int chunk = (N + 255) / 256;
-    const int c0 = tid * chunk, c1 = min(N, c0 + chunk);
-    double s = 0.0;
-    for (int i = c0; i < c1; ++i)
-      if (order_key(logits[i]) >= kth) s += (double)expf((logits[i] - m) * inv_temp);
-    chunk_sum[tid] = s;
+    if (tid < 256) {
+      const int c0 = tid * chunk, c1 = min(N, c0 + chunk);
+      double s = 0.0;
+      for (int i = c0; i < c1; ++i)
+        if (order_key(logits[i]) >= kth) s += (double)expf((logits[i] - m) * inv_temp);
+      chunk_sum[tid] = s;
+    }
     __syncthreads();
     if (tid == 0) {
       double Z = 0.0;
@@ -205,8 +224,17 @@ extern "C" int g4r_sample_advance_f32(const float* logits, int N, float temperat
   G4R_REQUIRE(top_k >= 0 && top_k <= LIST_CAP, "sample_advance: top_k in [0, 1024] (0 = disabled)");
   if (top_p < 1.f && !(top_k >= 1 && (top_k < N || N <= LIST_CAP)))
     return g4r_note_error(G4R_ERR_UNSUPPORTED, "sample_advance: top_p < 1 needs top_k in [1, 1024] (below the vocabulary size)");
-  hipLaunchKernelGGL(sample_advance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, N, 1.0f / temperature,
-                     top_k, top_p, seed, tok, out_ids, step, pos, max_steps, u_out);
+  const int in_lds = (size_t)N * 4 <= 140 * 1024;       // + 15 KB of static LDS: within the 160 KB of a CU
+  const size_t lds = in_lds ? (size_t)N * 4 : 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_advance_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    if (e != hipSuccess) return g4r_note_hip_error(e, "sample_advance: hipFuncSetAttribute");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sample_advance_kernel, dim3(1), dim3(SNT), lds, (hipStream_t)stream, logits, N, in_lds,
+                     1.0f / temperature, top_k, top_p, seed, tok, out_ids, step, pos, max_steps, u_out);
   G4R_CHECK_LAUNCH("sample_advance");
   return G4R_OK;
 }
