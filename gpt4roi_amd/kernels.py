@@ -185,7 +185,9 @@ def pick_tile(M, N, K=0):
             return 24
     t128 = -(-M // 128) * -(-N // 128)
     if t128 >= 192:
-        return 7 if (K >= 4096 and t128 < 512) else 0     # o_proj 767x4096x4096: 47.8 us vs 63.8 (tools/proj_tiles.py)
+        # o_proj 767x4096x4096 (192 tiles): 8-wave ring 45.7 us vs 65.9 on the two-stage tile; with more than one tile per CU
+        # the two-stage tile wins again (ViT fc2 at batch 8, 4616x1024x4096 = 296 tiles: 71.2 vs 83.6 us)
+        return 7 if (K >= 4096 and t128 <= 256) else 0
     # Small M (CLIP ViT at batch 1, M = 577): fewer workgroups than CUs and only 16-64 K tiles, so ONE workgroup's
     # latency is the time -> deep LDS-DMA rings (tools/gemm_bench.cpp on MI355X, profiles/r02_gemm_tiles.md):
     # 577x3072x1024 15.1 us on 64x64 ring-4 vs 22.1 on the two-stage 64x128; 577x1024x1024 12.3 vs 20.5;

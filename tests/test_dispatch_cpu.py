@@ -1,0 +1,38 @@
+"""CPU: the tile / split dispatch of the production shapes (pure host logic in gpt4roi_amd/kernels.py).  Every decision below
+was taken from an A/B measurement on MI355X (profiles/r02_gemm_tiles.md, r02_gemm_small_m.txt, r02_conv_k_order.jsonl,
+DESIGN.md section 3); this test pins them so that a heuristic edit for one shape cannot silently move another."""
+import pytest
+
+from gpt4roi_amd import kernels as K
+
+
+@pytest.mark.parametrize("M,N,Kd,tile,main", [
+    (767, 12288, 4096, 24, None),      # LLaMA fused qkv: ring ping-pong 256x256 (144 tiles)
+    (767, 22016, 4096, 0, 21760),      # gate|up: whole-wave column split, 255 tiles on the ring kernel + 256 columns
+    (767, 32006, 4096, 0, 21760),      # lm_head
+    (767, 4096, 4096, 7, None),        # o_proj: 128x128 x 8 waves, ring of 4
+    (767, 256, 4096, 14, None),        # the gate|up remainder: 64x64 ring-4 (+ 2 K slices in gemm())
+    (577, 3072, 1024, 14, None), (577, 1024, 1024, 14, None), (577, 4096, 1024, 13, None), (577, 1024, 4096, 14, None),  # ViT, batch 1
+    (4616, 3072, 1024, 24, None), (4616, 1024, 4096, 0, None),                                                           # ViT, batch 8
+    (8, 12288, 4096, 14, None), (8, 4096, 4096, 14, None), (8, 22016, 4096, 13, None), (16, 4096, 11008, 14, None),      # batched decode
+])
+def test_gemm_tile_dispatch(M, N, Kd, tile, main):
+    assert K.pick_tile(M, N, Kd) == tile
+    assert K.wave_split(M, N, Kd) == main
+
+
+@pytest.mark.parametrize("M,Cout,Kd,want", [
+    (36864, 1024, 9216, (24, 1)),      # a 192^2 level on its own (the fuse rounds use conv3x3_mlvl: one launch for all levels)
+    (2304, 1024, 9216, (4, 1)),
+    (6272, 1024, 36864, (24, 2)),      # pconv, 32 RoIs: 100 tiles x 2 K slices on the ring kernel
+    (15288, 1024, 36864, (24, 1)),     # pconv, training batch (78 RoIs)
+])
+def test_conv_tile_dispatch(M, Cout, Kd, want):
+    assert K.pick_conv_tile(M, Cout, Kd) == want
+
+
+def test_mlvl_geometry_of_the_336_pyramid_is_three_full_waves():
+    rows = sum(h * h for h in (192, 96, 48, 24))
+    assert rows == 48960 and -(-rows // 256) * (1024 // 256) == 768 == 3 * 256
+    for start in (192 * 192, 192 * 192 + 96 * 96, 192 * 192 + 96 * 96 + 48 * 48):
+        assert start % 256 == 0                                   # level boundaries fall on tile boundaries at P = 24
