@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r2s; mkdir -p $O
+O=gpurun_out/r2w; mkdir -p $O
 timeout 2400 python -m pytest tests -q -m gpu > $O/pytest_all.log 2>&1
 echo "pytest rc $?" >> $O/pytest_all.log
 grep -E "passed|failed|rc |^FAILED|^E  " $O/pytest_all.log | tail -20 | cut -c1-220
@@ -11,7 +11,7 @@ echo "bench rc $?" >> $O/bench.err; tail -3 $O/bench.err
 python - <<'PY'
 import json
 try:
-    d = json.loads(open("gpurun_out/r2s/bench.log").read().strip().splitlines()[-1])
+    d = json.loads(open("gpurun_out/r2w/bench.log").read().strip().splitlines()[-1])
     for k in ("value", "ms_per_step", "single_stream", "roofline", "cpu_baseline", "decode", "train"):
         print(k, json.dumps(d.get(k))[:1200])
     for k, v in list(d["kernels"].items())[:14]: print(k, v)
