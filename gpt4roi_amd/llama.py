@@ -9,6 +9,7 @@ llava/model/llava.py:235-238: RMSNorm -> fused QKV GEMM -> rotary (rotate_half) 
 sized once for `max_positions` (288 GB of HBM make whole-sequence residency the default).
 """
 import math
+import os
 
 import torch
 
@@ -295,8 +296,11 @@ class LlamaDecoder:
         if pool is None:
             pool = self._attn_ws = {}
         if batch not in pool:
+            # keys of a (sequence, head) split over `splits` workgroups: 8 for one sequence (32 heads -> 256 workgroups), fewer
+            # as the batch itself fills the chip (fewer partials to merge, longer runs of keys per workgroup)
+            splits = int(os.environ.get("G4R_ATTN_SPLITS", 0)) or max(1, min(8, 512 // (self.heads * batch)))
             with torch.inference_mode(False):
-                pool[batch] = K.DecodeAttnWorkspace(self.heads, self.head_dim, self.device, splits=8, batch=batch)
+                pool[batch] = K.DecodeAttnWorkspace(self.heads, self.head_dim, self.device, splits=splits, batch=batch)
         return pool[batch]
 
     def _advance(self, logits_row, st, sampler):
