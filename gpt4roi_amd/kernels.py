@@ -280,8 +280,11 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
                 splits = max(1, min(4, 256 // tiles, K // 1024))
         if splits == 1 and tile_cfg == 14 and K >= 4096 and -(-M // 64) * -(-N // 64) <= 256:
             splits = 2                 # ViT fc2 577x1024x4096: 24.2 us vs 27.1 unsplit (29.4 before: 64x128 x 3 splits)
-            if M <= 64:                # batched decode: o_proj / down_proj want 4 slices (8x4096x4096: 13.4 vs 23.6 us;
-                splits = 4 if N <= 4096 else 1   # x11008: 24.9 vs 54.8), the wide projections none (measured unsplit)
+            if -(-M // 64) * -(-N // 64) <= 64:
+                splits = 4             # <= 64 tiles: the gate|up remainder 767x256x4096 13.8 vs 17.2 us (x2) / 23.6 (x1);
+                #                        batched decode o_proj / down_proj 8x4096x4096 13.4 vs 23.6, x11008 24.9 vs 54.8
+            elif M <= 64:
+                splits = 1             # batched decode, wide projections: measured unsplit (25.4 / 40.1 us)
     if splits > 1 and workspace is None:
         workspace = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
     _launch("g4r_gemm_bf16_nt", (
