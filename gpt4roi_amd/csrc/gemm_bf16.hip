@@ -1114,8 +1114,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   constexpr int ROWB = 64, SPR = 4;
   constexpr int WTM = BM / 2, WTN = BN / 4;      // wave tile: 2 row groups (the two ping-pong groups) x 4 column slices
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  static_assert(BM + BN == 512 && WTM % 32 == 0 && WTN % 32 == 0, "32 KB per K tile, 32x32 accumulator blocks");
-  constexpr int NA = BM * SPR / NT, NB = BN * SPR / NT;  // 2 + 2 pieces per wave per K tile
+  static_assert((BM + BN == 512 || (BM == 192 && BN == 256)) && WTM % 32 == 0 && WTN % 32 == 0,
+                "32 KB (28 KB for 192 x 256) per K tile, 32x32 accumulator blocks");
+  // pieces per wave per K tile: 2 + 2; for BM = 192 the A tile has 12 pieces -> waves 0-3 carry two, waves 4-7 one
+  constexpr int NA = (BM * SPR + NT - 1) / NT, NB = BN * SPR / NT;
+  constexpr bool UNEVEN = (BM * SPR) % NT != 0;
   constexpr int A_BYTES = BM * BKT * 2, STAGE_BYTES = (BM + BN) * BKT * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // RING * STAGE_BYTES = 128 KB
   const int tid = threadIdx.x;
@@ -1214,6 +1217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   auto piece = [&](int j, const TileSrc& ts, int buf) {
     char* sa = smem + buf * STAGE_BYTES;
     if (j < NA) {
+      if (UNEVEN && (j * NW + wave) * 16 >= BM) return;        // this wave has no j-th A piece (wave-uniform)
       const bf16_t* src = a_src[j] + ts.a_off;
       if (AMODE == 2) src += (long)(ts.dy * a_w[j] + ts.dx) * p.lda;
       if (AMODE >= 1) {
@@ -1307,7 +1311,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
       if (i + RING - 1 < nt) {
         stage(t_begin + i + RING - 1, (i + RING - 1) & (RING - 1));
         G4R_PP32_STAMP(2);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile i+1's pieces (issued two read phases ago) have landed
+        // tile i+1's pieces (issued two read phases ago) have landed: all but the two youngest tiles' pieces are waited for
+        if (UNEVEN && wave >= 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -1326,7 +1332,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     if (grp == 0) G4R_PP_BARRIER();
   }
   __syncthreads();   // every wave is done with the operand ring: its space now stages the epilogue
-  constexpr int EPR = TN == 2 ? 64 : 32;     // rows per epilogue pass: 8 waves x pass must fit the 160 KB of LDS
+  constexpr int EPR = (TN == 2 && TM % 2 == 0) ? 64 : 32;   // rows per epilogue pass: 8 waves x pass must fit the 160 KB of LDS
   gemm_epilogue_lds<TM, TN, EPR>(p, acc, smem + wave * EpiLds<TN, EPR>::WAVE_BYTES, m0 + wm * WTM, n0 + wn * WTN, lane, split);
   if (PROBE) { if (wg_probe) { wg_stamps[3] = __builtin_amdgcn_s_memtime(); wg_stamps[6] = wall_clock64(); } }
 }
@@ -1603,8 +1609,8 @@ int launch_pp32(GemmArgs& p, hipStream_t stream) {
   }
   p.tiles_m = g4r_ceil_div(p.M, BM);
   p.tiles_n = g4r_ceil_div(p.N, BN);
-  constexpr int TN = BN / 4 / 32;
-  const size_t ring = 4 * (BM + BN) * 32 * 2, epi = 8 * (size_t)EpiLds<TN, (TN == 2 ? 64 : 32)>::WAVE_BYTES;
+  constexpr int TN = BN / 4 / 32, TM = BM / 2 / 32;
+  const size_t ring = 4 * (BM + BN) * 32 * 2, epi = 8 * (size_t)EpiLds<TN, ((TN == 2 && TM % 2 == 0) ? 64 : 32)>::WAVE_BYTES;
   const size_t lds = ring > epi ? ring : epi;
   auto kern = gemm_bf16_pp32_kernel<AMODE, PROBE, BM, BN>;
   static bool attr_set = false;
@@ -1718,6 +1724,7 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 22: return launch_pp<AMODE>(p, stream);                                 // 256x256 ping-pong (4 barriers / K tile)
     case 24: return launch_pp32<AMODE>(p, stream);                               // 256x256 ping-pong, K 32 ring of 4
     case 27: return launch_pp32<AMODE, false, 128, 384>(p, stream);              // 128x384 ring ping-pong (767 x 12288: 192 workgroups)
+    case 28: return launch_pp32<AMODE, false, 192, 256>(p, stream);              // 192x256 ring ping-pong (767 x 12288: 4 x 48 = 192 workgroups)
     case 25: return launch_pp32<AMODE, true>(p, stream);                         // same + s_memtime stamps (tools only)
     case 23: return launch_pp<AMODE, true>(p, stream);                           // same + s_memtime stamps into ws (tools only)
     default: return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");

@@ -119,7 +119,7 @@ class _Profiler:
 PROFILER = _Profiler()
 TILE_NAMES = {0: "128x128", 1: "256x128", 2: "128x128reg", 4: "64x128", 5: "128x128s3", 6: "128x128s4",
               7: "128x128w8s4", 8: "256x128s3", 9: "256x256", 10: "128x128w8", 11: "128x64", 12: "64x128s4", 13: "64x128s3", 14: "64x64s4",
-              15: "128x64s4", 22: "256x256pp", 24: "256x256pp32", 26: "256x256w4"}
+              15: "128x64s4", 22: "256x256pp", 24: "256x256pp32", 26: "256x256w4", 27: "128x384pp32", 28: "192x256pp32"}
 
 
 def _launch(name, args, tag=None, flops=0.0, nbytes=0.0):
@@ -182,6 +182,11 @@ def pick_tile(M, N, K=0):
     if K >= 1024 and K % 64 == 0 and (-(-M // 256) * 256) <= 1.1 * M:     # K = 1024: ViT at batch 8 (4616x3072x1024: 715 vs 552 TF/s)
         eff = t256 / (-(-t256 // 256) * 256)
         if (t256 <= 256 and eff >= 0.55) or eff >= 0.85:
+            # one partial wave: 192-row tiles when they give more of the 256 CUs a (smaller) tile -- LLaMA fused qkv
+            # 767x12288x4096: 4 x 48 = 192 workgroups of 0.75 the work, 101.6 vs 114.6 us (profiles/r02_gemm_tiles.md)
+            t192 = -(-M // 192) * -(-N // 256)
+            if t256 <= 256 and eff < 0.75 and t256 < t192 <= 256 and (-(-M // 192) * 192) <= 1.1 * M:
+                return 28
             return 24
     t128 = -(-M // 128) * -(-N // 128)
     if t128 >= 192:
@@ -256,7 +261,7 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
     assert out.stride(1) == 1 and out.shape == (M, n_out)
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
-    if tile_cfg is None and splits == 1 and pick_tile(M, N, K) != 24:
+    if tile_cfg is None and splits == 1 and pick_tile(M, N, K) not in (24, 28):
         n_main = wave_split(M, N, K)
         if n_main is not None:
             o_main = n_main // 2 if act == "swiglu" else n_main

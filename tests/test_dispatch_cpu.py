@@ -7,7 +7,7 @@ from gpt4roi_amd import kernels as K
 
 
 @pytest.mark.parametrize("M,N,Kd,tile,main", [
-    (767, 12288, 4096, 24, None),      # LLaMA fused qkv: ring ping-pong 256x256 (144 tiles)
+    (767, 12288, 4096, 28, None),      # LLaMA fused qkv: ring ping-pong with 192-row tiles (4 x 48 = 192 workgroups)
     (767, 22016, 4096, 0, 21760),      # gate|up: whole-wave column split, 255 tiles on the ring kernel + 256 columns
     (767, 32006, 4096, 0, 21760),      # lm_head
     (767, 4096, 4096, 7, None),        # o_proj: 128x128 x 8 waves, ring of 4

@@ -148,7 +148,7 @@ def test_roi_align_mlvl_staged_path_edge_boxes():
 
 
 # ------------------------------------------------------------------------------------------ GEMM / conv
-@pytest.mark.parametrize("tile", [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 22, 24, 26, 27])
+@pytest.mark.parametrize("tile", [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 22, 24, 26, 27, 28])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 328, 192), (37, 1024, 1024), (800, 512, 2048),
                                    (50, 30, 64), (300, 256, 128)])
 def test_gemm_plain(tile, M, N, K):
@@ -186,7 +186,7 @@ def test_gemm_epilogue(act):
     # the 256x256 kernels finish through LDS (row-major, whole-line stores): same arithmetic, bit-identical results to the
     # direct epilogue of the 128-wide tiles on the same fp32 sums -- checked on ragged shapes too (N not a multiple of 8,
     # strided output / residual, fp32 output, split-K partials)
-    for tile in (22, 24, 26, 27):
+    for tile in (22, 24, 26, 27, 28):
         close(K.gemm(a, w, bias=bias, residual=res, act=act, tile_cfg=tile), ref, 0.05, 1e-2, f"epilogue {act} tile {tile}")
         close(K.gemm(a, w, bias=bias, residual=res, act=act, out_dtype=torch.float32, tile_cfg=tile), ref, 0.02, 2e-3,
               f"f32 out tile {tile}")
@@ -206,7 +206,7 @@ def test_gemm_swiglu_epilogue():
     a, g, u = rnd(M, Kd, seed=20), rnd(Fd, Kd, scale=0.1, seed=21), rnd(Fd, Kd, scale=0.1, seed=22)
     gate, up = a.float() @ g.float().t(), a.float() @ u.float().t()
     ref = F.silu(gate).to(torch.bfloat16).float() * up
-    for tile in (0, 4, 7, 24, 26):
+    for tile in (0, 4, 7, 24, 26, 28):
         got = K.gemm(a, K.interleave_gate_up(g, u), act="swiglu", tile_cfg=tile)
         assert got.shape == (M, Fd)
         close(got, ref, 0.03, 2e-2, f"swiglu epilogue tile {tile}")
@@ -244,7 +244,7 @@ def test_gemm_flatten_linear_shape():
     close(got, ref, 0.05, 1e-2, "flatten_linear")
 
 
-@pytest.mark.parametrize("tile", [0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 22, 24, 26])
+@pytest.mark.parametrize("tile", [0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 22, 24, 26, 28])
 def test_conv3x3(tile):
     B, H, W, Cin, Cout = 2, 13, 9, 64, 96
     x = rnd(B, H, W, Cin, seed=14)
