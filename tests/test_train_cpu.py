@@ -42,7 +42,7 @@ def test_cosine_schedule_matches_hf_trainer():
 def test_tile_planners():
     from gpt4roi_amd import kernels as K
     # the ring ping-pong tile only where whole waves of 256x256 tiles come out; never for skinny or short-K problems
-    assert K.pick_tile(767, 12288, 4096) == 24 and K.pick_tile(4096, 4096, 4096) == 24
+    assert K.pick_tile(767, 12288, 4096) == 28 and K.pick_tile(4096, 4096, 4096) == 24   # ring ping-pong: 192- / 256-row tiles
     assert K.pick_tile(767, 22016, 4096) != 24 and K.pick_tile(577, 4096, 1024) != 24 and K.pick_tile(1, 4096, 4096) != 24
     assert K.wave_split(767, 22016, 4096) == 85 * 256      # 3 x 85 = 255 tiles = one wave; tail of 256 columns
     assert K.wave_split(767, 32006, 4096) == 85 * 256
