@@ -1,6 +1,6 @@
 """tools/decode_bench.py -- the KV-cache decode step of row a17 in isolation (LLaMA-7B shapes, synthetic weights, batch 1):
 ms per token of the captured hipGraph, and the weight-streaming rate it corresponds to.  Run under
-`rocprofv3 --kernel-trace --stats` for the per-kernel split (tools/gpu_run10.sh).
+`rocprofv3 --kernel-trace --stats` for the per-kernel split (tools/runs/gpu_run10.sh).
     python tools/decode_bench.py [--tokens 64] [--prompt 767] [--layers 32] [--sample]"""
 import argparse
 import os
