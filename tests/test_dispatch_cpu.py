@@ -36,3 +36,19 @@ def test_mlvl_geometry_of_the_336_pyramid_is_three_full_waves():
     assert rows == 48960 and -(-rows // 256) * (1024 // 256) == 768 == 3 * 256
     for start in (192 * 192, 192 * 192 + 96 * 96, 192 * 192 + 96 * 96 + 48 * 48):
         assert start % 256 == 0                                   # level boundaries fall on tile boundaries at P = 24
+
+
+def test_mlvl_maps_layout_is_level_major_with_contiguous_per_level_views():
+    """kernels.MlvlMaps: the buffer conv3x3_mlvl reads / writes -- [level][b][y][x][C] in one allocation, each level a
+    contiguous NHWC view at the row offset the kernel's level table assumes."""
+    import torch
+    m = K.MlvlMaps(2, [(6, 5), (3, 3), (2, 1)], 8, "cpu", dtype=torch.float32)
+    rows = [2 * 6 * 5, 2 * 3 * 3, 2 * 2 * 1]
+    assert m.flat.shape == (sum(rows), 8) and [tuple(v.shape) for v in m.levels] == [(2, 6, 5, 8), (2, 3, 3, 8), (2, 2, 1, 8)]
+    off = 0
+    for v, n in zip(m.levels, rows):
+        assert v.is_contiguous() and v.data_ptr() == m.flat[off].data_ptr()
+        off += n
+    m.levels[1][1, 2, 0, 3] = 7.0                                 # level 1, image 1, y 2, x 0 -> flat row 60 + 9 + 6
+    assert float(m.flat[60 + 9 + 6, 3]) == 7.0
+    assert list(m._hw[0]) == [6, 3, 2] and list(m._hw[1]) == [5, 3, 1]
