@@ -173,7 +173,7 @@ def from_pretrained(cls, path, device="cuda", vision_tower=None, tokenizer=None,
     # token ids: from the config when it carries them (checkpoints this path wrote), else the positions
     # initialize_vision_tokenizer gives them (spi_llava.py:248-258) at the END of the vocabulary; a tokenizer, when
     # given, is authoritative (app.py:84-104 reads the ids off the tokenizer).
-    ids = syn.token_ids(vocab - 6)
+    ids = syn.token_ids(vocab - 5)      # the LAST five rows: <im_patch>, <bbox>, <point>, <im_start>, <im_end> (after [PAD])
     for k in ("im_patch_token", "im_start_token", "im_end_token", "bbox_token", "point_token"):
         if k in cfg:
             setattr(ids, k, int(cfg[k]))

@@ -665,6 +665,8 @@ __device__ __forceinline__ float dot8_bf16(const uint4v& a, const uint4v& b, flo
 // ws [H][S][D + 2] (un-normalised o, running max m, sum l per split), mS = S, mD = D.  Doing the merge in the consumer's
 // staging loop replaces a cross-workgroup hand-off inside the attention launch (sc1 write-through, arrival counter, sc1
 // read-back: ~6 us of serial memory round trips per layer) by a kernel boundary that is there anyway.
+// x is staged in dynamic LDS (2 K bytes) next to a 16-byte static array: both must fit the default 64 KB limit
+#define G4R_GEMV_MAX_K 32736
 template <int R, int U, int XMODE, int NWV>
 __global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                         float eps, int mS, int mD, const bf16_t* __restrict__ W,
@@ -1749,7 +1751,7 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
   G4R_REQUIRE(act >= 0 && act <= 4, "gemm: act must be 0..4");
   G4R_REQUIRE(act != 4 || (N % 4 == 0 && ldc % 2 == 0 && !residual && !bias && !out_f32 && K % BK == 0),
               "gemm: swiglu epilogue needs N % 4 == 0, bf16 output, no bias/residual");
-  if (M == 1 && K % 8 == 0 && (ldw % 8) == 0 && splits == 1 && K >= 512 && K <= 32768 && (act != 4 || N % 4 == 0)) {
+  if (M == 1 && K % 8 == 0 && (ldw % 8) == 0 && splits == 1 && K >= 512 && K <= G4R_GEMV_MAX_K && (act != 4 || N % 4 == 0)) {
     // single-token decode: weight-streaming GEMV
     gemv_dispatch(g_gemm_dbg >= 100 ? g_gemm_dbg - 100 : -1, 0, (const bf16_t*)A, nullptr, 0.f, 0, 0, (const bf16_t*)W, C,
                   bias, (const bf16_t*)residual, N, K, ldw, act, out_f32, (hipStream_t)stream);
@@ -1787,7 +1789,7 @@ int g4r_gemv_rmsnorm_bf16(const void* x, const float* gamma, float eps, const vo
   G4R_REQUIRE(x && W && C, "gemv: null pointer");
   G4R_REQUIRE(act >= 0 && act <= 4, "gemv: act must be 0..4");
   G4R_REQUIRE(act != 4 || (N % 4 == 0 && !residual && !bias && !out_f32), "gemv: swiglu needs N % 4 == 0, bf16 output");
-  G4R_REQUIRE(K <= (gamma ? 8192 : 32768), "gemv: K <= 8192 with the fused norm, <= 32768 without");
+  G4R_REQUIRE(K <= (gamma ? 8192 : G4R_GEMV_MAX_K), "gemv: K <= 8192 with the fused norm, <= 32736 without (x is staged in 64 KB of LDS)");
   gemv_dispatch(g_gemm_dbg >= 100 ? g_gemm_dbg - 100 : -1, gamma ? 1 : 0, (const bf16_t*)x, gamma, eps, 0, 0,
                 (const bf16_t*)W, C, bias, (const bf16_t*)residual, N, K, ldw, act, out_f32, (hipStream_t)stream);
   G4R_CHECK_LAUNCH("gemv_rmsnorm_bf16");
@@ -1798,7 +1800,7 @@ int g4r_gemv_rmsnorm_bf16(const void* x, const float* gamma, float eps, const vo
 // from the per-split partials g4r_attn_decode_bf16 wrote with defer_merge (partials [H][splits][head_dim + 2] fp32).
 int g4r_gemv_attn_merge_bf16(const float* partials, int splits, int head_dim, const void* W, void* C, const float* bias,
                              const void* residual, int N, int K, int ldw, int out_f32, void* stream) {
-  G4R_REQUIRE(N > 0 && K >= 512 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K && K <= 32768, "gemv_attn_merge: bad shape");
+  G4R_REQUIRE(N > 0 && K >= 512 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K && K <= G4R_GEMV_MAX_K, "gemv_attn_merge: bad shape");
   G4R_REQUIRE(partials && W && C, "gemv_attn_merge: null pointer");
   G4R_REQUIRE(splits >= 1 && splits <= 64 && (head_dim == 64 || head_dim == 128) && K % head_dim == 0,
               "gemv_attn_merge: splits in [1, 64], head_dim 64 or 128 dividing K");

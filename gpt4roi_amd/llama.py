@@ -356,15 +356,14 @@ class LlamaDecoder:
         key = None if sampler is None else tuple(float(x) for x in sampler)
         graph = st["graphs"].get(key) if use_graph else None
 
+        checked = [0]                               # tokens already shown to stop_ids / the criteria
+
         def finished(n):
             ids = st["out"][:n].tolist()
-            hit = [i for i, t in enumerate(ids) if t in stop_ids]
-            if hit:
-                return hit[0] + 1
-            if on_tokens is not None:
-                for m in range(1, n + 1):          # criteria see the sequence token by token, like HF's loop
-                    if on_tokens(ids[:m]):
-                        return m
+            for m in range(checked[0] + 1, n + 1):  # each prefix once, token by token, like HF's loop: n calls in all
+                if ids[m - 1] in stop_ids or (on_tokens is not None and on_tokens(ids[:m])):
+                    return m
+            checked[0] = n
             return None
 
         end = finished(done) if (stop_ids or on_tokens) else None

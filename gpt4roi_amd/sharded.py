@@ -180,8 +180,22 @@ class ShardedAdamW:
                 if self.world > 1:
                     dist.all_reduce(total, group=self.group)    # -> the global squared norm (8 bytes)
             f.step(shards_g, lr, max_grad_norm if clip else None, total_sq=total)
+        self.publish()
+        return total if clip else None
+
+    def publish(self):
+        """In-place all-gather of every flat parameter bucket from the ranks' owned slices (the live tensors the kernels
+        read are views of these buckets)."""
         if self.world > 1:
             for b in self.buckets:
                 self._async(lambda b=b: dist.all_gather_into_tensor(b.param, b.param_shard, group=self.group), b)
             self._wait()
-        return total if clip else None
+
+    def load_masters(self):
+        """After the fp32 masters were restored (checkpoint resume): rewrite the live parameters from them -- the owned
+        slice as dtype(master), then the all-gather -- so the first forward reads the restored weights, not the ones the
+        process was constructed with."""
+        for b in self.buckets:
+            if b.live_dtype != torch.float32:                   # fp32 buckets: the master IS the parameter slice
+                b.param_shard.copy_(b.master)
+        self.publish()

@@ -296,6 +296,15 @@ class SPILlavaLlamaModel(nn.Module):
                 for k in ("mm_projector.bias", "mm_projector.weight"):
                     on_grad(k, grads[k])
         if ctx["sctx"] is None:
+            # a batch without regions: the reference keeps every region-module parameter in the graph through a zero
+            # dummy term (gpt4roi/models/layers.py:314-317, spi_llava.py:94-108), so the step -- and with world > 1 the
+            # gradient exchange, which waits for every registered gradient on every rank -- goes on with ZERO gradients
+            named = list(self.spi_module.named_parameters())
+            for k, prm in reversed(named):                                      # the order the real backward reports in
+                g = torch.zeros(prm.shape, dtype=torch.float32, device=d_emb.device)
+                grads[f"spi_module.{k}"] = g
+                if on_grad is not None:
+                    on_grad(f"spi_module.{k}", g)
             return grads
         idx_bbox = (flat == cfg.bbox_token).nonzero().flatten().to(torch.int32)
         assert idx_bbox.numel() == ctx["boxes"].n, "number of <bbox> tokens != number of regions"
@@ -508,6 +517,8 @@ class SPILlavaMPTForCausalLM(nn.Module):
         # decode loop owns the KV cache, so hand it the spliced embeddings
         embeds = self._prefill_embeds(fwd, model_inputs, kw)
         stops = set(int(s) for s in stop_ids)
+        if eos_token_id is None:                            # HF generate stops on the config's EOS id by default
+            eos_token_id = getattr(self.config, "eos_token_id", None)
         if eos_token_id is not None:
             stops.update([int(eos_token_id)] if not isinstance(eos_token_id, (list, tuple)) else map(int, eos_token_id))
         on_tokens = None

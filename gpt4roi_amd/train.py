@@ -307,3 +307,6 @@ class ShardedFullTrainer(FullTrainer):
             b.master.copy_(s["master"])
             b.exp_avg.copy_(s["exp_avg"])
             b.exp_avg_sq.copy_(s["exp_avg_sq"])
+        self.sharded.load_masters()                         # live bf16 / fp32 parameters <- restored masters, all ranks
+        self.model.prepare()
+        self.model.llama.refresh_transposes()

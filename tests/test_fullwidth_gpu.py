@@ -277,3 +277,101 @@ def test_config5_shape_224_crops_64_regions_full_width():
     e = relerr(got, want)
     print(f"configs[4] shape (224^2, 64 regions, C = 1024): region tokens vs oracle {e:.4f}")
     assert got.shape == (64, 4096) and e < 3e-2
+
+
+# ------------------------------------------------------------------------------------------ the BENCHMARKED model, full depth
+def test_bench_model_full_depth_32_layers_vs_hf_fp32_on_the_gpu():
+    """What bench.py times -- ViT-L/14@336 (23 blocks) + region module (C = 1024, P = 24, 32 RoIs) + projector + splice +
+    LLaMA-7B at its FULL depth (32 layers x 4096, T = 767) -- against the arithmetic the reference actually calls:
+    HF `CLIPVisionModel` and `LlamaForCausalLM` (spi_llava.py:66-67, 198-205; llava.py:235-249), built from the SAME
+    state dicts and run in fp32 with eager attention ON THE GPU (PyTorch-ROCm's own kernels: arithmetic independent of
+    everything under gpt4roi_amd/), with the region module from oracle/spi_oracle.py (bf16 rounding points, CPU, its
+    RoIAlign node = the C oracle pinned to the reference's compiled CPU op) in between.  Asserts the logits of all 767
+    positions and 16 greedy ids (generate(do_sample=False), app.py:293-300 with sampling off).
+    Tolerance: logits within 4e-2 of the logit range (a bf16 pipeline, 32 layers deep, against fp32); ids identical, unless
+    the fp32 top-2 margin at the first differing step is a near tie (< 1 % of that step's logit range) -- printed."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel, LlamaConfig, LlamaForCausalLM
+    Hv, P, image, heads_v, n_new = 1024, 24, 336, 16, 16
+    ids = syn.token_ids(32000)
+    l = syn.LLAMA_7B
+    # bf16-representable weights, generated on the device like bench.build_model does (same generator stream)
+    vsd = syn.vit_state(Hv, 4 * Hv, 24, image, seed=81, device=DEV, dtype=torch.bfloat16)
+    lsd = syn.llama_state(l["hidden"], l["inter"], l["layers"], ids.vocab, seed=82, device=DEV, dtype=torch.bfloat16)
+    tower = ClipVisionTower(vsd, heads=heads_v, device=DEV)
+    dec = LlamaDecoder(lsd, heads=l["heads"], max_positions=1024, device=DEV)
+    model = SPILlavaLlamaModel(tower, dec, ids, embed_dims=Hv)
+    orc = S.MLVLROIQueryOracle(embed_dims=Hv, P=P)
+    spi_sd = S.synthetic_state(orc, 83)
+    orc.load_state_dict(spi_sd)
+    model.spi_module.load_state_dict(spi_sd)
+    g = torch.Generator().manual_seed(84)
+    pw, pb = torch.randn(4096, Hv, generator=g) / Hv ** 0.5, torch.randn(4096, generator=g) * 0.05
+    with torch.no_grad():
+        model.mm_projector.weight.copy_(pw)
+        model.mm_projector.bias.copy_(pb)
+    lm = SPILlavaMPTForCausalLM(model)
+    img = torch.randn(1, 3, image, image, generator=g)
+    boxes = [syn.boxes(32, g)]
+    prompt = syn.prompt_ids(ids, P, 32, g)[None]
+    assert prompt.size(1) == T_PROMPT and len([k for k in lsd if k.endswith("input_layernorm.weight")]) == 32
+    dboxes = [b.to(DEV) for b in boxes]
+    with torch.no_grad():
+        out = lm(input_ids=prompt.to(DEV), images=img.to(DEV), bboxes=dboxes)
+        got_ids = lm.generate(input_ids=prompt.to(DEV), images=img.to(DEV), bboxes=dboxes, do_sample=False,
+                              max_new_tokens=n_new, return_new_tokens=True)
+    model.check_status()
+    logits = out.logits.float()
+
+    # ---- the reference side: HF modules, fp32, eager attention, on the GPU
+    vcfg = CLIPVisionConfig(hidden_size=Hv, intermediate_size=4 * Hv, num_hidden_layers=24, num_attention_heads=heads_v,
+                            image_size=image, patch_size=14, hidden_act="quick_gelu", attn_implementation="eager")
+    with torch.device(DEV):
+        hf_v = CLIPVisionModel(vcfg).float().eval()
+    vkeys = set(hf_v.state_dict().keys())
+    pre = "" if "embeddings.class_embedding" in vkeys else "vision_model."
+    missing = hf_v.load_state_dict({pre + k: v.float() for k, v in vsd.items()}, strict=False)
+    assert not [k for k in missing.missing_keys if "position_ids" not in k] and not missing.unexpected_keys, missing
+    lcfg = LlamaConfig(vocab_size=ids.vocab, hidden_size=l["hidden"], intermediate_size=l["inter"],
+                       num_hidden_layers=l["layers"], num_attention_heads=l["heads"], num_key_value_heads=l["heads"],
+                       rms_norm_eps=1e-6, max_position_embeddings=2048, attention_bias=False, tie_word_embeddings=False,
+                       rope_theta=10000.0, attn_implementation="eager")
+    with torch.device(DEV):
+        hf_l = LlamaForCausalLM(lcfg).float().eval()
+    r = hf_l.load_state_dict({k: v.float() for k, v in lsd.items()}, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    with torch.no_grad():
+        hs = hf_v(img.to(DEV), output_hidden_states=True).hidden_states
+        assert len(hs) == 25
+        img_feat, lv = T.select_spi_levels([h.cpu() for h in hs], -2, 4)       # spi_llava.py:58-82
+        spi = orc(lv, boxes, emulate=True)
+        proj = img_feat @ pw.t() + pb
+        emb = lsd["model.embed_tokens.weight"].float().cpu()[prompt]
+        spliced = S.splice(prompt, emb, proj, spi, ids.im_start_token, ids.im_end_token, ids.bbox_token)
+        o = hf_l(inputs_embeds=spliced.to(DEV), use_cache=True)
+        want = o.logits.float()
+        # greedy loop on the HF side (generate(do_sample=False) with a KV cache)
+        want_ids, trace, past, last = [], [], o.past_key_values, o.logits[0, -1]
+        embed = hf_l.get_input_embeddings()
+        for _ in range(n_new):
+            trace.append(last.float().cpu())
+            nxt = int(last.argmax())
+            want_ids.append(nxt)
+            o = hf_l(inputs_embeds=embed(torch.tensor([[nxt]], device=DEV)), past_key_values=past, use_cache=True)
+            past, last = o.past_key_values, o.logits[0, -1]
+    span = (want.max() - want.min()).item()
+    e_abs = (logits - want).abs().max().item()
+    e_rel = relerr(logits, want)
+    agree = (logits[0].argmax(-1) == want[0].argmax(-1)).float().mean().item()
+    print(f"bench model, 32 layers x 4096, T={T_PROMPT}: logits vs HF fp32 max |err| {e_abs:.4f} = {e_abs / span:.4f} of the "
+          f"logit range {span:.2f} ({e_rel:.4f} of max |logit|); per-position argmax agreement {agree:.4f}")
+    print(f"greedy ids  HIP: {got_ids}\n            HF : {want_ids}")
+    assert logits.shape == want.shape == (1, T_PROMPT, ids.vocab)
+    assert e_abs < 4e-2 * span
+    if got_ids != want_ids:
+        k = next(i for i, (a, b) in enumerate(zip(got_ids, want_ids)) if a != b)
+        top2 = trace[k].topk(2).values
+        margin, sp = float(top2[0] - top2[1]), float(trace[k].max() - trace[k].min())
+        print(f"ids differ from HF fp32 at step {k}: HF top-2 margin {margin:.3e} of a logit range {sp:.2f}")
+        assert margin < 1e-2 * sp, f"greedy ids differ from HF fp32 at step {k} with a CLEAR margin {margin:.3e}"
+    else:
+        print(f"{n_new} greedy ids identical to HF LlamaForCausalLM fp32")

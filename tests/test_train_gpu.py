@@ -666,3 +666,41 @@ def test_sharded_stage2_trainer_equals_unsharded_on_one_rank():
     sd = tb.state_dict()
     tb.load_state_dict(sd)
     assert tb.steps == 3 and len(sd["buckets"]) == len(tb.sharded.buckets)
+
+
+def test_region_less_batch_steps_with_zero_region_gradients():
+    """A batch without any region (text-only / image-only sample): the reference keeps training through a zero dummy term
+    (gpt4roi/models/layers.py:314-317, spi_llava.py:94-108).  RegionTrainer must report a ZERO gradient for every region-
+    module parameter -- through `on_grad` too, which is what the bucketed exchange waits for on every rank -- and the step
+    must leave the region module untouched while the projector trains."""
+    from gpt4roi_amd.spi_llava import SPILlavaLlamaModel
+    from gpt4roi_amd.train import RegionTrainer
+    from gpt4roi_amd.vit import ClipVisionTower
+    H, P, image = 512, 8, 112
+    ids = syn.token_ids(vocab_base=990)
+    tower = ClipVisionTower(syn.vit_state(H, 4 * H, 12, image, seed=8), heads=8, device=DEV)
+    dec = LlamaDecoder(syn.llama_state(512, 1408, 2, ids.vocab, seed=9), heads=4, max_positions=256, device=DEV)
+    model = SPILlavaLlamaModel(tower, dec, ids, embed_dims=H)
+    model.spi_module.load_state_dict(syn.spi_state(model.spi_module, 5))
+    g = torch.Generator().manual_seed(12)
+    img = torch.randn(1, 3, image, image, generator=g).to(DEV)
+    prompt = syn.prompt_ids(ids, P, 0, g, sys_len=6, question_len=9, vocab_base=990)[None].to(DEV)
+    labels = prompt.clone()
+    labels[:, :8 + P * P] = -100
+    labels[labels >= 990] = -100
+    tr = RegionTrainer(model, lr=1e-3, max_grad_norm=1.0, train_projector=True)
+    before = {k: p.detach().clone() for k, p in tr.params.items()}
+    seen = []
+    m = tr.model
+    logits, ctx = m.forward_train(prompt, img, [torch.zeros(0, 4, device=DEV)])
+    loss, dlogits = m.llama.loss_and_dlogits(logits, labels)
+    grads = m.backward(ctx, dlogits, train_projector=True, on_grad=lambda n, t: seen.append(n))
+    assert set(grads) == set(tr.params) and set(seen) == set(tr.params)            # every registered tensor is reported
+    assert all(float(grads[k].abs().max()) == 0.0 and grads[k].numel() == tr.params[k].numel()
+               for k in grads if k.startswith("spi_module."))
+    assert float(grads["mm_projector.weight"].abs().max()) > 0
+    loss2 = tr.step(prompt, img, [torch.zeros(0, 4, device=DEV)], labels)
+    assert torch.isfinite(loss2).all() and abs(float(loss2) - float(loss)) < 1e-3
+    for k, p in tr.params.items():
+        moved = float((p.detach() - before[k]).abs().max())
+        assert (moved == 0.0) if k.startswith("spi_module.") else (moved > 0.0), (k, moved)
