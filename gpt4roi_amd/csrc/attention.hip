@@ -484,7 +484,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeAttnArgs p) {
 
 }  // namespace
 
-static int g_attn_variant = 0;   // tools only: 1 = force the 4-wave head_dim-128 kernel, 2 = force the 2-wave one
+static int g_attn_variant = 0;   // tools only: 1 = force the first-form kernel (head_dim 128: 4 waves), 2 = its 2-wave form,
+                                 // >= 10: the second form (attention_v2.hip) with NWG * 10 + NG
+
+// attention_v2.hip: key groups inside the workgroup, K/V by LDS-DMA, V through ds_read_b64_tr_b16
+int g4r_attn2_dispatch(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk, int head_dim,
+                       long q_row, long k_row, long v_row, long o_row, long q_batch, long k_batch, long v_batch,
+                       long o_batch, float scale, int causal, const int* kv_len_dev, float* lse, int variant,
+                       void* stream);
 
 extern "C" {
 
@@ -504,6 +511,11 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
                   k_batch % 8 == 0 && v_batch % 8 == 0 && o_batch % 4 == 0,
               "flash_attn: strides must keep 16-byte alignment");
   G4R_REQUIRE(!causal || Tk >= Tq, "flash_attn: causal needs Tk >= Tq");
+  // the prefill shapes of the path go to the second form; a handful of query rows against a long cache (the host-loop
+  // decode, Tq < 32) stays on the first form, whose 2 x 64-row workgroups waste less on an almost empty query block
+  if ((g_attn_variant == 0 && Tq >= 32) || g_attn_variant >= 10)
+    return g4r_attn2_dispatch(Q, K, V, O, B, H, Tq, Tk, head_dim, q_row, k_row, v_row, o_row, q_batch, k_batch, v_batch,
+                              o_batch, scale, causal, kv_len_dev, lse, g_attn_variant >= 10 ? g_attn_variant : 0, stream);   // + 1000 * ablation bits (tools)
   AttnArgs a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_row, k_row, v_row, o_row,
                 q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal, kv_len_dev, lse};
   // 64 query rows per workgroup (2 waves): ~2x the workgroups of a 128-row block for the short

@@ -1,0 +1,338 @@
+// attention_v2.hip -- the prefill attention forward of the path, second form (round 3).
+//
+//   CLIP ViT-L/14 self-attention  (16 heads x 64, S = P^2+1, bidirectional)     SURVEY 8a row a4
+//   LLaMA-7B self-attention       (32 heads x 128, causal, KV cache)            row a16 (region tokens x KV)
+// Reference arithmetic: HF transformers attention (spi_llava.py:66-67, 198-205) / flash-attn
+// (llava/train/llama_flash_attn_monkey_patch.py:15-91): softmax(Q K^T * scale [+ causal mask]) V.
+//
+// What was wrong with the first form (attention.hip, kept for Tq < 32 and as the A/B arm): one wave per SIMD ran the K/V
+// staging (global -> registers -> LDS, V transposed by 8-byte stores), two barriers, the softmax and the 32 MFMAs of a
+// 64-key tile back to back (~2.4 us per tile against 0.5 us of MFMA), and at T = 767 the longest workgroup walks 12 tiles
+// while the shortest walks 2.  Here:
+//   * a workgroup = NG key GROUPS x NWG waves.  All groups own the SAME 32 x NWG query rows; group g takes the key tiles
+//     g, g + NG, g + 2 NG, ... (flash-decoding inside the workgroup).  The critical path of the longest query block
+//     drops from 12 tiles to 12 / NG steps, and every SIMD hosts NG waves whose softmax / MFMA / LDS phases overlap.
+//     The NG partial states (m, l, O) meet once, through LDS, at the end.
+//   * K and V tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB pieces): no staging registers, no
+//     ds_write pass, next tile in flight during the current tile's compute (double buffer, one barrier per step).
+//     K image: row-major [64 keys][D] with the 16-byte-slot XOR swizzle applied to the per-lane SOURCE address and to
+//     the ds_read_b128 address ("both sides or neither").  V image: [D/16 d-blocks][64 keys][16 d] (32-byte rows,
+//     d-blocks 2176 B apart so that the two 16-lane groups of a half-wave hit different banks), read with
+//     ds_read_b64_tr_b16: a 16-lane group fetches a [4 keys][16 d] block and each lane receives one COLUMN of it = 4
+//     keys of its own d -- the V^T fragment of the MFMA A operand with no transposing store anywhere.
+//   * register mapping as in the first form: S^T = K Q^T with v_mfma_f32_32x32x16_bf16 so a lane owns one query
+//     column (its 32 scores, its running max / sum, its O^T registers); the key order inside a 16-key MFMA step is
+//     permuted to the order the lane already holds P in.
+#include "g4r_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Attn2Args {
+  const bf16_t* Q;
+  const bf16_t* K;
+  const bf16_t* V;
+  bf16_t* O;
+  long q_row, k_row, v_row, o_row;
+  long q_batch, k_batch, v_batch, o_batch;
+  int Tq, Tk, H;
+  float scale;
+  int causal;
+  const int* kv_len_dev;
+  float* lse;
+  int dbg;          // tools only (ablation timing, results wrong): 1 skip V pieces, 2 skip K pieces, 4 skip softmax, 8 skip PV, 16 skip QK
+};
+
+constexpr int A2_KVB = 64;        // keys per tile
+constexpr int A2_VSUB = 64 * 32 + 128;   // bytes of one [64 keys][16 d] V sub-image + the bank offset pad
+
+template <int D>
+__device__ __forceinline__ int a2_kswz(int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); }
+
+template <int D>
+constexpr int a2_tile_bytes() { return A2_KVB * D * 2 + (D / 16) * A2_VSUB; }
+
+template <int D, int NWG, int NG>
+__global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args p) {
+  constexpr int QB = NWG * 32;
+  constexpr int SLOTS = D / 8, KSTEPS = D / 16, DB = D / 32, NDD = D / 16;
+  constexpr int K_BYTES = A2_KVB * D * 2, TILE_BYTES = a2_tile_bytes<D>();
+  constexpr int KP = K_BYTES / 1024, VP = NDD * 2;        // 1 KiB pieces of a K / V tile
+  constexpr int PPW = (KP + VP) / NWG, KPW = KP / NWG;    // pieces per wave: the first KPW are K pieces
+  constexpr int RPP = 1024 / (D * 2);                     // key rows per K piece
+  static_assert(KP % NWG == 0 && VP % NWG == 0, "piece split");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // NG groups x 2 buffers x TILE_BYTES (one array: no second
+                                                                // __shared__ object beside an LDS-DMA pipeline)
+  if (p.kv_len_dev) p.Tk = *p.kv_len_dev + p.Tq;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave / NWG, wv = wave % NWG;
+  const int hi = lane >> 5, ql = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qblock = ((int)gridDim.x - 1 - (int)blockIdx.x) * QB;     // heaviest (latest) causal blocks first
+  const int qw0 = qblock + wv * 32;
+  const int qi = qw0 + ql;
+  const int off = p.Tk - p.Tq;
+  const bf16_t* Qb = p.Q + (size_t)b * p.q_batch + (size_t)h * D;
+  const bf16_t* Kb = p.K + (size_t)b * p.k_batch + (size_t)h * D;
+  const bf16_t* Vb = p.V + (size_t)b * p.v_batch + (size_t)h * D;
+  char* gbuf = smem + grp * (2 * TILE_BYTES);
+
+  bf16x8 qf[KSTEPS];
+  {
+    const int qr = qi < p.Tq ? qi : p.Tq - 1;
+    const bf16_t* qrow = Qb + (size_t)qr * p.q_row + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>((p.dbg & 64) ? Qb + lane * 8 : qrow + kk * 16);
+  }
+  float16v oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sc2 = p.scale * 1.4426950408889634f;
+
+  int kend = p.Tk;
+  if (p.causal) {
+    const int last = qblock + QB - 1 + off + 1;
+    if (last < kend) kend = last;
+  }
+  const int ntiles = (kend + A2_KVB - 1) / A2_KVB;
+  const int nsteps = (ntiles + NG - 1) / NG;
+
+  // ---- this lane's part of the wave's pieces: row inside the tile and element offset inside the row ----
+  int prow[PPW], pcol[PPW], pdst[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    if (j < KPW) {
+      const int pk = wv + NWG * j;
+      const int row = pk * RPP + lane / SLOTS;
+      prow[j] = row;
+      pcol[j] = ((lane % SLOTS) ^ a2_kswz<D>(row)) * 8;
+      pdst[j] = pk * 1024;
+    } else {
+      const int pv = wv + NWG * (j - KPW);
+      const int dd = pv >> 1, half = pv & 1;
+      prow[j] = half * 32 + (lane >> 1);
+      pcol[j] = dd * 16 + (lane & 1) * 8;
+      pdst[j] = K_BYTES + dd * A2_VSUB + half * 1024;
+    }
+  }
+  auto issue = [&](int tile, int buf) {
+    const int j0 = tile * A2_KVB;
+    char* dst = gbuf + buf * TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      if (p.dbg & (j < KPW ? 2 : 1)) continue;
+      int key = j0 + prow[j];
+      if (key > p.Tk - 1) key = p.Tk - 1;
+      const bf16_t* src = (j < KPW ? Kb + (size_t)key * p.k_row : Vb + (size_t)key * p.v_row) + pcol[j];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + pdst[j]), 16, 0, 0);
+    }
+  };
+
+  // per-lane LDS offsets of the fragment reads
+  const int k_row_off = ql * (D * 2);
+  const int k_sw = a2_kswz<D>(ql);      // rows ql and ql + 32 share the swizzle (32 = 0 mod 16; (32 >> 1) = 0 mod 8)
+  const int v_lane_off = K_BYTES + ((lane >> 4) & 1) * A2_VSUB + hi * 128 + (lane & 15) * 8;
+
+  if (grp < ntiles) issue(grp, 0);
+  for (int s = 0; s < nsteps; ++s) {
+    const int tile = s * NG + grp;
+    const int buf = s & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of step s have landed
+    __builtin_amdgcn_s_barrier();                          // ... everyone's; and everyone is done reading buffer buf ^ 1
+    if (tile + NG < ntiles) issue(tile + NG, buf ^ 1);
+    const int j0 = tile * A2_KVB;
+    // a wave skips tiles that are beyond the keys (ragged tail of the split) or entirely above its causal diagonal
+    if (tile < ntiles && !(p.causal && j0 > qw0 + 31 + off)) {
+      const char* kt = gbuf + buf * TILE_BYTES;
+      // ---- S^T = K Q^T for two 32-key blocks ----
+      float16v sacc[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+        const char* krow = kt + kb * 32 * (D * 2) + k_row_off;
+        if (p.dbg & 16) continue;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((kk * 2 + hi) ^ k_sw) << 4));
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sacc[kb], 0, 0, 0);
+        }
+      }
+      // ---- online softmax of this lane's query (keys j0 + kb*32 + (r&3) + 8*(r>>2) + 4*hi), log2 domain ----
+      const bool need_mask = (j0 + A2_KVB > p.Tk) || (p.causal && j0 + A2_KVB - 1 > qw0 + off);
+      float mt = -INFINITY;
+      if (p.dbg & 4) {
+        mt = 0.f;
+      } else if (need_mask) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float sv = sacc[kb][r] * sc2;
+            if (key >= p.Tk || (p.causal && key > qi + off)) sv = -INFINITY;
+            sacc[kb][r] = sv;
+            mt = fmaxf(mt, sv);
+          }
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            sacc[kb][r] *= sc2;
+            mt = fmaxf(mt, sacc[kb][r]);
+          }
+      }
+      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      const float m_new = fmaxf(m_run, mt);
+      const float m_use = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+      float rs = 0.f;
+      if (!(p.dbg & 4)) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(sacc[kb][r] - m_use);
+          sacc[kb][r] = e;
+          rs += e;
+        }
+      }
+      rs += __shfl_xor(rs, 32);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      // ---- O^T += V^T P^T : A operand = 4 + 4 keys of this lane's d through two transpose reads ----
+      const char* vt = kt + v_lane_off;
+      if (!(p.dbg & 8))
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          uint4v pw;
+          pw.x = pack_bf16x2(sacc[kb][hf * 8 + 0], sacc[kb][hf * 8 + 1]);
+          pw.y = pack_bf16x2(sacc[kb][hf * 8 + 2], sacc[kb][hf * 8 + 3]);
+          pw.z = pack_bf16x2(sacc[kb][hf * 8 + 4], sacc[kb][hf * 8 + 5]);
+          pw.w = pack_bf16x2(sacc[kb][hf * 8 + 6], sacc[kb][hf * 8 + 7]);
+          const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+          for (int d = 0; d < DB; ++d) {
+            const char* a = vt + d * 2 * A2_VSUB + (kb * 32 + hf * 16) * 32;
+            const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (short4v __attribute__((address_space(3)))*)(a));
+            const short4v up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (short4v __attribute__((address_space(3)))*)(a + 8 * 32));
+            const short8 vv = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[d], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  // ---- merge the NG partial states through LDS (the tile buffers are free after this barrier) ----
+  if (NG > 1 && !(p.dbg & 128)) {
+    __builtin_amdgcn_s_barrier();
+    float* mo = reinterpret_cast<float*>(smem);
+    constexpr int REGS = DB * 16 + 2;                      // O^T registers + m + l, per (group - 1, wave, lane)
+    if (grp > 0) {
+      float* dst = mo + ((size_t)((grp - 1) * NWG + wv) * REGS) * 64 + lane;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(d * 16 + r) * 64] = oacc[d][r];
+      dst[(DB * 16) * 64] = m_run;
+      dst[(DB * 16 + 1) * 64] = l_run;
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < NG; ++g) {
+      const float* src = mo + ((size_t)((g - 1) * NWG + wv) * REGS) * 64 + lane;
+      const float m_o = src[(DB * 16) * 64], l_o = src[(DB * 16 + 1) * 64];
+      const float m_new = fmaxf(m_run, m_o);
+      const float m_use = m_new == -INFINITY ? 0.f : m_new;
+      const float a_me = __builtin_amdgcn_exp2f(m_run - m_use), a_o = __builtin_amdgcn_exp2f(m_o - m_use);
+      l_run = l_run * a_me + l_o * a_o;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = oacc[d][r] * a_me + src[(d * 16 + r) * 64] * a_o;
+    }
+  }
+
+  if (qi < p.Tq && !((p.dbg & 32) && l_run != 12345.f)) {
+    if (p.lse && hi == 0) p.lse[((size_t)b * p.H + h) * p.Tq + qi] = m_run + __log2f(l_run);
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    bf16_t* orow = p.O + (size_t)b * p.o_batch + (size_t)qi * p.o_row + (size_t)h * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint2v w = {pack_bf16x2(oacc[d][g * 4] * inv, oacc[d][g * 4 + 1] * inv),
+                          pack_bf16x2(oacc[d][g * 4 + 2] * inv, oacc[d][g * 4 + 3] * inv)};
+        *reinterpret_cast<uint2v*>(orow + d * 32 + g * 8 + 4 * hi) = w;
+      }
+  }
+}
+
+template <int D, int NWG, int NG>
+int launch_attn2(const Attn2Args& a, int B, hipStream_t st) {
+  constexpr int LDS = NG * 2 * a2_tile_bytes<D>();
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  static_assert(LDS >= (NG - 1) * NWG * (D / 32 * 16 + 2) * 64 * 4, "merge area fits the tile buffers");
+  auto kfn = flash_attn_fwd2_kernel<D, NWG, NG>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return g4r_note_hip_error(e, "flash_attn_fwd2: hipFuncSetAttribute");
+    attr_set = true;
+  }
+  dim3 grid(g4r_ceil_div(a.Tq, NWG * 32), a.H, B);
+  hipLaunchKernelGGL(kfn, grid, dim3(NWG * NG * 64), LDS, st, a);
+  return G4R_OK;
+}
+
+}  // namespace
+
+// variant: 0 = production choice; otherwise NWG * 10 + NG of an instantiated form (tools / tests)
+int g4r_attn2_dispatch(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk, int head_dim,
+                       long q_row, long k_row, long v_row, long o_row, long q_batch, long k_batch, long v_batch,
+                       long o_batch, float scale, int causal, const int* kv_len_dev, float* lse, int variant,
+                       void* stream) {
+  Attn2Args a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_row, k_row, v_row, o_row,
+                 q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal, kv_len_dev, lse, variant / 1000};
+  variant %= 1000;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = G4R_OK;
+  if (head_dim == 128) {
+    if (variant == 0) variant = 42;
+    if (variant == 42) rc = launch_attn2<128, 4, 2>(a, B, st);
+    else if (variant == 41) rc = launch_attn2<128, 4, 1>(a, B, st);
+    else if (variant == 22) rc = launch_attn2<128, 2, 2>(a, B, st);
+    else return g4r_note_error(G4R_ERR_INVALID_ARG, "flash_attn_fwd2: unknown variant for head_dim 128");
+  } else {
+    if (variant == 0) {
+      // few workgroups (the batch-1 ViT: 16 heads x 577 rows): 64-row blocks x 4 key groups; otherwise 128-row blocks
+      const long wgs128 = (long)g4r_ceil_div(Tq, 128) * H * B;
+      variant = wgs128 < 256 ? 24 : 42;
+    }
+    if (variant == 24) rc = launch_attn2<64, 2, 4>(a, B, st);
+    else if (variant == 42) rc = launch_attn2<64, 4, 2>(a, B, st);
+    else if (variant == 44) rc = launch_attn2<64, 4, 4>(a, B, st);
+    else if (variant == 41) rc = launch_attn2<64, 4, 1>(a, B, st);
+    else return g4r_note_error(G4R_ERR_INVALID_ARG, "flash_attn_fwd2: unknown variant for head_dim 64");
+  }
+  if (rc != G4R_OK) return rc;
+  G4R_CHECK_LAUNCH("flash_attn_fwd2");
+  return G4R_OK;
+}

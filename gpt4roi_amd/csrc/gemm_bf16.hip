@@ -1110,6 +1110,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 // BM x BN = 256 x 256 (wave tile 128 x 64) or 128 x 384 (wave tile 64 x 96: 6 x 32 = 192 workgroups for the LLaMA fused-qkv
 // shape 767 x 12288, where 256 x 256 tiles give only 144 of the 256 CUs a tile); both stage 32 KB per K tile = 4 LDS-DMA
 // pieces per wave, so the ring, the waits and the phase structure are identical.
+// (Round 3 probe, since removed: issuing a wave's W pieces -- or all four -- at the HEAD of its MFMA phase instead of the
+// end of its read phase, i.e. while the other group is still reading fragments and the address path is idle, changes
+// nothing: 4096^3 1174 / 1141 / 1153 TF/s back to back, conv 192^2 860 / 859 / 739; profiles/r03_gemm_bench_a.jsonl.)
 template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   constexpr int NW = 8, NT = 512, BKT = 32, RING = 4;
@@ -1151,6 +1154,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   const bf16_t* a_src[NA];
   int a_y[NA], a_x[NA];
   int a_h[NA], a_w[NA];                    // AMODE 2: the row's own map size (rows of several pyramid levels in one GEMM)
+  unsigned a_ok[NA];
+  int a_pitch[NA];
   const bf16_t* b_src[NB];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
@@ -1180,6 +1185,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
       a_y[j] = rem / p.Wd;
       a_x[j] = rem - a_y[j] * p.Wd;
     }
+    // the nine taps' in-image bits of this lane's pixel and its row pitch in elements: the per-K-tile work of a piece is
+    // then one bit test, one multiply-add and a select (the four compares and the 64-bit multiply per piece per K tile of
+    // round 2 sat in the READ phase, the longer one of the ping-pong: the conv's K tile ran 1.3x the dense GEMM's)
+    a_ok[j] = 0;
+    a_pitch[j] = a_w[j] * p.lda;
+    if (AMODE >= 1) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int yy = a_y[j] + tp / 3 - 1, xx = a_x[j] + tp % 3 - 1;
+        if (yy >= 0 && yy < a_h[j] && xx >= 0 && xx < a_w[j]) a_ok[j] |= 1u << tp;
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -1190,28 +1207,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     if (gn > p.N - 1) gn = p.N - 1;
     b_src[j] = p.W + (size_t)gn * p.ldw + kslot * 8;
   }
-  struct TileSrc { long a_off; int k0, dy, dx; };
+  struct TileSrc { long a_off; int k0, dy, dx, tap; };
+  // (channel slice, group, tap) of the NEXT tile to stage: tiles are staged strictly in order, so the walk is a counter
+  // (taps fastest, then groups, then 32-channel slices) instead of two runtime divisions per K tile per wave
+  int st_ct = 0, st_g = 0, st_tap = 0;
+  if (AMODE >= 1) {
+    const int n_taps = 9 * p.groups;
+    st_ct = t_begin / n_taps;
+    const int rem = t_begin - st_ct * n_taps;
+    st_g = rem / 9;
+    st_tap = rem - st_g * 9;
+  }
   auto tile_src = [&](int t) {
     TileSrc ts;
     ts.k0 = t * BKT;
     ts.a_off = ts.k0;
-    ts.dy = ts.dx = 0;
+    ts.dy = ts.dx = ts.tap = 0;
     if (AMODE >= 1) {
-      const int n_taps = 9 * p.groups;          // taps fastest, channel slice outer (see gemm_bf16_nt_kernel)
-      int ct = t / n_taps;
-      int tap_lin = t - ct * n_taps;
-      if (p.dbg == 7) {                         // A/B probe (tools only): taps outermost, the round-1 order
-        const int per_tap = p.Cin / BKT;
-        tap_lin = t / per_tap;
-        ct = t - tap_lin * per_tap;
-      }
-      const int c0 = ct * BKT;
-      const int g = tap_lin / 9, tap = tap_lin - g * 9;
-      ts.dy = tap / 3 - 1;
-      ts.dx = tap - (tap / 3) * 3 - 1;
-      ts.a_off = (long)g * p.a_group_stride + ((long)ts.dy * p.Wd + ts.dx) * p.lda + c0;
+      const int c0 = st_ct * BKT;
+      ts.tap = st_tap;
+      ts.dy = st_tap / 3 - 1;
+      ts.dx = st_tap - (st_tap / 3) * 3 - 1;
+      ts.a_off = (long)st_g * p.a_group_stride + (long)((ts.dy * p.Wd + ts.dx) * p.lda) + c0;
       if (AMODE == 2) ts.a_off = c0;            // the pixel shift depends on the row's own map width: added per piece
-      ts.k0 = tap_lin * p.Cin + c0;
+      ts.k0 = (st_g * 9 + st_tap) * p.Cin + c0;
+      if (++st_tap == 9) {
+        st_tap = 0;
+        if (++st_g == p.groups) { st_g = 0; ++st_ct; }
+      }
     }
     return ts;
   };
@@ -1221,10 +1244,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     if (j < NA) {
       if (UNEVEN && (j * NW + wave) * 16 >= BM) return;        // this wave has no j-th A piece (wave-uniform)
       const bf16_t* src = a_src[j] + ts.a_off;
-      if (AMODE == 2) src += (long)(ts.dy * a_w[j] + ts.dx) * p.lda;
+      if (AMODE == 2) src += ts.dy * a_pitch[j] + ts.dx * p.lda;
       if (AMODE >= 1) {
-        const int yy = a_y[j] + ts.dy, xx = a_x[j] + ts.dx;
-        if (yy < 0 || yy >= a_h[j] || xx < 0 || xx >= a_w[j]) src = p.zeros + (lane & 3) * 8;
+        if (!((a_ok[j] >> ts.tap) & 1u)) src = p.zeros + (lane & 3) * 8;
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sa + (j * NW + wave) * 1024), 16, 0, 0);

@@ -305,6 +305,38 @@ def test_flash_attention(B, H, D, Tq, Tk, causal):
     close(got, _attn_ref(q, k, v, H, scale, causal), 2e-2, 2e-2, f"attn {B,H,D,Tq,Tk,causal}")
 
 
+@pytest.mark.parametrize("B,H,D,Tq,Tk,causal", [(1, 32, 128, 767, 767, True), (1, 16, 64, 577, 577, False),
+                                                 (1, 8, 128, 100, 300, True), (2, 3, 128, 129, 129, True),
+                                                 (1, 4, 64, 32, 1000, False), (3, 16, 64, 577, 577, False)])
+def test_flash_attention_second_form_every_variant_output_and_lse(B, H, D, Tq, Tk, causal):
+    """csrc/attention_v2.hip (key groups inside the workgroup, K/V by LDS-DMA, V through the transpose read) at the
+    shapes of the path -- LLaMA prefill T = 767, ViT S = 577, a cached prefill with an offset diagonal -- for every
+    instantiated (waves per group, groups) form, against the fp32 statement: output and the log2-domain LSE the
+    backward consumes.  Head 0 has peaked rows (the rescale path)."""
+    from gpt4roi_amd import _lib
+    lib = _lib.lib()
+    q, k, v = rnd(B, Tq, H * D, seed=60), rnd(B, Tk, H * D, seed=61), rnd(B, Tk, H * D, seed=62)
+    q[:, :, :D] *= 6.0
+    scale = 1.0 / math.sqrt(D)
+    want = _attn_ref(q, k, v, H, scale, causal)
+    qh = q.float().view(B, Tq, H, D).transpose(1, 2)
+    kh = k.float().view(B, Tk, H, D).transpose(1, 2)
+    sc = qh @ kh.transpose(-1, -2) * scale
+    if causal:
+        i = torch.arange(Tq, device=q.device)[:, None] + (Tk - Tq)
+        sc = sc.masked_fill(torch.arange(Tk, device=q.device)[None, :] > i, float("-inf"))
+    want_lse = torch.logsumexp(sc, -1) * 1.4426950408889634
+    try:
+        for var in ([42, 41, 22] if D == 128 else [24, 42, 41, 44]):
+            lib.g4r_attn_debug_variant(var)
+            lse = torch.full((B, H, Tq), float("nan"), dtype=torch.float32, device=DEV)
+            got = K.flash_attn(q, k, v, H, scale, causal, lse=lse)
+            close(got, want, 2e-2, 2e-2, f"attention_v2 variant {var} {B,H,D,Tq,Tk,causal}")
+            assert float((lse - want_lse).abs().max()) < 2e-2, (var, float((lse - want_lse).abs().max()))
+    finally:
+        lib.g4r_attn_debug_variant(0)
+
+
 def test_flash_attention_strided_qkv_and_peaked_rows():
     # fused qkv buffer [B, T, 3*H*D] (ViT) and one dominant key per row (rescale path)
     B, T, H, D = 1, 130, 4, 64

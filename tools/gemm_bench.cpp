@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 tools/gemm_bench.cpp -Lgpt4roi_amd/lib -lgpt4roi_hip \
 //         -Wl,-rpath,'$ORIGIN/../../gpt4roi_amd/lib' -o tools/probe/gemm_bench
-//   tools/probe/gemm_bench [--rounds R] [--fill u|z|n] case...
+//   tools/probe/gemm_bench [--rounds R] [--fill u|z|n] [--burst N] case...
 //     case = g:M,N,K,tile,splits[,act[,f32[,dbg]]] dense C = A W^T through g4r_gemm_bf16_nt (M = 1: dbg 100+v picks GEMV variant v)
 //            c:B,H,W,C,tile,splits[,dbg]         3x3 conv through g4r_conv3x3_nhwc_bf16 (Cin = Cout = C); dbg 7 = taps-outermost K order
 //
@@ -75,7 +75,7 @@ struct Case {
   uint16_t *A, *Wt, *zeros;
   void* Cout;
   float* ws;
-  std::vector<float> us;
+  std::vector<float> us, us_burst;
   double flops;
   float max_err, max_ref;
   int bad;
@@ -123,11 +123,12 @@ static int launch(Case& c, hipStream_t st) {
 }
 
 int main(int argc, char** argv) {
-  int rounds = 11, fill = 'u';
+  int rounds = 11, fill = 'u', burst = 0;
   std::vector<Case> cases;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--rounds")) { rounds = atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "--fill")) { fill = argv[++i][0]; continue; }
+    if (!strcmp(argv[i], "--burst")) { burst = atoi(argv[++i]); continue; }
     Case c = {};
     c.name = argv[i];
     c.kind = argv[i][0];
@@ -217,9 +218,28 @@ int main(int argc, char** argv) {
       if (r >= 2) c.us.push_back(ms * 1e3f);
     }
   }
+  // second arm: `burst` launches of ONE case back to back inside one event pair (what a captured graph / a GEMM chain
+  // sees: no event round trip between launches), interleaved over the cases per round; median per launch
+  for (int r = 0; r < (burst > 0 ? rounds / 2 + 2 : 0); ++r) {
+    for (auto& c : cases) {
+      CK(hipEventRecord(e0, st));
+      for (int b = 0; b < burst; ++b) launch(c, st);
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (r >= 2) c.us_burst.push_back(ms * 1e3f / burst);
+    }
+  }
   for (auto& c : cases) {
     std::sort(c.us.begin(), c.us.end());
+    std::sort(c.us_burst.begin(), c.us_burst.end());
     const float med = c.us[c.us.size() / 2], mn = c.us.front();
+    if (!c.us_burst.empty()) {
+      const float mb = c.us_burst[c.us_burst.size() / 2];
+      printf("{\"case\": \"%c:%s\", \"burst\": %d, \"burst_median_us\": %.2f, \"burst_TFLOPs\": %.1f}\n", c.kind,
+             c.name.c_str() + 2, burst, mb, c.flops / mb * 1e-6);
+    }
     printf("{\"case\": \"%c:%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"tile\": %d, \"splits\": %d, \"fill\": \"%c\", "
            "\"median_us\": %.2f, \"min_us\": %.2f, \"TFLOPs_median\": %.1f, \"TFLOPs_best\": %.1f, \"checked_bad\": %d, "
            "\"max_err\": %.3e, \"max_ref\": %.3f}\n",
