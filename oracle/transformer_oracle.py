@@ -44,8 +44,8 @@ def attention(q, k, v, heads, scale, causal, emulate=False):
     vh = v.view(B, Tk, heads, D).transpose(1, 2)
     s = (qh @ kh.transpose(-1, -2)) * scale
     if causal:
-        i = torch.arange(Tq)[:, None] + (Tk - Tq)
-        s = s.masked_fill(torch.arange(Tk)[None, :] > i, float("-inf"))
+        i = torch.arange(Tq, device=q.device)[:, None] + (Tk - Tq)
+        s = s.masked_fill(torch.arange(Tk, device=q.device)[None, :] > i, float("-inf"))
     m = s.max(-1, keepdim=True).values
     e = torch.exp(s - m)
     o = (_r(e, emulate) @ vh) / e.sum(-1, keepdim=True)
@@ -123,7 +123,7 @@ def llama_forward(w, inputs_embeds, heads, eps=1e-6, theta=10000.0, kv_cache=Non
     layer with the previously cached positions [B, pos0, C]."""
     B, T, C = inputs_embeds.shape
     D = C // heads
-    cos, sin = rope_tables(pos0 + T, D, theta)
+    cos, sin = (t.to(inputs_embeds.device) for t in rope_tables(pos0 + T, D, theta))   # tests may run this on the GPU
     L = n_layers if n_layers is not None else sum(1 for k in w if k.endswith("input_layernorm.weight"))
     x = _r(inputs_embeds.float(), emulate)
     new_cache = []
