@@ -51,6 +51,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int n_fastest;  // tile order: 1 = consecutive workgroups walk N first (share the A / activation tile)
   int dbg;  // ablation probe (tools only): 1 = skip the loads after the first tile, 2 = skip the MFMAs
+  unsigned a_bytes, w_bytes;   // extent of the A / W operands in bytes when < 2 GiB (buffer descriptors), else 0
 };
 
 constexpr int BK = 64;
@@ -586,6 +587,52 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
 // split-K combine + epilogue: C = act(sum_s ws[s] + bias) + residual
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
   const long total = (long)p.M * p.N;
+  // vector path: 4 consecutive columns per thread, 16-byte loads of every partial (the scalar loops below moved 4 bytes per
+  // lane per load: 10 us average over the 89 reduce launches of a round-2 step).  Same summation order (s = 0, 1, ...) and
+  // the same bias -> activation -> residual -> one rounding sequence: bit-identical to the scalar path.
+  if ((p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.act != 4 || (p.ldc & 1) == 0)) {
+    const int n4 = p.N >> 2;
+    const long quads = (long)p.M * n4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < quads; i += (long)gridDim.x * 256) {
+      const int c4 = (int)(i % n4) * 4;
+      const long m = i / n4;
+      float4v x = {0.f, 0.f, 0.f, 0.f};
+      const float* src = p.ws + m * p.N + c4;
+      for (int s0 = 0; s0 < p.splits; s0 += 4) {      // up to 4 partial loads in flight
+        float4v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (s0 + u < p.splits) v[u] = *reinterpret_cast<const float4v*>(src + (size_t)(s0 + u) * total);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (s0 + u < p.splits) x += v[u];
+      }
+      if (p.act == 4) {
+        const float s0v = bf16lo(pack_bf16x2(x[0] / (1.f + __expf(-x[0])), 0.f));
+        const float s1v = bf16lo(pack_bf16x2(x[2] / (1.f + __expf(-x[2])), 0.f));
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + (c4 >> 1)) =
+            pack_bf16x2(s0v * x[1], s1v * x[3]);
+        continue;
+      }
+      if (p.bias) {
+        const float4v bv = *reinterpret_cast<const float4v*>(p.bias + c4);
+        x += bv;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = apply_act(x[e], p.act);
+      if (p.residual) {
+        const uint2v r = *reinterpret_cast<const uint2v*>(p.residual + (size_t)m * p.ldr + c4);
+        x[0] += bf16lo(r.x); x[1] += bf16hi(r.x); x[2] += bf16lo(r.y); x[3] += bf16hi(r.y);
+      }
+      if (p.out_f32) {
+        *reinterpret_cast<float4v*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + c4) = x;
+      } else {
+        const uint2v w = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
+        *reinterpret_cast<uint2v*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + c4) = w;
+      }
+    }
+    return;
+  }
   if (p.act == 4) {  // SwiGLU over interleaved (gate, up) column pairs: C has N/2 columns (bf16)
     const int half = p.N >> 1;
     const long pairs = (long)p.M * half;
@@ -1113,7 +1160,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 // (Round 3 probe, since removed: issuing a wave's W pieces -- or all four -- at the HEAD of its MFMA phase instead of the
 // end of its read phase, i.e. while the other group is still reading fragments and the address path is idle, changes
 // nothing: 4096^3 1174 / 1141 / 1153 TF/s back to back, conv 192^2 860 / 859 / 739; profiles/r03_gemm_bench_a.jsonl.)
-template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256>
+// one 1 KiB LDS-DMA piece as buffer_load_dwordx4 ... lds: descriptor over `base`, per-lane byte offset, scalar byte offset.
+// (A free __device__ function: the same builtins written inside a lambda of the kernel make hipcc drop the kernel's host
+// handle -- the lambda is implicitly __host__ __device__ and the builtin does not exist on the host.)
+__device__ __forceinline__ void g4r_buffer_piece(const void* base, unsigned bytes, void* lds, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+// BUF (round 3, the default): the pieces are buffer_load_dwordx4 ... lds through a buffer descriptor -- a 32-bit per-lane
+// byte offset computed once + a scalar K / tap offset per tile -- instead of global_load_lds with 64-bit per-lane
+// addresses: one SALU add (M0) and one VMEM instruction per piece, no VALU in the read phase for the dense case.  An
+// out-of-image conv tap is an offset beyond the descriptor's num_records, which the hardware returns as zeros (no zero
+// line, no 64-bit select).  Measured (tools/gemm_bench.cpp, burst arm): 4096^3 1101 -> 1157 TF/s, 8192^2 x 4096
+// 1099 -> 1186, the 144-workgroup qkv launch 767 x 12288 x 4096 106.5 -> 88.1 us.  BUF = false (global_load_lds) remains
+// for operands of 2 GiB and more, which a 32-bit offset cannot span.
+template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   constexpr int NW = 8, NT = 512, BKT = 32, RING = 4;
   constexpr int ROWB = 64, SPR = 4;
@@ -1157,6 +1219,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   unsigned a_ok[NA];
   int a_pitch[NA];
   const bf16_t* b_src[NB];
+  int a_voff[NA], b_voff[NB];              // BUF: byte offsets of this lane's 16 bytes from the matrix base (k = 0)
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int pslot = (j * NW + wave) * 64 + lane;
@@ -1165,6 +1228,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     int gm = m0 + row;
     if (gm > p.M - 1) gm = p.M - 1;
     a_src[j] = p.A + (size_t)gm * p.lda + kslot * 8;
+    a_voff[j] = (gm * p.lda + kslot * 8) * 2;
     a_y[j] = a_x[j] = 0;
     a_h[j] = p.H; a_w[j] = p.Wd;
     if (AMODE == 2) {
@@ -1206,8 +1270,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     int gn = n0 + row;
     if (gn > p.N - 1) gn = p.N - 1;
     b_src[j] = p.W + (size_t)gn * p.ldw + kslot * 8;
+    b_voff[j] = (gn * p.ldw + kslot * 8) * 2;
   }
-  struct TileSrc { long a_off; int k0, dy, dx, tap; };
+  struct TileSrc { long a_off; int k0, dy, dx, tap, shift, soff; };   // shift / soff: the BUF form of a_off (elements / bytes)
   // (channel slice, group, tap) of the NEXT tile to stage: tiles are staged strictly in order, so the walk is a counter
   // (taps fastest, then groups, then 32-channel slices) instead of two runtime divisions per K tile per wave
   int st_ct = 0, st_g = 0, st_tap = 0;
@@ -1222,7 +1287,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     TileSrc ts;
     ts.k0 = t * BKT;
     ts.a_off = ts.k0;
-    ts.dy = ts.dx = ts.tap = 0;
+    ts.dy = ts.dx = ts.tap = ts.shift = 0;
+    ts.soff = ts.k0 * 2;
     if (AMODE >= 1) {
       const int c0 = st_ct * BKT;
       ts.tap = st_tap;
@@ -1230,6 +1296,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
       ts.dx = st_tap - (st_tap / 3) * 3 - 1;
       ts.a_off = (long)st_g * p.a_group_stride + (long)((ts.dy * p.Wd + ts.dx) * p.lda) + c0;
       if (AMODE == 2) ts.a_off = c0;            // the pixel shift depends on the row's own map width: added per piece
+      // buffer form: the (possibly negative) pixel shift goes into the per-lane offset, the scalar offset stays >= 0
+      ts.shift = AMODE == 2 ? 0 : (ts.dy * p.Wd + ts.dx) * p.lda;
+      ts.soff = (int)(((long)st_g * p.a_group_stride + c0) * 2);
       ts.k0 = (st_g * 9 + st_tap) * p.Cin + c0;
       if (++st_tap == 9) {
         st_tap = 0;
@@ -1243,6 +1312,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     char* sa = smem + buf * STAGE_BYTES;
     if (j < NA) {
       if (UNEVEN && (j * NW + wave) * 16 >= BM) return;        // this wave has no j-th A piece (wave-uniform)
+      if (BUF) {
+        int voff = a_voff[j];
+        if (AMODE == 1) voff += ts.shift * 2;
+        if (AMODE == 2) voff += (ts.dy * a_pitch[j] + ts.dx * p.lda) * 2;
+        if (AMODE >= 1 && !((a_ok[j] >> ts.tap) & 1u)) voff = (int)0x80000000;      // beyond num_records: reads as zeros
+        g4r_buffer_piece(p.A, p.a_bytes, sa + (j * NW + wave) * 1024, voff, ts.soff);
+        return;
+      }
       const bf16_t* src = a_src[j] + ts.a_off;
       if (AMODE == 2) src += ts.dy * a_pitch[j] + ts.dx * p.lda;
       if (AMODE >= 1) {
@@ -1251,6 +1328,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sa + (j * NW + wave) * 1024), 16, 0, 0);
     } else {
+      if (BUF) {
+        g4r_buffer_piece(p.W, p.w_bytes, sa + A_BYTES + ((j - NA) * NW + wave) * 1024, b_voff[j - NA], ts.k0 * 2);
+        return;
+      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[j - NA] + ts.k0),
                                        (__attribute__((address_space(3))) void*)(sa + A_BYTES + ((j - NA) * NW + wave) * 1024), 16, 0, 0);
     }
@@ -1622,8 +1703,16 @@ int launch_w4(GemmArgs& p, hipStream_t stream) {
   return G4R_OK;
 }
 
-template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256>
+template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true>
 int launch_pp32(GemmArgs& p, hipStream_t stream) {
+  if (BUF) {
+    // extents for the buffer descriptors: the last byte a clamped row / in-image tap can touch
+    size_t ab = (size_t)p.M * p.lda * 2, wb = (size_t)p.N * p.ldw * 2;
+    if (AMODE == 1) ab = ((size_t)(p.groups - 1) * p.a_group_stride + (size_t)p.M * p.lda) * 2;
+    if (ab >= 0x7fffffffu || wb >= 0x7fffffffu || g_gemm_dbg == 8) return launch_pp32<AMODE, PROBE, BM, BN, false>(p, stream);
+    p.a_bytes = (unsigned)ab;
+    p.w_bytes = (unsigned)wb;
+  }
   {
     const int nt = p.K / 32;
     int splits = p.splits < 1 ? 1 : p.splits;
@@ -1636,7 +1725,7 @@ int launch_pp32(GemmArgs& p, hipStream_t stream) {
   constexpr int TN = BN / 4 / 32, TM = BM / 2 / 32;
   const size_t ring = 4 * (BM + BN) * 32 * 2, epi = 8 * (size_t)EpiLds<TN, ((TN == 2 && TM % 2 == 0) ? 64 : 32)>::WAVE_BYTES;
   const size_t lds = ring > epi ? ring : epi;
-  auto kern = gemm_bf16_pp32_kernel<AMODE, PROBE, BM, BN>;
+  auto kern = gemm_bf16_pp32_kernel<AMODE, PROBE, BM, BN, BUF>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1750,6 +1839,7 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 27: return launch_pp32<AMODE, false, 128, 384>(p, stream);              // 128x384 ring ping-pong (767 x 12288: 192 workgroups)
     case 28: return launch_pp32<AMODE, false, 192, 256>(p, stream);              // 192x256 ring ping-pong (767 x 12288: 4 x 48 = 192 workgroups)
     case 25: return launch_pp32<AMODE, true>(p, stream);                         // same + s_memtime stamps (tools only)
+    case 30: return launch_pp32<AMODE, false, 256, 256, false>(p, stream);       // A/B arm: pieces by global_load_lds (the round-2 form)
     case 23: return launch_pp<AMODE, true>(p, stream);                           // same + s_memtime stamps into ws (tools only)
     default: return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");
   }
