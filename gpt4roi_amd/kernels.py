@@ -275,7 +275,9 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
         # LLaMA down_proj 767x4096x11008 (48 tiles of 256x256): 5 K-slices on the one-wave-per-SIMD kernel, 100.2 us
         # (incl. the reduce) vs 110.4 for the ring ping-pong kernel x 4 slices and 115.3 for the 128x128 ring on the
         # same box (tools/gemm_bench.cpp, profiles/r02_gemm_tiles.md)
-        tile_cfg, splits = 26, 5
+        # round 3: with the pieces as buffer loads the 192x256 ring ping-pong tile x 4 K-slices (64 x 4 = 256 workgroups) is
+        # the best form: 85.0 us vs 88.0 (256x256 x 5) and 87.6 (one wave per SIMD x 5), reduce included
+        tile_cfg, splits = 28, 4
     if tile_cfg is None:
         tile_cfg = pick_tile(M, N, K)
         if splits == 1 and tile_cfg == 4 and K >= 2048 and K % 64 == 0 and M > 1:
