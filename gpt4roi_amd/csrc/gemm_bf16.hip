@@ -1157,24 +1157,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 // BM x BN = 256 x 256 (wave tile 128 x 64) or 128 x 384 (wave tile 64 x 96: 6 x 32 = 192 workgroups for the LLaMA fused-qkv
 // shape 767 x 12288, where 256 x 256 tiles give only 144 of the 256 CUs a tile); both stage 32 KB per K tile = 4 LDS-DMA
 // pieces per wave, so the ring, the waits and the phase structure are identical.
-// (Round 3 probe, since removed: issuing a wave's W pieces -- or all four -- at the HEAD of its MFMA phase instead of the
-// end of its read phase, i.e. while the other group is still reading fragments and the address path is idle, changes
-// nothing: 4096^3 1174 / 1141 / 1153 TF/s back to back, conv 192^2 860 / 859 / 739; profiles/r03_gemm_bench_a.jsonl.)
-// one 1 KiB LDS-DMA piece as buffer_load_dwordx4 ... lds: descriptor over `base`, per-lane byte offset, scalar byte offset.
-// (A free __device__ function: the same builtins written inside a lambda of the kernel make hipcc drop the kernel's host
-// handle -- the lambda is implicitly __host__ __device__ and the builtin does not exist on the host.)
-__device__ __forceinline__ void g4r_buffer_piece(const void* base, unsigned bytes, void* lds, int voff, int soff) {
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
-}
-
-// BUF (round 3, the default): the pieces are buffer_load_dwordx4 ... lds through a buffer descriptor -- a 32-bit per-lane
-// byte offset computed once + a scalar K / tap offset per tile -- instead of global_load_lds with 64-bit per-lane
-// addresses: one SALU add (M0) and one VMEM instruction per piece, no VALU in the read phase for the dense case.  An
-// out-of-image conv tap is an offset beyond the descriptor's num_records, which the hardware returns as zeros (no zero
-// line, no 64-bit select).  Measured (tools/gemm_bench.cpp, burst arm): 4096^3 1101 -> 1157 TF/s, 8192^2 x 4096
-// 1099 -> 1186, the 144-workgroup qkv launch 767 x 12288 x 4096 106.5 -> 88.1 us.  BUF = false (global_load_lds) remains
-// for operands of 2 GiB and more, which a 32-bit offset cannot span.
+// (Round-3 probes, since removed: issuing a wave's W pieces -- or all four -- at the HEAD of its MFMA phase instead of the end
+// of its read phase changes nothing with global_load_lds pieces (4096^3 1174 / 1141 / 1153 TF/s back to back, conv 192^2
+// 860 / 859 / 739; profiles/r03_gemm_bench_a.jsonl) and loses 5 % with the buffer form below (1153 -> 1098; conv 1013 ->
+// 895); a piece after every fourth MFMA is 14x slower.  In-kernel stamps with the buffer form: fragment reads 220-300
+// cycles + 4 pieces 260-270 (the 16 pieces of a group now go out at the vector-memory path's 16 cycles each) + 92 + 85 of
+// wait / barrier = ~670 against 512 + ~60 for the MFMA phase: 1410 cycles per K = 32 tile, was 1481.)
 template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   constexpr int NW = 8, NT = 512, BKT = 32, RING = 4;
