@@ -1163,6 +1163,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 // 895); a piece after every fourth MFMA is 14x slower.  In-kernel stamps with the buffer form: fragment reads 220-300
 // cycles + 4 pieces 260-270 (the 16 pieces of a group now go out at the vector-memory path's 16 cycles each) + 92 + 85 of
 // wait / barrier = ~670 against 512 + ~60 for the MFMA phase: 1410 cycles per K = 32 tile, was 1481.)
+// one 1 KiB LDS-DMA piece as buffer_load_dwordx4 ... lds: descriptor over `base`, per-lane byte offset, scalar byte offset.
+// (A free __device__ function: the same builtins written inside a lambda of the kernel make hipcc drop the kernel's host
+// handle -- the lambda is implicitly __host__ __device__ and the builtin does not exist on the host.)
+__device__ __forceinline__ void g4r_buffer_piece(const void* base, unsigned bytes, void* lds, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+// BUF (round 3, the default): the pieces are buffer_load_dwordx4 ... lds through a buffer descriptor -- a 32-bit per-lane
+// byte offset computed once + a scalar K / tap offset per tile -- instead of global_load_lds with 64-bit per-lane
+// addresses: one SALU add (M0) and one VMEM instruction per piece, no VALU in the read phase for the dense case.  An
+// out-of-image conv tap is an offset beyond the descriptor's num_records, which the hardware returns as zeros (no zero
+// line, no 64-bit select).  Measured (tools/gemm_bench.cpp, burst arm): 4096^3 1101 -> 1157 TF/s, 8192^2 x 4096
+// 1099 -> 1186, the 144-workgroup qkv launch 767 x 12288 x 4096 106.5 -> 88.1 us.  BUF = false (global_load_lds) remains
+// for operands of 2 GiB and more, which a 32-bit offset cannot span.
 template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   constexpr int NW = 8, NT = 512, BKT = 32, RING = 4;
