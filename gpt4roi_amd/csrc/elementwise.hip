@@ -729,38 +729,3 @@ int g4r_image_preprocess_u8_f32(const void* image, int height, int width, long r
 }
 
 }  // extern "C"
-
-// ---------------------------------------------------------------------------------------------
-// Weight prefetch: pull `bytes` at `ptr` into the memory-side cache (256 MiB Infinity Cache) ahead of the kernels that
-// stream them.  The batch-1 ViT tower (M = 577) runs GEMMs of 10-20 us on 64-row tiles whose K loops are paced by the
-// latency of their operand loads; its 600 MB of weights never survive the LLaMA pass in any cache, so every layer starts
-// cold.  One small launch per layer on a side stream (a fork / join in the captured graph) reads the NEXT layer's 25 MB
-// while the current layer computes.  Nothing is written.
-// ---------------------------------------------------------------------------------------------
-namespace {
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint4v* __restrict__ p, size_t n16, unsigned* sink) {
-  uint4v acc = {0u, 0u, 0u, 0u};
-  const size_t stride = (size_t)gridDim.x * 256 * 4;
-  for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride) {
-    uint4v v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t j = i + (size_t)u * 256;
-      v[u] = p[j < n16 ? j : n16 - 1];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc ^= v[u];
-  }
-  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u && sink) *sink = 1u;   // keeps the loads alive; practically never taken
-}
-}  // namespace
-
-extern "C" int g4r_prefetch(const void* ptr, size_t bytes, int workgroups, void* stream) {
-  if (bytes < 16) return G4R_OK;
-  G4R_REQUIRE(ptr && ((uintptr_t)ptr & 15) == 0 && workgroups >= 1, "prefetch: 16-byte aligned pointer, >= 1 workgroup");
-  static unsigned* sink = nullptr;
-  hipLaunchKernelGGL(prefetch_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream,
-                     (const uint4v*)ptr, bytes / 16, sink);
-  G4R_CHECK_LAUNCH("prefetch");
-  return G4R_OK;
-}

@@ -74,7 +74,6 @@ _SIGS = {
                                      c_int, P],
     "g4r_roi_align_mlvl_nhwc_f32": [P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_int, P],
-    "g4r_prefetch": [P, ctypes.c_size_t, c_int, P],
 }
 _bound = {}
 
@@ -480,14 +479,6 @@ def gemv_attn_merge(work, heads, head_dim, w, bias=None, residual=None, out=None
                                          w.stride(0), 1 if out.dtype == torch.float32 else 0, _stream(w),),
             tag="gemv_bf16", flops=2.0 * N * K, nbytes=2.0 * N * K)
     return out
-
-
-def prefetch(t, workgroups=32, stream=None):
-    """Read tensor `t` (contiguous) on `stream` (default: the current one) and discard it: cache warm-up for the kernels that
-    will stream it."""
-    assert t.is_contiguous()
-    st = torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream.cuda_stream
-    _launch("g4r_prefetch", (_p(t), t.numel() * t.element_size(), int(workgroups), st), tag="g4r_prefetch")
 
 
 def layernorm(x, gamma, beta, eps=1e-5, relu_in=False, out=None):

@@ -51,25 +51,13 @@ class ClipVisionTower:
                               g(p + "self_attn.v_proj.weight")], 0).contiguous()
             bqkv = torch.cat([g(p + "self_attn.q_proj.bias"), g(p + "self_attn.k_proj.bias"),
                               g(p + "self_attn.v_proj.bias")], 0).float().contiguous()
-            # the four weight matrices of a layer live in ONE flat buffer: the next layer's weights are pulled into the
-            # memory-side cache by one prefetch launch while this layer computes (forward, `prefetch_weights`)
-            mats = dict(wqkv=wqkv, wo=g(p + "self_attn.out_proj.weight"), w1=g(p + "mlp.fc1.weight"),
-                        w2=g(p + "mlp.fc2.weight"))
-            flat = torch.empty(sum(m.numel() for m in mats.values()), dtype=bf, device=device)
-            off = 0
-            for nm, m in list(mats.items()):
-                v = flat[off:off + m.numel()].view(m.shape)
-                v.copy_(m)
-                mats[nm] = v
-                off += m.numel()
             self.layers.append(dict(
                 ln1=(g(p + "layer_norm1.weight", torch.float32), g(p + "layer_norm1.bias", torch.float32)),
-                bqkv=bqkv, bo=g(p + "self_attn.out_proj.bias").float().contiguous(),
+                wqkv=wqkv, bqkv=bqkv,
+                wo=g(p + "self_attn.out_proj.weight"), bo=g(p + "self_attn.out_proj.bias").float().contiguous(),
                 ln2=(g(p + "layer_norm2.weight", torch.float32), g(p + "layer_norm2.bias", torch.float32)),
-                b1=g(p + "mlp.fc1.bias").float().contiguous(), b2=g(p + "mlp.fc2.bias").float().contiguous(),
-                flat=flat, **mats))
-        self.prefetch_weights = True     # batch-1 tower: every layer starts with cold weights otherwise
-        self._side = None
+                w1=g(p + "mlp.fc1.weight"), b1=g(p + "mlp.fc1.bias").float().contiguous(),
+                w2=g(p + "mlp.fc2.weight"), b2=g(p + "mlp.fc2.bias").float().contiguous()))
 
     @torch.no_grad()
     def forward(self, images):
@@ -89,15 +77,7 @@ class ClipVisionTower:
         if 0 in wanted:
             keep[0] = x.view(B, T, C)
         scale = D ** -0.5
-        pf = self.prefetch_weights and B * T <= 2048 and x.is_cuda     # large batches hide the latency themselves
-        if pf and self._side is None:
-            self._side = torch.cuda.Stream(device=x.device)
-        cur = torch.cuda.current_stream(x.device) if pf else None
         for i, L in enumerate(self.layers):
-            if pf and i + 1 < len(self.layers):
-                # fork: the side stream reads layer i + 1's 25 MB while this layer's seven launches run; join at its end
-                self._side.wait_stream(cur)
-                K.prefetch(self.layers[i + 1]['flat'], workgroups=32, stream=self._side)
             h = K.layernorm(x, L['ln1'][0], L['ln1'][1], self.eps)
             qkv = K.gemm(h, L['wqkv'], bias=L['bqkv']).view(B, T, 3 * C)
             a = K.flash_attn(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], H, scale, False)
@@ -105,8 +85,6 @@ class ClipVisionTower:
             h = K.layernorm(x, L['ln2'][0], L['ln2'][1], self.eps)
             f = K.gemm(h, L['w1'], bias=L['b1'], act='quick_gelu')
             x = K.gemm(f, L['w2'], bias=L['b2'], residual=x)
-            if pf and i + 1 < len(self.layers):
-                cur.wait_stream(self._side)
             if i + 1 in wanted:
                 keep[i + 1] = x.view(B, T, C)
         return keep

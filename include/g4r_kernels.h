@@ -116,11 +116,6 @@ int g4r_attn_decode_bf16(const void* Q, const void* qkv, const float* cos_tab, c
 int g4r_gemv_attn_merge_bf16(const float* partials, int splits, int head_dim, const void* W, void* C, const float* bias,
                              const void* residual, int N, int K, int ldw, int out_f32, void* stream);
 
-/* Reads `bytes` at `ptr` (16-byte aligned) and discards them: pulls the NEXT layer's weights into the memory-side cache
- * from a side stream while the current layer computes (the batch-1 CLIP tower, spi_llava.py:66-67, starts every layer
- * cold).  `workgroups` x 256 threads. */
-int g4r_prefetch(const void* ptr, size_t bytes, int workgroups, void* stream);
-
 /* LayerNorm over the last dim (CLIP pre_layrnorm / layer_norm1,2; pos_embedd LayerNorms
  * gpt4roi/models/layers.py:260-267).  gamma/beta fp32.  relu_in: apply ReLU to x first. */
 int g4r_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, int rows, int cols,
