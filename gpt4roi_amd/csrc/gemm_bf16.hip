@@ -1178,7 +1178,17 @@ __device__ __forceinline__ void g4r_buffer_piece(const void* base, unsigned byte
 // line, no 64-bit select).  Measured (tools/gemm_bench.cpp, burst arm): 4096^3 1101 -> 1157 TF/s, 8192^2 x 4096
 // 1099 -> 1186, the 144-workgroup qkv launch 767 x 12288 x 4096 106.5 -> 88.1 us.  BUF = false (global_load_lds) remains
 // for operands of 2 GiB and more, which a 32-bit offset cannot span.
-template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true>
+// SCHED 1 (round 3): ONE barrier per K tile and the two groups' loop bodies rotated against each other,
+//        interval k:   group 0:  read(k)  pieces(k+3)  MFMA(k)            | vmcnt, barrier
+//                      group 1:  MFMA(k-1)  read(k)  pieces(k+3)          | vmcnt, barrier
+// instead of the two barriers per tile of SCHED 0, which lock the groups into "one reads while the other multiplies"
+// slots of max(read phase, MFMA phase) = ~705 cycles each (1410 per tile; the read phase, ~670, is the longer one).
+// Here a wave's tile costs read + MFMA = ~1180 of its own time and the other wave of its SIMD has its MFMAs exactly
+// where this one reads (group 1 multiplies tile k-1 during group 0's read of tile k, group 0 multiplies tile k during
+// group 1's read of it).  Prefetch distance 2 in the ring of 4: the pieces of tile k+2 overwrite the buffer of tile k-2,
+// whose last reads were two barriers ago for BOTH groups; tile k's pieces were waited for (counted vmcnt, leaving only
+// tile k+1's in flight) before barrier k by every wave.
+template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true, int SCHED = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   constexpr int NW = 8, NT = 512, BKT = 32, RING = 4;
   constexpr int ROWB = 64, SPR = 4;
@@ -1388,7 +1398,48 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   };
 
   const int nt = t_end - t_begin;
-  if (nt > 0) {
+  if (SCHED == 1 && nt > 0) {
+#pragma unroll
+    for (int t = 0; t < RING - 1; ++t)
+      if (t < nt) stage(t_begin + t, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto tail_wait = [&](int i) {          // end of interval i: tile i+1 has landed (tiles i+2, i+3 may still be in flight)
+      if (i + RING - 1 < nt) {
+        if (UNEVEN && wave >= 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    if (grp == 0) {
+      for (int i = 0; i < nt; ++i) {
+        const int buf = i & (RING - 1);
+        ldchunk(buf, 0);
+        ldchunk(buf, 1);
+        ldchunk(buf, 2);
+        if (i + RING - 1 < nt) stage(t_begin + i + RING - 1, (i + RING - 1) & (RING - 1));
+        mma();
+        tail_wait(i);
+        G4R_PP_BARRIER();
+      }
+      G4R_PP_BARRIER();                    // group 1's last interval (its MFMAs of the last tile)
+    } else {
+      for (int i = 0; i <= nt; ++i) {
+        if (i > 0) mma();                  // tile i-1: fragments read in the previous interval
+        if (i < nt) {
+          const int buf = i & (RING - 1);
+          ldchunk(buf, 0);
+          ldchunk(buf, 1);
+          ldchunk(buf, 2);
+          if (i + RING - 1 < nt) stage(t_begin + i + RING - 1, (i + RING - 1) & (RING - 1));
+        }
+        tail_wait(i);
+        G4R_PP_BARRIER();
+      }
+    }
+  }
+  if (SCHED == 0 && nt > 0) {
 #pragma unroll
     for (int t = 0; t < RING - 1; ++t)
       if (t < nt) stage(t_begin + t, t);
@@ -1706,13 +1757,13 @@ int launch_w4(GemmArgs& p, hipStream_t stream) {
   return G4R_OK;
 }
 
-template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true>
+template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true, int SCHED = 0>
 int launch_pp32(GemmArgs& p, hipStream_t stream) {
   if (BUF) {
     // extents for the buffer descriptors: the last byte a clamped row / in-image tap can touch
     size_t ab = (size_t)p.M * p.lda * 2, wb = (size_t)p.N * p.ldw * 2;
     if (AMODE == 1) ab = ((size_t)(p.groups - 1) * p.a_group_stride + (size_t)p.M * p.lda) * 2;
-    if (ab >= 0x7fffffffu || wb >= 0x7fffffffu || g_gemm_dbg == 8) return launch_pp32<AMODE, PROBE, BM, BN, false>(p, stream);
+    if (ab >= 0x7fffffffu || wb >= 0x7fffffffu || g_gemm_dbg == 8) return launch_pp32<AMODE, PROBE, BM, BN, false, SCHED>(p, stream);
     p.a_bytes = (unsigned)ab;
     p.w_bytes = (unsigned)wb;
   }
@@ -1728,7 +1779,7 @@ int launch_pp32(GemmArgs& p, hipStream_t stream) {
   constexpr int TN = BN / 4 / 32, TM = BM / 2 / 32;
   const size_t ring = 4 * (BM + BN) * 32 * 2, epi = 8 * (size_t)EpiLds<TN, ((TN == 2 && TM % 2 == 0) ? 64 : 32)>::WAVE_BYTES;
   const size_t lds = ring > epi ? ring : epi;
-  auto kern = gemm_bf16_pp32_kernel<AMODE, PROBE, BM, BN, BUF>;
+  auto kern = gemm_bf16_pp32_kernel<AMODE, PROBE, BM, BN, BUF, SCHED>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1838,11 +1889,17 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 15: return launch_tile<128, 64, 2, 2, AMODE, true, 4>(p, stream);   // 96 KB ring of 4
     case 26: return launch_w4<AMODE>(p, stream);                                 // 256x256, 4 waves x (128x128): one wave per SIMD, K 32 ring of 4
     case 22: return launch_pp<AMODE>(p, stream);                                 // 256x256 ping-pong (4 barriers / K tile)
-    case 24: return launch_pp32<AMODE>(p, stream);                               // 256x256 ping-pong, K 32 ring of 4
+    case 24:                                                                     // 256x256 ping-pong, K 32 ring of 4
+      // the implicit-GEMM convs take the rotated single-barrier schedule (192^2 conv 693 -> 668 us, tools/gemm_bench.cpp
+      // tile 31); the dense GEMMs lose 8-12 % on it (4096^3 1172 -> 1076 TF/s) and keep the two-barrier form
+      if constexpr (AMODE >= 1) return launch_pp32<AMODE, false, 256, 256, true, 1>(p, stream);
+      else return launch_pp32<AMODE>(p, stream);
     case 27: return launch_pp32<AMODE, false, 128, 384>(p, stream);              // 128x384 ring ping-pong (767 x 12288: 192 workgroups)
     case 28: return launch_pp32<AMODE, false, 192, 256>(p, stream);              // 192x256 ring ping-pong (767 x 12288: 4 x 48 = 192 workgroups)
     case 25: return launch_pp32<AMODE, true>(p, stream);                         // same + s_memtime stamps (tools only)
     case 30: return launch_pp32<AMODE, false, 256, 256, false>(p, stream);       // A/B arm: pieces by global_load_lds (the round-2 form)
+    case 31: return launch_pp32<AMODE, false, 256, 256, true, 1>(p, stream);     // rotated single-barrier schedule (A/B arm for dense)
+    case 33: return launch_pp32<AMODE, false, 256, 256, true, 0>(p, stream);     // two-barrier schedule (A/B arm for the convs)
     case 23: return launch_pp<AMODE, true>(p, stream);                           // same + s_memtime stamps into ws (tools only)
     default: return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");
   }
@@ -1975,7 +2032,7 @@ int g4r_conv3x3_mlvl_nhwc_bf16(const void* X, const void* W, void* Y, const floa
   p.lda = Cin; p.ldw = p.K; p.ldc = Cout;
   p.act = act; p.H = level_h[0]; p.Wd = level_w[0]; p.Cin = Cin; p.groups = 1;
   p.n_fastest = 1; p.dbg = g_gemm_dbg; p.splits = 1;
-  return launch_pp32<2>(p, (hipStream_t)stream);
+  return launch_pp32<2, false, 256, 256, true, 1>(p, (hipStream_t)stream);
 }
 
 }  // extern "C"
