@@ -146,27 +146,57 @@ __device__ __forceinline__ F8 sample_src(const ShuffleSrc& s, int b, int y, int 
   return o;
 }
 
-__global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShuffleSrc own, ShuffleSrc top, ShuffleSrc down,
-                                                           bf16_t* __restrict__ out, int B, int C) {
+__device__ __forceinline__ void shuffle_item(const ShuffleSrc& own, const ShuffleSrc& top, const ShuffleSrc& down,
+                                             bf16_t* __restrict__ out, int C, long i) {
   const int H = own.H, W = own.W;
   const int nvec = C >> 3;
   const int R = C >> 1, S = C >> 2;
-  const long total = (long)B * H * W * nvec;
+  const int v = (int)(i % nvec);
+  const long pix = i / nvec;
+  const int x = (int)(pix % W);
+  const int y = (int)((pix / W) % H);
+  const int b = (int)(pix / ((long)W * H));
+  const int c = v * 8;
+  F8 o;
+  if (c < R)
+    o = sample_src(own, b, y, x, H, W, C, c);
+  else if (c < R + S)
+    o = sample_src(top, b, y, x, H, W, C, c + S);   // top[:, R+S + (c-R)]
+  else
+    o = sample_src(down, b, y, x, H, W, C, c - S);  // down[:, R + (c-R-S)]
+  st8(out + (size_t)pix * C + c, o);
+}
+
+__global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShuffleSrc own, ShuffleSrc top, ShuffleSrc down,
+                                                           bf16_t* __restrict__ out, int B, int C) {
+  const long total = (long)B * own.H * own.W * (C >> 3);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+    shuffle_item(own, top, down, out, C, i);
+}
+
+// The same assembly for EVERY target level of a fuse round in one launch (the four per-level launches of round 2 cost
+// 4-57 us each: the small levels are pure launch latency, 0.42 ms per image over the five rounds).
+#define G4R_SHUFFLE_MAX_LEVELS 4
+struct ShuffleLevels {
+  ShuffleSrc own[G4R_SHUFFLE_MAX_LEVELS], top[G4R_SHUFFLE_MAX_LEVELS], down[G4R_SHUFFLE_MAX_LEVELS];
+  bf16_t* out[G4R_SHUFFLE_MAX_LEVELS];
+  long end[G4R_SHUFFLE_MAX_LEVELS];   // running item count: level l owns items [end[l-1], end[l])
+  int n;
+};
+__global__ __launch_bounds__(256) void fuse_shuffle_mlvl_kernel(ShuffleLevels a, int C) {
+  const long total = a.end[a.n - 1];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int v = (int)(i % nvec);
-    const long pix = i / nvec;
-    const int x = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    const int b = (int)(pix / ((long)W * H));
-    const int c = v * 8;
-    F8 o;
-    if (c < R)
-      o = sample_src(own, b, y, x, H, W, C, c);
-    else if (c < R + S)
-      o = sample_src(top, b, y, x, H, W, C, c + S);   // top[:, R+S + (c-R)]
-    else
-      o = sample_src(down, b, y, x, H, W, C, c - S);  // down[:, R + (c-R-S)]
-    st8(out + (size_t)pix * C + c, o);
+    int l = 0;
+#pragma unroll
+    for (int q = 0; q < G4R_SHUFFLE_MAX_LEVELS - 1; ++q)
+      if (q + 1 < a.n && i >= a.end[q]) l = q + 1;
+    const long base = l == 0 ? 0 : a.end[l - 1];
+    // the level is almost always wave-uniform (a boundary falls inside at most one wave per level): switch on it so
+    // that the ShuffleSrc fields are read from scalar registers
+    if (l == 0) shuffle_item(a.own[0], a.top[0], a.down[0], a.out[0], C, i - base);
+    else if (l == 1) shuffle_item(a.own[1], a.top[1], a.down[1], a.out[1], C, i - base);
+    else if (l == 2) shuffle_item(a.own[2], a.top[2], a.down[2], a.out[2], C, i - base);
+    else shuffle_item(a.own[3], a.top[3], a.down[3], a.out[3], C, i - base);
   }
 }
 
@@ -584,6 +614,36 @@ int g4r_upsample_coord_nhwc_bf16(const void* in, void* out, int B, int Hin, int 
   hipLaunchKernelGGL(upsample_coord_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)in, (bf16_t*)out, B, Hin, Win, in_batch_stride, ldin, H, W, C, Cpad);
   G4R_CHECK_LAUNCH("upsample_coord");
+  return G4R_OK;
+}
+
+/* n_levels (<= 4) target levels in one launch.  For target level t: own = maps[t], top = maps[top_idx[t]], down =
+ * maps[down_idx[t]] (layers.py:108-112: the neighbour, or the level itself at the ends of the pyramid); maps[l] is NHWC
+ * [B, heights[l], widths[l], C] bf16 with the optional deferred GroupNorm+ReLU affine affines[l] ([B, 2, C] fp32 or null;
+ * `affines` itself may be null); outs[t] receives the assembled conv input of level t. */
+int g4r_fuse_shuffle_mlvl_nhwc_bf16(const void* const* maps, const float* const* affines, const int* heights,
+                                    const int* widths, const int* top_idx, const int* down_idx, void* const* outs,
+                                    int n_levels, int B, int C, void* stream) {
+  G4R_REQUIRE(n_levels >= 1 && n_levels <= G4R_SHUFFLE_MAX_LEVELS && B > 0, "fuse_shuffle_mlvl: 1..4 levels");
+  G4R_REQUIRE(C % 32 == 0, "fuse_shuffle_mlvl: C must be a multiple of 32");
+  G4R_REQUIRE(maps && heights && widths && top_idx && down_idx && outs, "fuse_shuffle_mlvl: null pointer");
+  ShuffleLevels a;
+  long run = 0;
+  for (int t = 0; t < G4R_SHUFFLE_MAX_LEVELS; ++t) {
+    const int l = t < n_levels ? t : 0;
+    const int tp = top_idx[l], dn = down_idx[l];
+    G4R_REQUIRE(tp >= 0 && tp < n_levels && dn >= 0 && dn < n_levels && maps[l] && outs[l] && heights[l] > 0 &&
+                    widths[l] > 0, "fuse_shuffle_mlvl: bad level");
+    a.own[t] = ShuffleSrc{(const bf16_t*)maps[l], affines ? affines[l] : nullptr, heights[l], widths[l]};
+    a.top[t] = ShuffleSrc{(const bf16_t*)maps[tp], affines ? affines[tp] : nullptr, heights[tp], widths[tp]};
+    a.down[t] = ShuffleSrc{(const bf16_t*)maps[dn], affines ? affines[dn] : nullptr, heights[dn], widths[dn]};
+    a.out[t] = (bf16_t*)outs[l];
+    if (t < n_levels) run += (long)B * heights[l] * widths[l] * (C / 8);
+    a.end[t] = run;
+  }
+  a.n = n_levels;
+  hipLaunchKernelGGL(fuse_shuffle_mlvl_kernel, dim3(grid_for(run)), dim3(256), 0, (hipStream_t)stream, a, C);
+  G4R_CHECK_LAUNCH("fuse_shuffle_mlvl");
   return G4R_OK;
 }
 

@@ -52,6 +52,7 @@ struct GemmArgs {
   int n_fastest;  // tile order: 1 = consecutive workgroups walk N first (share the A / activation tile)
   int dbg;  // ablation probe (tools only): 1 = skip the loads after the first tile, 2 = skip the MFMAs
   unsigned a_bytes, w_bytes;   // extent of the A / W operands in bytes when < 2 GiB (buffer descriptors), else 0
+  int defer_reduce;            // split-K: leave the fp32 partials in ws, the CALLER's next kernel combines them
 };
 
 constexpr int BK = 64;
@@ -1747,7 +1748,7 @@ int launch_w4(GemmArgs& p, hipStream_t stream) {
   }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(256), lds, stream, p);
   G4R_CHECK_LAUNCH("gemm_bf16_w4");
-  if (p.splits > 1) {
+  if (p.splits > 1 && !p.defer_reduce) {
     long total = (long)p.M * p.N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -1789,7 +1790,7 @@ int launch_pp32(GemmArgs& p, hipStream_t stream) {
   }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(512), lds, stream, p);
   G4R_CHECK_LAUNCH("gemm_bf16_pp32");
-  if (p.splits > 1) {
+  if (p.splits > 1 && !p.defer_reduce) {
     long total = (long)p.M * p.N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -1822,7 +1823,7 @@ int launch_pp(GemmArgs& p, hipStream_t stream) {
   }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(512), lds, stream, p);
   G4R_CHECK_LAUNCH("gemm_bf16_pp");
-  if (p.splits > 1) {
+  if (p.splits > 1 && !p.defer_reduce) {
     long total = (long)p.M * p.N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -1856,7 +1857,7 @@ int launch_tile(GemmArgs& p, hipStream_t stream) {
   dim3 grid(p.tiles_m * p.tiles_n, p.splits);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
   G4R_CHECK_LAUNCH("gemm_bf16_nt");
-  if (p.splits > 1) {
+  if (p.splits > 1 && !p.defer_reduce) {
     long total = (long)p.M * p.N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -1914,6 +1915,27 @@ extern "C" {
 void g4r_gemm_debug_mode(int mode) { g_gemm_dbg = mode; }
 
 // See include/g4r_kernels.h for the contract.
+// C = A W^T as `*splits_out` fp32 K-slice partials [slice][M][N] in `workspace` (>= splits * M * N floats), WITHOUT the reduce
+// launch: the consumer combines them (g4r_rmsnorm_splitk_bf16: the reduce of the LLaMA down_proj folded into the next
+// RMSNorm).  splits >= 2; the number of slices actually written (<= splits) is returned through splits_out.
+int g4r_gemm_bf16_nt_partials(const void* A, const void* W, float* workspace, int M, int N, int K, int lda, int ldw,
+                              int splits, int tile_cfg, int* splits_out, void* stream) {
+  G4R_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0, "gemm_partials: K must be a positive multiple of 64");
+  G4R_REQUIRE(A && W && workspace && splits_out, "gemm_partials: null pointer");
+  G4R_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && splits >= 2, "gemm_partials: 16-byte rows, splits >= 2");
+  GemmArgs p = {};
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = workspace; p.ws = workspace;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = N; p.ldr = 0;
+  p.act = 0; p.out_f32 = 1; p.dbg = g_gemm_dbg;
+  p.n_fastest = (long)M * 1 > (long)N * 2;
+  p.splits = splits;
+  p.defer_reduce = 1;
+  const int rc = launch_gemm<0>(p, tile_cfg, (hipStream_t)stream);
+  *splits_out = p.splits;
+  G4R_REQUIRE(rc != G4R_OK || p.splits >= 2, "gemm_partials: the tile's K slices collapsed to one (K too short for `splits`)");
+  return rc;
+}
+
 int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, const void* residual,
                      float* workspace, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                      int act, int out_f32, int splits, int tile_cfg, void* stream) {

@@ -74,6 +74,10 @@ _SIGS = {
                                      c_int, P],
     "g4r_roi_align_mlvl_nhwc_f32": [P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_int, P],
+    "g4r_groupnorm_affine_mlvl_nhwc_bf16": [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_float, P],
+    "g4r_gemm_bf16_nt_partials": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
+    "g4r_rmsnorm_splitk_bf16": [P, c_int, P, c_long, P, c_long, P, P, c_long, c_int, c_int, c_float, P],
+    "g4r_fuse_shuffle_mlvl_nhwc_bf16": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
 }
 _bound = {}
 
@@ -246,6 +250,44 @@ def wave_split(M, N, K):
     return n_main
 
 
+def long_k_plan(M, N, K):
+    """(tile_cfg, K slices) for the long-K / few-tiles shape of the LLaMA down_proj (767 x 4096 x 11008: 48 tiles of 256 x 256),
+    or None: the 192 x 256 ring ping-pong tile x 4 K-slices = 64 x 4 = 256 workgroups."""
+    if K >= 8192 and K % 64 == 0 and (-(-M // 256) * 256) <= 1.1 * M and 32 <= -(-M // 256) * -(-N // 256) <= 64:
+        return 28, 4
+    return None
+
+
+def gemm_partials(a, w, splits, tile_cfg):
+    """a [M,K] @ w[N,K]^T as fp32 K-slice partials [n_slices, M, N] WITHOUT the reduce launch (the consumer combines them:
+    rmsnorm_splitk).  Returns (partials, n_slices)."""
+    _bf16(a, w)
+    M, K = a.shape
+    N = w.size(0)
+    assert a.stride(1) == 1 and w.stride(1) == 1 and splits >= 2
+    ws = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
+    n = c_int(0)
+    _launch("g4r_gemm_bf16_nt_partials", (_p(a), _p(w), _p(ws), M, N, K, a.stride(0), w.stride(0), int(splits), int(tile_cfg),
+                                          ctypes.byref(n), _stream(a),),
+            tag=f"gemm_bf16_nt<{TILE_NAMES.get(tile_cfg, tile_cfg)}>+splitk", flops=2.0 * M * N * K,
+            nbytes=2.0 * (M * K + N * K) + 4.0 * splits * M * N)
+    return ws, n.value
+
+
+def rmsnorm_splitk(partials, n_slices, residual, gamma, eps=1e-6):
+    """x = bf16(sum of the first n_slices partials + residual); y = rmsnorm(x; gamma) -> (x, y): the split-K reduce of a
+    residual GEMM and the RMSNorm that follows it in one pass (bit-identical to gemm(..., residual=) + rmsnorm())."""
+    _f32(partials, gamma)
+    _bf16(residual)
+    _, M, N = partials.shape
+    x = torch.empty((M, N), dtype=torch.bfloat16, device=partials.device)
+    y = torch.empty_like(x)
+    _launch("g4r_rmsnorm_splitk_bf16", (_p(partials), int(n_slices), _p(residual), residual.stride(0) if residual is not None else 0,
+                                        _p(x), x.stride(0), _p(gamma), _p(y), y.stride(0), M, N, float(eps), _stream(x),),
+            tag="g4r_rmsnorm_bf16")
+    return x, y
+
+
 def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfloat16, splits=1,
          tile_cfg=None, workspace=None):
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + residual.  a may be row-strided (last dim dense)."""
@@ -270,14 +312,13 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
             gemm(a, w[n_main:], bias[n_main:] if bias is not None else None,
                  residual[:, n_main:] if residual is not None else None, act, out[:, o_main:])
             return out
-    if tile_cfg is None and splits == 1 and K >= 8192 and K % 64 == 0 and (-(-M // 256) * 256) <= 1.1 * M \
-            and 32 <= -(-M // 256) * -(-N // 256) <= 64:
+    if tile_cfg is None and splits == 1 and long_k_plan(M, N, K) is not None:
         # LLaMA down_proj 767x4096x11008 (48 tiles of 256x256): 5 K-slices on the one-wave-per-SIMD kernel, 100.2 us
         # (incl. the reduce) vs 110.4 for the ring ping-pong kernel x 4 slices and 115.3 for the 128x128 ring on the
         # same box (tools/gemm_bench.cpp, profiles/r02_gemm_tiles.md)
         # round 3: with the pieces as buffer loads the 192x256 ring ping-pong tile x 4 K-slices (64 x 4 = 256 workgroups) is
         # the best form: 85.0 us vs 88.0 (256x256 x 5) and 87.6 (one wave per SIMD x 5), reduce included
-        tile_cfg, splits = 28, 4
+        tile_cfg, splits = long_k_plan(M, N, K)
     if tile_cfg is None:
         tile_cfg = pick_tile(M, N, K)
         if splits == 1 and tile_cfg == 4 and K >= 2048 and K % 64 == 0 and M > 1:
@@ -517,6 +558,52 @@ def groupnorm_affine(x, gamma, beta, groups, eps=1e-5):
         _p(x), _p(gamma), _p(beta), _p(acc), _p(ss), B, H * W, C, groups,
                                                float(eps), _stream(x),))
     return ss
+
+
+def groupnorm_affine_mlvl(z, gamma, beta, groups, eps=1e-5):
+    """z: MlvlMaps (bf16) -> list over levels of scale_shift [B, 2, C] fp32 (views of one [L, B, 2, C] tensor): the deferred
+    GN of every level of a fuse round in two launches (bit-identical per level to groupnorm_affine)."""
+    assert isinstance(z, MlvlMaps)
+    _bf16(z.flat)
+    _f32(gamma, beta)
+    L, B, C = len(z.sizes), z.B, z.C
+    acc = torch.empty((L, B, 256, groups, 2), dtype=torch.float32, device=z.flat.device)
+    ss = torch.empty((L, B, 2, C), dtype=torch.float32, device=z.flat.device)
+    hw = (c_int * L)(*[h * w for h, w in z.sizes])
+    _launch("g4r_groupnorm_affine_mlvl_nhwc_bf16", (_p(z.flat), _p(gamma), _p(beta), _p(acc), _p(ss), L, ctypes.cast(hw, P), B, C,
+                                                    groups, float(eps), _stream(z.flat),),
+            tag="g4r_groupnorm_affine_nhwc_bf16")
+    return [ss[l] for l in range(L)]
+
+
+def fuse_shuffle_mlvl(maps, affs, lvl_list, out):
+    """Every target level of a fuse round in one launch.  maps: list over levels of NHWC bf16 maps; affs: list of [B,2,C] fp32
+    or None per level; lvl_list: [(target, top, down)] covering every level once (layers.py:108-112); out: MlvlMaps."""
+    assert isinstance(out, MlvlMaps)
+    _bf16(*maps)
+    L = len(maps)
+    B, _, _, C = maps[0].shape
+    top, down = [0] * L, [0] * L
+    for tar, tp, dn in lvl_list:
+        top[tar], down[tar] = tp, dn
+    for m in maps:
+        assert m.is_contiguous() and m.size(0) == B and m.size(3) == C
+    has_aff = any(a is not None for a in affs)
+    if has_aff:
+        _f32(*[a for a in affs if a is not None])
+    PA = c_void_p * L
+    ma = PA(*[m.data_ptr() for m in maps])
+    aa = PA(*[(a.data_ptr() if a is not None else None) for a in affs]) if has_aff else None
+    oa = PA(*[o.data_ptr() for o in out.levels])
+    ha = (c_int * L)(*[m.size(1) for m in maps])
+    wa = (c_int * L)(*[m.size(2) for m in maps])
+    ta = (c_int * L)(*top)
+    da = (c_int * L)(*down)
+    _launch("g4r_fuse_shuffle_mlvl_nhwc_bf16", (ctypes.cast(ma, P), ctypes.cast(aa, P) if aa is not None else None,
+                                                ctypes.cast(ha, P), ctypes.cast(wa, P), ctypes.cast(ta, P), ctypes.cast(da, P),
+                                                ctypes.cast(oa, P), L, B, C, _stream(maps[0]),),
+            tag="g4r_fuse_shuffle_nhwc_bf16")
+    return out
 
 
 def upsample_coord(tokens, hin, win, H, W, cpad):

@@ -124,11 +124,10 @@ class MLVLFuseModule(nn.Module):
         for rnd in range(self.num_fuse):
             g, bt, groups, eps = r['gn'][rnd]
             inp = K.MlvlMaps(B, hw, self.embed_dims, dev)
-            for tar, top, dow in self.fuse_lvl_list:
-                K.fuse_shuffle(maps[tar], maps[top], maps[dow], affs[tar], affs[top], affs[dow], out=inp.levels[tar])
+            K.fuse_shuffle_mlvl(maps, affs, self.fuse_lvl_list, inp)       # every level's conv input: one launch
             z = K.conv3x3_mlvl(inp, r['w_f'][rnd])
             maps = z.levels
-            affs = [K.groupnorm_affine(m, g, bt, groups, eps) for m in maps]
+            affs = K.groupnorm_affine_mlvl(z, g, bt, groups, eps)          # every level's deferred GN: two launches
         return maps, affs
 
 
@@ -153,12 +152,10 @@ class MLVLFuseModule(nn.Module):
         for rnd in range(self.num_fuse):
             g, bt, groups, eps = r['gn'][rnd]
             inp = K.MlvlMaps(B, hw, self.embed_dims, dev)          # all levels in one buffer: one conv launch per round
-            for tar, top, dow in self.fuse_lvl_list:
-                K.fuse_shuffle(all_maps[-1][tar], all_maps[-1][top], all_maps[-1][dow], all_affs[-1][tar],
-                               all_affs[-1][top], all_affs[-1][dow], out=inp.levels[tar])
-            new_maps = K.conv3x3_mlvl(inp, r['w_f'][rnd]).levels
-            all_maps.append(new_maps)
-            all_affs.append([K.groupnorm_affine(m, g, bt, groups, eps) for m in new_maps])
+            K.fuse_shuffle_mlvl(all_maps[-1], all_affs[-1], self.fuse_lvl_list, inp)
+            z = K.conv3x3_mlvl(inp, r['w_f'][rnd])
+            all_maps.append(z.levels)
+            all_affs.append(K.groupnorm_affine_mlvl(z, g, bt, groups, eps))
         return all_maps[-1], all_affs[-1], dict(xs=xs, maps=all_maps, affs=all_affs, B=B)
 
     def backward(self, ctx, d_y, on_grad=None):

@@ -79,8 +79,10 @@ class LlamaDecoder:
         x = x.contiguous()
         scale = 1.0 / math.sqrt(D)
         q = torch.empty((B, T, C), dtype=torch.bfloat16, device=x.device)
+        h = None                                             # the next RMSNorm output when the down_proj reduce produced it
         for li, L in enumerate(self.layers):
-            h = K.rmsnorm(x, L['n1'], self.eps)
+            if h is None:
+                h = K.rmsnorm(x, L['n1'], self.eps)
             qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
             if T == 1:                                       # decode step: RoPE + cache append + split-key attention,
                 a = torch.empty_like(q)                      # one launch for the B sequences of the batch
@@ -93,9 +95,18 @@ class LlamaDecoder:
             x = K.gemm(a.view(B * T, C), L['wo'], residual=x)
             h = K.rmsnorm(x, L['n2'], self.eps)
             f = K.gemm(h, L['wgu'], act="swiglu")            # gate|up GEMM with the SiLU*up epilogue
-            x = K.gemm(f, L['wd'], residual=x)
+            plan = K.long_k_plan(B * T, C, f.size(1))
+            if plan is not None:
+                # prefill: the down_proj runs as K slices; their reduce (+ residual) and the NEXT RMSNorm (the next layer's
+                # input_layernorm, or the final norm) are one pass over the row instead of two launches
+                part, ns = K.gemm_partials(f, L['wd'], plan[1], plan[0])
+                g_next = self.layers[li + 1]['n1'] if li + 1 < len(self.layers) else self.norm
+                x, h = K.rmsnorm_splitk(part, ns, x, g_next, self.eps)
+            else:
+                x = K.gemm(f, L['wd'], residual=x)
+                h = None
         self.pos = pos0 + T
-        xn = K.rmsnorm(x, self.norm, self.eps).view(B, T, C)
+        xn = (h if h is not None else K.rmsnorm(x, self.norm, self.eps)).view(B, T, C)
         if return_hidden:
             return xn
         if not all_logits:

@@ -116,6 +116,24 @@ int g4r_attn_decode_bf16(const void* Q, const void* qkv, const float* cos_tab, c
 int g4r_gemv_attn_merge_bf16(const float* partials, int splits, int head_dim, const void* W, void* C, const float* bias,
                              const void* residual, int N, int K, int ldw, int out_f32, void* stream);
 
+/* The per-level launches of a fuse round merged (round 3): GroupNorm affines of every level of a stacked pyramid in two
+ * launches, and the "_single_shuffle" input assembly of every target level in one (gpt4roi/models/layers.py:152-195, the
+ * same arithmetic as g4r_groupnorm_affine_nhwc_bf16 / g4r_fuse_shuffle_nhwc_bf16 per level). */
+int g4r_groupnorm_affine_mlvl_nhwc_bf16(const void* x, const float* gamma, const float* beta, float* partial,
+                                        float* scale_shift, int n_levels, const int* level_hw, int B, int C, int G,
+                                        float eps, void* stream);
+int g4r_fuse_shuffle_mlvl_nhwc_bf16(const void* const* maps, const float* const* affines, const int* heights,
+                                    const int* widths, const int* top_idx, const int* down_idx, void* const* outs,
+                                    int n_levels, int B, int C, void* stream);
+
+/* Split-K GEMM with the reduce deferred to the consumer, and the consumer: the K-slice reduce of the LLaMA down_proj
+ * (+ residual) folded into the following RMSNorm (HF LlamaDecoderLayer: x = x + mlp(...); h = input_layernorm(x) of the next
+ * layer, spi_llava.py:198-205).  Bit-identical to g4r_gemm_bf16_nt(splits) + g4r_rmsnorm_bf16. */
+int g4r_gemm_bf16_nt_partials(const void* A, const void* W, float* workspace, int M, int N, int K, int lda, int ldw,
+                              int splits, int tile_cfg, int* splits_out, void* stream);
+int g4r_rmsnorm_splitk_bf16(const float* partials, int splits, const void* residual, long ldr, void* x_out, long ldxo,
+                            const float* gamma, void* y, long ldy, int rows, int cols, float eps, void* stream);
+
 /* LayerNorm over the last dim (CLIP pre_layrnorm / layer_norm1,2; pos_embedd LayerNorms
  * gpt4roi/models/layers.py:260-267).  gamma/beta fp32.  relu_in: apply ReLU to x first. */
 int g4r_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, int rows, int cols,

@@ -760,3 +760,47 @@ def test_attn_decode_batch_of_sequences_in_one_launch(B, H, D, kv):
     got = K.attn_decode(None, k2, v2, H, scale, wB, kv_len_dev=pos, qkv=qkv, cos=cos, sin=sin)
     assert got.shape == (B, C) and torch.equal(got, want)
     assert torch.equal(k2, k1) and torch.equal(v2, v1) and int(wB.cnt.abs().sum()) == 0
+
+
+def test_merged_level_shuffle_and_groupnorm_equal_the_per_level_launches():
+    """Round 3: the fuse round's per-level launches merged (g4r_fuse_shuffle_mlvl_nhwc_bf16, g4r_groupnorm_affine_mlvl_nhwc_bf16)
+    must be BIT-identical to the per-level kernels they replace (gpt4roi/models/layers.py:152-195): a batch of two images,
+    four levels, with and without the deferred GroupNorm affines."""
+    B, C, sizes = 2, 256, [(24, 24), (12, 12), (6, 6), (3, 3)]
+    g = torch.Generator().manual_seed(77)
+    maps = [torch.randn(B, h, w, C, generator=g).to(torch.bfloat16).to(DEV) for h, w in sizes]
+    affs = [torch.stack([1 + 0.2 * torch.randn(B, C, generator=g), 0.3 * torch.randn(B, C, generator=g)], 1).float().to(DEV).contiguous()
+            for _ in sizes]
+    lvl_list = [(l, min(l + 1, 3), max(l - 1, 0)) for l in range(4)]
+    for use_aff in (False, True):
+        a = affs if use_aff else [None] * 4
+        out = K.MlvlMaps(B, sizes, C, DEV)
+        K.fuse_shuffle_mlvl(maps, a, lvl_list, out)
+        for tar, top, dow in lvl_list:
+            want = K.fuse_shuffle(maps[tar], maps[top], maps[dow], a[tar], a[top], a[dow])
+            assert torch.equal(out.levels[tar], want), (use_aff, tar)
+    z = K.MlvlMaps(B, sizes, C, DEV)
+    for lv, m in zip(z.levels, maps):
+        lv.copy_(m)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    got = K.groupnorm_affine_mlvl(z, gamma, beta, 16, 1e-5)
+    for l in range(4):
+        want = K.groupnorm_affine(z.levels[l], gamma, beta, 16, 1e-5)
+        assert torch.equal(got[l], want), l
+
+
+def test_split_k_reduce_folded_into_the_next_rmsnorm_is_bit_identical():
+    """g4r_gemm_bf16_nt_partials + g4r_rmsnorm_splitk_bf16 (the LLaMA down_proj's K-slice reduce + residual folded into the
+    following RMSNorm) against the two-launch form it replaces: same residual stream, same normalised rows, bit for bit."""
+    M, N, K_ = 767, 4096, 11008
+    a, w = rnd(M, K_, scale=0.5, seed=400), rnd(N, K_, scale=0.02, seed=401)
+    res = rnd(M, N, seed=402)
+    gamma = (1 + 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(403))).to(DEV)
+    tile, splits = K.long_k_plan(M, N, K_)
+    x_want = K.gemm(a, w, residual=res)                       # production dispatch: the same tile x K slices + reduce launch
+    h_want = K.rmsnorm(x_want, gamma, 1e-6)
+    part, ns = K.gemm_partials(a, w, splits, tile)
+    assert ns == splits and part.shape == (splits, M, N)
+    x_got, h_got = K.rmsnorm_splitk(part, ns, res, gamma, 1e-6)
+    assert torch.equal(x_got, x_want) and torch.equal(h_got, h_want)
