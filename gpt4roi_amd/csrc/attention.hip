@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeAttnArgs p) {
     unpack8(*reinterpret_cast<const uint4v*>(p.qkv + own), a);
     unpack8(*reinterpret_cast<const uint4v*>(p.qkv + oth), b);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = second ? a[e] * c[e] + b[e] * sn[e] : a[e] * c[e] - b[e] * sn[e];
+    for (int e = 0; e < 8; ++e) o[e] = second ? __builtin_fmaf(a[e], c[e], b[e] * sn[e]) : __builtin_fmaf(a[e], c[e], -(b[e] * sn[e]));
     {
       const uint4v qr = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
       unpack8(qr, q);
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeAttnArgs p) {
     unpack8(*reinterpret_cast<const uint4v*>(p.qkv + HD + own), a);
     unpack8(*reinterpret_cast<const uint4v*>(p.qkv + HD + oth), b);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = second ? a[e] * c[e] + b[e] * sn[e] : a[e] * c[e] - b[e] * sn[e];
+    for (int e = 0; e < 8; ++e) o[e] = second ? __builtin_fmaf(a[e], c[e], b[e] * sn[e]) : __builtin_fmaf(a[e], c[e], -(b[e] * sn[e]));
     k_new = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
     v_new = *reinterpret_cast<const uint4v*>(p.qkv + 2 * HD + own);
     if (s == 0 && wave == 0 && ks == 0) {                      // append the new row for the tokens to come

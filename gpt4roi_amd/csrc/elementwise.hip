@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(const bf16_t* __restrict_
       F8 o1, o2;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        o1.v[k] = a.v[k] * c.v[k] - b.v[k] * s.v[k];
-        o2.v[k] = b.v[k] * c.v[k] + a.v[k] * s.v[k];
+        o1.v[k] = __builtin_fmaf(a.v[k], c.v[k], -(b.v[k] * s.v[k]));   // pinned: the fused epilogue form
+        o2.v[k] = __builtin_fmaf(b.v[k], c.v[k], a.v[k] * s.v[k]);      // (g4r_gemm_qkv_rope_bf16) rounds alike
       }
       st8(qout + (size_t)t * HD + off, o1);
       st8(qout + (size_t)t * HD + off + half, o2);
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(const bf16_t* __restrict_
       F8 o1, o2;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        o1.v[k] = a.v[k] * c.v[k] - b.v[k] * s.v[k];
-        o2.v[k] = b.v[k] * c.v[k] + a.v[k] * s.v[k];
+        o1.v[k] = __builtin_fmaf(a.v[k], c.v[k], -(b.v[k] * s.v[k]));   // pinned: the fused epilogue form
+        o2.v[k] = __builtin_fmaf(b.v[k], c.v[k], a.v[k] * s.v[k]);      // (g4r_gemm_qkv_rope_bf16) rounds alike
       }
       st8(kcache + (size_t)pos * HD + off, o1);
       st8(kcache + (size_t)pos * HD + off + half, o2);

@@ -53,6 +53,16 @@ struct GemmArgs {
   int dbg;  // ablation probe (tools only): 1 = skip the loads after the first tile, 2 = skip the MFMAs
   unsigned a_bytes, w_bytes;   // extent of the A / W operands in bytes when < 2 GiB (buffer descriptors), else 0
   int defer_reduce;            // split-K: leave the fp32 partials in ws, the CALLER's next kernel combines them
+  // act == 5 (fused q|k|v projection of a LLaMA layer, ring ping-pong tiles only): RoPE and the KV-cache append happen in
+  // the epilogue -- what g4r_rope_qkv_bf16 did in a launch of its own.  Columns [0, HD) -> rotated q rows of rope_q,
+  // [HD, 2 HD) -> rotated k into the cache rows pos0 + t, [2 HD, 3 HD) -> v into the cache.  Row m = b * rope_T + t.
+  bf16_t* rope_q;              // [M][HD]
+  bf16_t* rope_k;              // cache base of this layer: + b * rope_kbatch + (pos0 + t) * rope_krow
+  bf16_t* rope_v;
+  const float* rope_cos;       // [maxT][D/2] fp32
+  const float* rope_sin;
+  long rope_krow, rope_kbatch;
+  int rope_T, rope_pos0, rope_HD;
 };
 
 constexpr int BK = 64;
@@ -249,6 +259,56 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, float16v (&
           *reinterpret_cast<float4v*>(wave_lds + (i2 * 32 + wr) * E::RS + (j * 32 + q * 8 + wh * 4) * 4) =
               float4v{c[q * 4], c[q * 4 + 1], c[q * 4 + 2], c[q * 4 + 3]};
         }
+    if (p.act == 5) {
+      // ---- fused RoPE + KV-cache append (head_dim 128: this wave's 64 columns are HALF a head, the other half sits in
+      //      the LDS slice of the neighbouring wave, same rows, same lane -> column map) ----
+      if constexpr (E::WTN == 64) {
+        __syncthreads();                                     // every wave has parked this pass
+        const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const char* mate_lds = wave_lds + ((wave_id & 1) ? -E::WAVE_BYTES : E::WAVE_BYTES);
+        const int part = n_wave0 / p.rope_HD;                // 0 q, 1 k, 2 v (a 256-column tile never straddles: HD % 256 == 0)
+        const bool second = (wave_id & 1) != 0;              // this wave holds d in [64, 128) of its head
+#pragma unroll 2
+        for (int it = 0; it < NIT; ++it) {
+          const int r = it * RPI + rrow;
+          if (rrow >= RPI || r >= PR) continue;
+          const int m = m_wave0 + half * PR + r;
+          if (m >= p.M) continue;
+          const float4v a0 = *reinterpret_cast<const float4v*>(wave_lds + r * E::RS + rcol * 4);
+          const float4v a1 = *reinterpret_cast<const float4v*>(wave_lds + r * E::RS + rcol * 4 + 16);
+          float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          const int b = m / p.rope_T, t = m - b * p.rope_T;
+          const int pos = p.rope_pos0 + t;
+          const int col = n_wave0 + rcol - part * p.rope_HD;   // column inside q / k / v
+          // the unfused path stored the projection as bf16 before rotating it: keep that rounding point
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = bf16_to_f32(f32_to_bf16(v[k]));
+          if (part < 2) {
+            const float4v m0 = *reinterpret_cast<const float4v*>(mate_lds + r * E::RS + rcol * 4);
+            const float4v m1 = *reinterpret_cast<const float4v*>(mate_lds + r * E::RS + rcol * 4 + 16);
+            float u[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            const float* cp = p.rope_cos + (size_t)pos * 64 + rcol;
+            const float* sp = p.rope_sin + (size_t)pos * 64 + rcol;
+            const float4v c0 = *reinterpret_cast<const float4v*>(cp), c1 = *reinterpret_cast<const float4v*>(cp + 4);
+            const float4v s0 = *reinterpret_cast<const float4v*>(sp), s1 = *reinterpret_cast<const float4v*>(sp + 4);
+            const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float mate = bf16_to_f32(f32_to_bf16(u[k]));
+              // rotate_half: first half  a' = a cos - b sin ; second half  b' = b cos + a sin   (a = x[d], b = x[d + 64])
+              v[k] = second ? __builtin_fmaf(v[k], cs[k], mate * sn[k]) : __builtin_fmaf(v[k], cs[k], -(mate * sn[k]));
+            }
+          }
+          bf16_t* dst = part == 0 ? p.rope_q + (size_t)m * p.rope_HD + col
+                                  : (part == 1 ? p.rope_k : p.rope_v) + (size_t)b * p.rope_kbatch + (size_t)pos * p.rope_krow + col;
+          *reinterpret_cast<uint4v*>(dst) = uint4v{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                   pack_bf16x2(v[6], v[7])};
+        }
+        __syncthreads();                                     // the neighbour is done with this wave's slice
+      }
+      continue;
+    }
     // ---- read back row-major and finish ----
 #pragma unroll 2
     for (int it = 0; it < NIT; ++it) {
@@ -1936,13 +1996,39 @@ int g4r_gemm_bf16_nt_partials(const void* A, const void* W, float* workspace, in
   return rc;
 }
 
+// The fused q|k|v projection of a LLaMA layer with RoPE and the KV-cache append in the GEMM epilogue: A [B*T, K] hidden rows,
+// W [3*heads*128, K] (q | k | v rows).  q_out [B*T, heads*128] receives the rotated queries; k_cache / v_cache (this layer's
+// cache, rows `cache_row` elements apart, sequences `cache_batch` apart) receive the rotated keys / the values at rows
+// pos0 + t.  cos / sin: [max_pos][64] fp32.  Same arithmetic and rounding points as g4r_gemm_bf16_nt + g4r_rope_qkv_bf16
+// (the projection is rounded to bf16, rotated in fp32, rounded once more).  tile_cfg: 24 or 28 (0 = 28).
+int g4r_gemm_qkv_rope_bf16(const void* A, const void* W, int B, int T, int K, int lda, int ldw, int heads, int head_dim,
+                           void* q_out, void* k_cache, void* v_cache, long cache_row, long cache_batch,
+                           const float* cos_tab, const float* sin_tab, int pos0, int tile_cfg, void* stream) {
+  G4R_REQUIRE(B > 0 && T > 0 && K > 0 && K % BK == 0 && heads > 0, "gemm_qkv_rope: bad shape");
+  G4R_REQUIRE(head_dim == 128 && (heads * head_dim) % 256 == 0, "gemm_qkv_rope: head_dim 128, heads * 128 a multiple of 256");
+  G4R_REQUIRE(A && W && q_out && k_cache && v_cache && cos_tab && sin_tab, "gemm_qkv_rope: null pointer");
+  G4R_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (cache_row % 8) == 0 && (cache_batch % 8) == 0, "gemm_qkv_rope: 16-byte rows");
+  if (tile_cfg == 0) tile_cfg = 28;
+  G4R_REQUIRE(tile_cfg == 24 || tile_cfg == 28, "gemm_qkv_rope: ring ping-pong tiles only (24 / 28)");
+  GemmArgs p = {};
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = q_out;
+  p.M = B * T; p.N = 3 * heads * head_dim; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = heads * head_dim;
+  p.act = 5; p.dbg = g_gemm_dbg;
+  p.n_fastest = 0;
+  p.splits = 1;
+  p.rope_q = (bf16_t*)q_out; p.rope_k = (bf16_t*)k_cache; p.rope_v = (bf16_t*)v_cache;
+  p.rope_cos = cos_tab; p.rope_sin = sin_tab; p.rope_krow = cache_row; p.rope_kbatch = cache_batch;
+  p.rope_T = T; p.rope_pos0 = pos0; p.rope_HD = heads * head_dim;
+  return launch_gemm<0>(p, tile_cfg, (hipStream_t)stream);
+}
+
 int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, const void* residual,
                      float* workspace, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                      int act, int out_f32, int splits, int tile_cfg, void* stream) {
   G4R_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative shape");
   if (M == 0 || N == 0) return G4R_OK;
   G4R_REQUIRE(A && W && C, "gemm: null pointer");
-  G4R_REQUIRE(act >= 0 && act <= 4, "gemm: act must be 0..4");
+  G4R_REQUIRE(act >= 0 && act <= 4, "gemm: act must be 0..4 (5 = the fused RoPE epilogue: g4r_gemm_qkv_rope_bf16)");
   G4R_REQUIRE(act != 4 || (N % 4 == 0 && ldc % 2 == 0 && !residual && !bias && !out_f32 && K % BK == 0),
               "gemm: swiglu epilogue needs N % 4 == 0, bf16 output, no bias/residual");
   if (M == 1 && K % 8 == 0 && (ldw % 8) == 0 && splits == 1 && K >= 512 && K <= G4R_GEMV_MAX_K && (act != 4 || N % 4 == 0)) {

@@ -76,6 +76,8 @@ _SIGS = {
                                     c_int, P],
     "g4r_groupnorm_affine_mlvl_nhwc_bf16": [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_float, P],
     "g4r_gemm_bf16_nt_partials": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
+    "g4r_gemm_qkv_rope_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_long, c_long, P, P, c_int,
+                               c_int, P],
     "g4r_rmsnorm_splitk_bf16": [P, c_int, P, c_long, P, c_long, P, P, c_long, c_int, c_int, c_float, P],
     "g4r_fuse_shuffle_mlvl_nhwc_bf16": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
 }
@@ -286,6 +288,29 @@ def rmsnorm_splitk(partials, n_slices, residual, gamma, eps=1e-6):
                                         _p(x), x.stride(0), _p(gamma), _p(y), y.stride(0), M, N, float(eps), _stream(x),),
             tag="g4r_rmsnorm_bf16")
     return x, y
+
+
+def gemm_qkv_rope(h, wqkv, B, T, heads, head_dim, q_out, k_cache, v_cache, cos, sin, pos0, tile_cfg=None):
+    """The fused q|k|v projection of a LLaMA layer with RoPE and the KV-cache append in the GEMM epilogue: h [B*T, K] ->
+    q_out [B, T, heads*D] (rotated), k_cache / v_cache [B, maxT, heads*D] rows pos0 .. pos0+T-1 (rotated keys, values).
+    Same rounding points as gemm() + rope_qkv().  Returns None when the shape is not one the ring ping-pong tiles serve
+    (the caller then runs the two launches)."""
+    _bf16(h, wqkv, q_out, k_cache, v_cache)
+    _f32(cos, sin)
+    M, Kd = h.shape
+    HD = heads * head_dim
+    if tile_cfg is None:
+        tile_cfg = pick_tile(M, 3 * HD, Kd)
+    if head_dim != 128 or HD % 256 != 0 or tile_cfg not in (24, 28) or M != B * T:
+        return None
+    assert wqkv.shape == (3 * HD, Kd) and q_out.is_contiguous() and cos.size(1) == 64 and cos.is_contiguous() and sin.is_contiguous()
+    assert k_cache.stride(2) == 1 and v_cache.stride() == k_cache.stride() and pos0 + T <= k_cache.size(1)
+    _launch("g4r_gemm_qkv_rope_bf16", (_p(h), _p(wqkv), B, T, Kd, h.stride(0), wqkv.stride(0), heads, head_dim, _p(q_out),
+                                       _p(k_cache), _p(v_cache), k_cache.stride(1), k_cache.stride(0), _p(cos), _p(sin), int(pos0),
+                                       int(tile_cfg), _stream(h),),
+            tag=f"gemm_bf16_nt<{TILE_NAMES.get(tile_cfg, tile_cfg)}>", flops=2.0 * M * 3 * HD * Kd,
+            nbytes=2.0 * (M * Kd + 3 * HD * Kd + 3 * M * HD))
+    return q_out
 
 
 def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfloat16, splits=1,

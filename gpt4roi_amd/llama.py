@@ -83,14 +83,18 @@ class LlamaDecoder:
         for li, L in enumerate(self.layers):
             if h is None:
                 h = K.rmsnorm(x, L['n1'], self.eps)
-            qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
             if T == 1:                                       # decode step: RoPE + cache append + split-key attention,
+                qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
                 a = torch.empty_like(q)                      # one launch for the B sequences of the batch
                 K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, self._attn_work(B), kv_len=pos0 + 1,
                               out=a.view(B, C), qkv=qkv.view(B, 3 * C), cos=self.cos, sin=self.sin)
             else:
-                for b in range(B):
-                    K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, pos0)
+                # prefill: RoPE and the cache append ride in the projection's epilogue (one launch instead of 1 + B)
+                if K.gemm_qkv_rope(h, L['wqkv'], B, T, H, D, q, self.kc[li, :B], self.vc[li, :B], self.cos, self.sin,
+                                   pos0) is None:
+                    qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
+                    for b in range(B):
+                        K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, pos0)
                 a = K.flash_attn(q, self.kc[li, :B, :pos0 + T], self.vc[li, :B, :pos0 + T], H, scale, True)
             x = K.gemm(a.view(B * T, C), L['wo'], residual=x)
             h = K.rmsnorm(x, L['n2'], self.eps)

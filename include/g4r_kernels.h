@@ -134,6 +134,12 @@ int g4r_gemm_bf16_nt_partials(const void* A, const void* W, float* workspace, in
 int g4r_rmsnorm_splitk_bf16(const float* partials, int splits, const void* residual, long ldr, void* x_out, long ldxo,
                             const float* gamma, void* y, long ldy, int rows, int cols, float eps, void* stream);
 
+/* Fused q|k|v projection + RoPE + KV-cache append (HF LlamaAttention.forward: q/k/v_proj, apply_rotary_pos_emb, cache update;
+ * the arithmetic spi_llava.py:198-205 delegates to).  See csrc/gemm_bf16.hip for the argument contract. */
+int g4r_gemm_qkv_rope_bf16(const void* A, const void* W, int B, int T, int K, int lda, int ldw, int heads, int head_dim,
+                           void* q_out, void* k_cache, void* v_cache, long cache_row, long cache_batch,
+                           const float* cos_tab, const float* sin_tab, int pos0, int tile_cfg, void* stream);
+
 /* LayerNorm over the last dim (CLIP pre_layrnorm / layer_norm1,2; pos_embedd LayerNorms
  * gpt4roi/models/layers.py:260-267).  gamma/beta fp32.  relu_in: apply ReLU to x first. */
 int g4r_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, int rows, int cols,

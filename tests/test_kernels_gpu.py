@@ -804,3 +804,26 @@ def test_split_k_reduce_folded_into_the_next_rmsnorm_is_bit_identical():
     assert ns == splits and part.shape == (splits, M, N)
     x_got, h_got = K.rmsnorm_splitk(part, ns, res, gamma, 1e-6)
     assert torch.equal(x_got, x_want) and torch.equal(h_got, h_want)
+
+
+@pytest.mark.parametrize("B,T,pos0,tile", [(1, 767, 0, 28), (1, 767, 0, 24), (2, 300, 17, 28)])
+def test_qkv_projection_with_rope_and_cache_append_in_the_epilogue(B, T, pos0, tile):
+    """g4r_gemm_qkv_rope_bf16 against the two launches it replaces (g4r_gemm_bf16_nt + g4r_rope_qkv_bf16 per sequence): the
+    rotated queries and the appended cache rows must be bit-identical, cache rows outside [pos0, pos0 + T) untouched."""
+    heads, D, Kd, maxT = 32, 128, 4096, 1024
+    HD = heads * D
+    h = rnd(B * T, Kd, seed=500)
+    w = rnd(3 * HD, Kd, scale=1 / 64, seed=501)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    ang = torch.arange(maxT, dtype=torch.float32)[:, None] * inv[None, :]
+    cos, sin = ang.cos().to(DEV).contiguous(), ang.sin().to(DEV).contiguous()
+    qkv = K.gemm(h, w, tile_cfg=tile).view(B, T, 3 * HD)
+    q_want = torch.empty((B, T, HD), dtype=torch.bfloat16, device=DEV)
+    kc_want = torch.full((B, maxT, HD), 7.0, dtype=torch.bfloat16, device=DEV)
+    vc_want = torch.full((B, maxT, HD), 7.0, dtype=torch.bfloat16, device=DEV)
+    for b in range(B):
+        K.rope_qkv(qkv[b], cos, sin, q_want[b], kc_want[b], vc_want[b], heads, D, pos0)
+    q_got = torch.empty_like(q_want)
+    kc_got, vc_got = torch.full_like(kc_want, 7.0), torch.full_like(vc_want, 7.0)
+    assert K.gemm_qkv_rope(h, w, B, T, heads, D, q_got, kc_got, vc_got, cos, sin, pos0, tile_cfg=tile) is not None
+    assert torch.equal(q_got, q_want) and torch.equal(kc_got, kc_want) and torch.equal(vc_got, vc_want)
