@@ -327,22 +327,40 @@ def main():
                     "launches_per_step": a["calls"], "avg_launch_us": round(1e3 * a["ms"] / a["calls"], 2),
                     "share_of_step": round(a["ms"] / tot, 3)}
         # HBM traffic, effective clock and MFMA-pipe utilisation per launch from the committed counter passes (collected
-        # separately, as rocprofv3 requires: profiles/r02_pmc_report.json, written by tools/pmc_report.py from
+        # separately, as rocprofv3 requires: the newest profiles/rNN_pmc_report.json, written by tools/pmc_report.py from
         # `rocprofv3 --pmc ... --kernel-trace -- python bench.py --steps 2 --streams 1 --no-graph`); null when no
         # profile is committed for this kernel
-        pmc = {}
+        pmc, pmc_file = {}, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_report.json")))
+            import glob
+            import re as _re
+            cands = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_report.json"))
+            # newest round first (r03 > r02), then the most recently written file of that round
+            cands.sort(key=lambda f: (int(_re.search(r"r(\d+)_", os.path.basename(f)).group(1)), os.path.getmtime(f)))
+            if cands:
+                pmc_file = os.path.relpath(cands[-1], ROOT)
+                pmc = json.load(open(cands[-1]))
         except Exception:
             pass
-        PMC_NAME = {"gemm_bf16_nt<256x256pp32>": "void gemm_bf16_pp32_kernel<0, false, 256, 256>",
-                    "conv3x3_igemm<256x256pp32>": "void gemm_bf16_pp32_kernel<2, false, 256, 256>",   # the one-launch-per-round form
-                    "gemm_bf16_nt<128x128w8s4>": "void gemm_bf16_nt_kernel<128, 128, 2, 4, 0, true, 4, 64, 0>",
-                    "roi_align_mlvl_nhwc": "void roi_align_mlvl_nhwc_kernel<unsigned short, true>"}
-        rec = pmc.get(PMC_NAME.get(dom, ""), {})
+        # kernel names as the counter pass records them, matched by prefix (template tails change between rounds)
+        PMC_PREFIX = {"gemm_bf16_nt<256x256pp32>": "void gemm_bf16_pp32_kernel<0, false, 256, 256",
+                      "gemm_bf16_nt<192x256pp32>": "void gemm_bf16_pp32_kernel<0, false, 192, 256",
+                      "conv3x3_igemm<256x256pp32>": "void gemm_bf16_pp32_kernel<2, false, 256, 256",   # the one-launch-per-round form
+                      "gemm_bf16_nt<128x128w8s4>": "void gemm_bf16_nt_kernel<128, 128, 2, 4, 0, true, 4, 64, 0>",
+                      "roi_align_mlvl_nhwc": "void roi_align_mlvl_nhwc_kernel<unsigned short, true>"}
+
+        def pmc_rec(tag):
+            pre = PMC_PREFIX.get(tag)
+            if not pre:
+                return {}
+            for k, v in pmc.items():
+                if k.startswith(pre):
+                    return v
+            return {}
+        rec = pmc_rec(dom)
         if "hbm_read_bytes" in rec:
             roofline["traffic"] = rec["hbm_read_bytes"] + rec.get("hbm_write_bytes", 0)
-            roofline["traffic_source"] = ("profiles/r02_pmc_report.json (PMC FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 per launch, "
+            roofline["traffic_source"] = (f"{pmc_file} (PMC FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 per launch, "
                                           "the gfx950 correction of MI355X_MICROARCH.md)")
             roofline["algorithmic_bytes_per_launch"] = int(a["bytes"] / a["calls"])
         if rec.get("mfma_util") is not None:
@@ -350,7 +368,7 @@ def main():
                                "source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), clock = GRBM_GUI_ACTIVE / 8 / duration"}
         cv = agg.get("conv3x3_igemm<256x256pp32>")
         if cv and cv.get("flops"):
-            crec = pmc.get(PMC_NAME["conv3x3_igemm<256x256pp32>"], {})
+            crec = pmc_rec("conv3x3_igemm<256x256pp32>")
             tf = cv["flops"] / (cv["ms"] * 1e-3) / 1e12
             roofline["conv"] = {"kernel": "conv3x3_igemm<256x256pp32>", "bound": "mfma", "achieved": round(tf, 1),
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
@@ -365,7 +383,7 @@ def main():
                                      "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(ra["bytes"]),
                                      "avg_launch_us": round(1e3 * ra["ms"] / ra["calls"], 2),
                                      "traffic": (lambda r: r["hbm_read_bytes"] + r.get("hbm_write_bytes", 0) if "hbm_read_bytes" in r
-                                                 else None)(pmc.get(PMC_NAME["roi_align_mlvl_nhwc"], {}))}
+                                                 else None)(pmc_rec("roi_align_mlvl_nhwc"))}
 
     decode = None
     if rank == 0 and args.decode_tokens > 0:

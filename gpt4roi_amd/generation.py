@@ -21,45 +21,55 @@ class StoppingCriteria:
 
 
 class KeywordsStoppingCriteria(StoppingCriteria):
-    """llava/model/utils.py:26-46, same constructor and the same two-stage test: a single-token keyword id at the end of
-    the sequence, else the keyword string inside the decoded new tokens.  As in the reference, the FIRST call only
-    records the prompt length (HF calls the criteria once per generated token)."""
+    """Stops generation at a keyword -- the contract of llava/model/utils.py:26-46, which gpt4roi/app.py:289-300 builds with
+    `['###']`: constructor `(keywords, tokenizer, input_ids)`; callable `(output_ids, scores) -> bool`.
+
+    Behaviour kept from the reference, because callers (and HF's per-token calling convention) rely on it:
+      * the first call arms the criterion (it only remembers how long the prompt was) and answers False;
+      * afterwards a hit is EITHER the newest token being the id of a keyword that tokenises to exactly one id, OR the
+        keyword text occurring in the decoded continuation (special tokens skipped);
+      * only row 0 of the batch is looked at (the app is batch 1).
+    Incremental use: `LlamaDecoder.decode_graph` shows it every prefix exactly once."""
 
     def __init__(self, keywords, tokenizer, input_ids):
-        self.keywords = keywords
-        self.keyword_ids = [tokenizer(keyword).input_ids for keyword in keywords]
-        self.keyword_ids = [keyword_id[0] for keyword_id in self.keyword_ids
-                            if type(keyword_id) is list and len(keyword_id) == 1]
+        self.keywords = list(keywords)
         self.tokenizer = tokenizer
-        self.start_len = None
         self.input_ids = input_ids
+        self.start_len = None                       # armed by the first call
+        single_token_ids = []
+        for word in self.keywords:
+            ids = tokenizer(word).input_ids
+            if isinstance(ids, list) and len(ids) == 1:
+                single_token_ids.append(ids[0])
+        self.keyword_ids = single_token_ids
+
+    def _prompt_length(self):
+        return self.input_ids.shape[1]
 
     def __call__(self, output_ids, scores=None, **kwargs) -> bool:
         if self.start_len is None:
-            self.start_len = self.input_ids.shape[1]
-        else:
-            for keyword_id in self.keyword_ids:
-                if output_ids[0, -1] == keyword_id:
-                    return True
-            outputs = self.tokenizer.batch_decode(output_ids[:, self.start_len:], skip_special_tokens=True)[0]
-            for keyword in self.keywords:
-                if keyword in outputs:
-                    return True
-        return False
+            self.start_len = self._prompt_length()
+            return False
+        newest = output_ids[0, -1]
+        if any(newest == kid for kid in self.keyword_ids):
+            return True
+        continuation = self.tokenizer.batch_decode(output_ids[:, self.start_len:], skip_special_tokens=True)[0]
+        return any(word in continuation for word in self.keywords)
 
 
 def prepare_inputs_for_generation(input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kwargs):
-    """llava/model/llava.py:263-283: after step 0 only the last token is fed; `images` rides along every step (the
-    vision branch is skipped for single-token calls, spi_llava.py:47-48)."""
+    """What HF `generate` asks the model for before every step (contract of llava/model/llava.py:263-283):
+    with a KV cache only the newest token id is fed; `inputs_embeds` may replace the ids on the cache-less first step only;
+    `images` is forwarded on every step (the vision branch ignores single-token calls, spi_llava.py:47-48)."""
+    first_step = past_key_values is None
     if past_key_values:
         input_ids = input_ids[:, -1:]
-    if inputs_embeds is not None and past_key_values is None:
-        model_inputs = {"inputs_embeds": inputs_embeds}
-    else:
-        model_inputs = {"input_ids": input_ids}
-    model_inputs.update({"past_key_values": past_key_values, "use_cache": kwargs.get("use_cache"),
-                         "attention_mask": attention_mask, "images": kwargs.get("images", None)})
-    return model_inputs
+    feed = {"inputs_embeds": inputs_embeds} if (inputs_embeds is not None and first_step) else {"input_ids": input_ids}
+    feed["past_key_values"] = past_key_values
+    feed["use_cache"] = kwargs.get("use_cache")
+    feed["attention_mask"] = attention_mask
+    feed["images"] = kwargs.get("images", None)
+    return feed
 
 
 @dataclass
