@@ -175,28 +175,75 @@ __global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShuffleSrc own, Shuff
 }
 
 // The same assembly for EVERY target level of a fuse round in one launch (the four per-level launches of round 2 cost
-// 4-57 us each: the small levels are pure launch latency, 0.42 ms per image over the five rounds).
+// 4-57 us each: the small levels are pure launch latency).  Restructured for the memory system as well: a workgroup owns
+// a run of pixels of one (level, image) and a thread ONE 8-channel vector for all of them, so its source (own / top /
+// down) and the deferred GroupNorm affine of its channels are fixed -- loaded once instead of per corner per pixel (the
+// first merged version spent 10 of its 12.5 loads per item on the affine table and ran at 2.3 TB/s) -- and the pixel
+// coordinates cost one division per pixel instead of three per item.  Same expressions per element: bit-identical.
 #define G4R_SHUFFLE_MAX_LEVELS 4
 struct ShuffleLevels {
   ShuffleSrc own[G4R_SHUFFLE_MAX_LEVELS], top[G4R_SHUFFLE_MAX_LEVELS], down[G4R_SHUFFLE_MAX_LEVELS];
   bf16_t* out[G4R_SHUFFLE_MAX_LEVELS];
-  long end[G4R_SHUFFLE_MAX_LEVELS];   // running item count: level l owns items [end[l-1], end[l])
+  int chunks[G4R_SHUFFLE_MAX_LEVELS];    // pixel chunks per image on level l
+  int blk_end[G4R_SHUFFLE_MAX_LEVELS];   // running workgroup count: level l owns [blk_end[l-1], blk_end[l]) = B * chunks[l]
   int n;
 };
-__global__ __launch_bounds__(256) void fuse_shuffle_mlvl_kernel(ShuffleLevels a, int C) {
-  const long total = a.end[a.n - 1];
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    int l = 0;
+
+__device__ __forceinline__ F8 affine_relu(const F8& x, const F8& ga, const F8& gs, bool on) {
+  if (!on) return x;
+  F8 o;
 #pragma unroll
-    for (int q = 0; q < G4R_SHUFFLE_MAX_LEVELS - 1; ++q)
-      if (q + 1 < a.n && i >= a.end[q]) l = q + 1;
-    const long base = l == 0 ? 0 : a.end[l - 1];
-    // the level is almost always wave-uniform (a boundary falls inside at most one wave per level): switch on it so
-    // that the ShuffleSrc fields are read from scalar registers
-    if (l == 0) shuffle_item(a.own[0], a.top[0], a.down[0], a.out[0], C, i - base);
-    else if (l == 1) shuffle_item(a.own[1], a.top[1], a.down[1], a.out[1], C, i - base);
-    else if (l == 2) shuffle_item(a.own[2], a.top[2], a.down[2], a.out[2], C, i - base);
-    else shuffle_item(a.own[3], a.top[3], a.down[3], a.out[3], C, i - base);
+  for (int k = 0; k < 8; ++k) o.v[k] = fmaxf(ga.v[k] * x.v[k] + gs.v[k], 0.f);
+  return o;
+}
+
+__global__ __launch_bounds__(256) void fuse_shuffle_mlvl_kernel(ShuffleLevels a, int B, int C, int ppb) {
+  int l = 0;
+#pragma unroll
+  for (int q = 0; q < G4R_SHUFFLE_MAX_LEVELS - 1; ++q)
+    if (q + 1 < a.n && (int)blockIdx.x >= a.blk_end[q]) l = q + 1;
+  const int local = (int)blockIdx.x - (l == 0 ? 0 : a.blk_end[l - 1]);
+  const int chunks = a.chunks[l];
+  const int b = local / chunks, chunk = local - b * chunks;
+  const int nvec = C >> 3;
+  const int v = threadIdx.x % nvec, plane = threadIdx.x / nvec, pstep = 256 / nvec;
+  const int R = C >> 1, S = C >> 2;
+  const int c = v * 8;
+  // this thread's source and the channel it reads there
+  ShuffleSrc src = a.own[l];
+  int cs = c;
+  if (c >= R + S) { src = a.down[l]; cs = c - S; }       // down[:, R + (c-R-S)]
+  else if (c >= R) { src = a.top[l]; cs = c + S; }       // top[:, R+S + (c-R)]
+  const int H = a.own[l].H, W = a.own[l].W;
+  const bool aff = src.affine != nullptr;
+  F8 ga, gs;
+  if (aff) {
+    ga = ld8f(src.affine + (size_t)b * 2 * C + cs);
+    gs = ld8f(src.affine + (size_t)b * 2 * C + C + cs);
+  }
+  const bf16_t* base = src.x + (size_t)b * src.H * src.W * C + cs;
+  const bool same = src.H == H && src.W == W;
+  bf16_t* out = a.out[l] + (size_t)b * H * W * C + c;
+  const int HW = H * W;
+  int p1 = (chunk + 1) * ppb;
+  if (p1 > HW) p1 = HW;
+  for (int p = chunk * ppb + plane; p < p1; p += pstep) {
+    const int y = p / W, x = p - y * W;
+    F8 o;
+    if (same) {
+      o = affine_relu(ld8(base + (size_t)p * C), ga, gs, aff);
+    } else {
+      const Lerp ly = lerp_ac(y, src.H, H), lx = lerp_ac(x, src.W, W);
+      const F8 p00 = affine_relu(ld8(base + ((size_t)ly.i0 * src.W + lx.i0) * C), ga, gs, aff);
+      const F8 p01 = affine_relu(ld8(base + ((size_t)ly.i0 * src.W + lx.i1) * C), ga, gs, aff);
+      const F8 p10 = affine_relu(ld8(base + ((size_t)ly.i1 * src.W + lx.i0) * C), ga, gs, aff);
+      const F8 p11 = affine_relu(ld8(base + ((size_t)ly.i1 * src.W + lx.i1) * C), ga, gs, aff);
+      const float wy1 = ly.w1, wy0 = 1.f - wy1, wx1 = lx.w1, wx0 = 1.f - wx1;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        o.v[k] = wy0 * (wx0 * p00.v[k] + wx1 * p01.v[k]) + wy1 * (wx0 * p10.v[k] + wx1 * p11.v[k]);
+    }
+    st8(out + (size_t)p * C, o);
   }
 }
 
@@ -627,8 +674,11 @@ int g4r_fuse_shuffle_mlvl_nhwc_bf16(const void* const* maps, const float* const*
   G4R_REQUIRE(n_levels >= 1 && n_levels <= G4R_SHUFFLE_MAX_LEVELS && B > 0, "fuse_shuffle_mlvl: 1..4 levels");
   G4R_REQUIRE(C % 32 == 0, "fuse_shuffle_mlvl: C must be a multiple of 32");
   G4R_REQUIRE(maps && heights && widths && top_idx && down_idx && outs, "fuse_shuffle_mlvl: null pointer");
+  const int nvec = C / 8;
+  G4R_REQUIRE(nvec <= 256 && 256 % nvec == 0, "fuse_shuffle_mlvl: C/8 must divide 256");
   ShuffleLevels a;
-  long run = 0;
+  const int ppb = 64;                  // pixels per workgroup: 64 x C x 2 B = 128 KB written per workgroup at C = 1024
+  int blocks = 0;
   for (int t = 0; t < G4R_SHUFFLE_MAX_LEVELS; ++t) {
     const int l = t < n_levels ? t : 0;
     const int tp = top_idx[l], dn = down_idx[l];
@@ -638,11 +688,12 @@ int g4r_fuse_shuffle_mlvl_nhwc_bf16(const void* const* maps, const float* const*
     a.top[t] = ShuffleSrc{(const bf16_t*)maps[tp], affines ? affines[tp] : nullptr, heights[tp], widths[tp]};
     a.down[t] = ShuffleSrc{(const bf16_t*)maps[dn], affines ? affines[dn] : nullptr, heights[dn], widths[dn]};
     a.out[t] = (bf16_t*)outs[l];
-    if (t < n_levels) run += (long)B * heights[l] * widths[l] * (C / 8);
-    a.end[t] = run;
+    a.chunks[t] = g4r_ceil_div((long)heights[l] * widths[l], ppb);
+    if (t < n_levels) blocks += B * a.chunks[t];
+    a.blk_end[t] = blocks;
   }
   a.n = n_levels;
-  hipLaunchKernelGGL(fuse_shuffle_mlvl_kernel, dim3(grid_for(run)), dim3(256), 0, (hipStream_t)stream, a, C);
+  hipLaunchKernelGGL(fuse_shuffle_mlvl_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, B, C, ppb);
   G4R_CHECK_LAUNCH("fuse_shuffle_mlvl");
   return G4R_OK;
 }
