@@ -513,9 +513,13 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
   G4R_REQUIRE(!causal || Tk >= Tq, "flash_attn: causal needs Tk >= Tq");
   // the prefill shapes of the path go to the second form; a handful of query rows against a long cache (the host-loop
   // decode, Tq < 32) stays on the first form, whose 2 x 64-row workgroups waste less on an almost empty query block
-  if ((g_attn_variant == 0 && Tq >= 32) || g_attn_variant >= 10)
+  // second form: every head_dim-64 launch of the path, and head_dim 128 while the 128-row query blocks number at most 512
+  // (LLaMA prefill of one or two prompts); beyond that the first form is as fast or faster (8 x 699 tokens: 90.9 vs 94.0 us)
+  const long wgs128 = (long)g4r_ceil_div(Tq, 128) * H * B;
+  const bool second_form = g_attn_variant >= 10 || (g_attn_variant == 0 && Tq >= 32 && (head_dim == 64 || wgs128 <= 512));
+  if (second_form && o_row % 8 == 0 && o_batch % 8 == 0)   // 16-byte O rows
     return g4r_attn2_dispatch(Q, K, V, O, B, H, Tq, Tk, head_dim, q_row, k_row, v_row, o_row, q_batch, k_batch, v_batch,
-                              o_batch, scale, causal, kv_len_dev, lse, g_attn_variant >= 10 ? g_attn_variant : 0, stream);   // + 1000 * ablation bits (tools)
+                              o_batch, scale, causal, kv_len_dev, lse, g_attn_variant >= 10 ? g_attn_variant : 0, stream);
   AttnArgs a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_row, k_row, v_row, o_row,
                 q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal, kv_len_dev, lse};
   // 64 query rows per workgroup (2 waves): ~2x the workgroups of a 128-row block for the short

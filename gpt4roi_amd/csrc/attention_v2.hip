@@ -41,7 +41,6 @@ struct Attn2Args {
   int causal;
   const int* kv_len_dev;
   float* lse;
-  int dbg;          // tools only (ablation timing, results wrong): 1 skip V pieces, 2 skip K pieces, 4 skip softmax, 8 skip PV, 16 skip QK
 };
 
 constexpr int A2_KVB = 64;        // keys per tile
@@ -53,7 +52,15 @@ __device__ __forceinline__ int a2_kswz(int row) { return D == 128 ? (row & 15) :
 template <int D>
 constexpr int a2_tile_bytes() { return A2_KVB * D * 2 + (D / 16) * A2_VSUB; }
 
-template <int D, int NWG, int NG>
+// PP (ping-pong): a step is two phases with a barrier after each, and odd groups run one phase behind even groups:
+//     phase A = the 16 QK^T MFMAs, the LDS-DMA pieces of the group's next tile, then scale / mask / row max (VALU)
+//     phase B = exp2 / row sum / P -> bf16 / O rescale (VALU), then the 16 PV MFMAs
+// so that on every SIMD one wave's MFMA burst runs beside the other wave's VALU burst and vice versa (the first version
+// had every wave in the same phase at the same time: QK, softmax and PV of both waves of a SIMD simply added up, ~2.3 us
+// per step against 1 us of MFMA).  All LDS tile buffers are group-private, so the offset adds no hazard: a group's next
+// tile is issued in its phase A (its buffer was last read in the group's phase A / B of the previous step, two barriers
+// ago) and waited for at the end of its phase B.
+template <int D, int NWG, int NG, bool PP>
 __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args p) {
   constexpr int QB = NWG * 32;
   constexpr int SLOTS = D / 8, KSTEPS = D / 16, DB = D / 32, NDD = D / 16;
@@ -61,7 +68,11 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
   constexpr int KP = K_BYTES / 1024, VP = NDD * 2;        // 1 KiB pieces of a K / V tile
   constexpr int PPW = (KP + VP) / NWG, KPW = KP / NWG;    // pieces per wave: the first KPW are K pieces
   constexpr int RPP = 1024 / (D * 2);                     // key rows per K piece
+  constexpr int NWAVES = NWG * NG;
+  constexpr int QP = QB * D * 2 / 1024;                   // 1 KiB pieces of the Q tile
+  constexpr int QPW = (QP + NWAVES - 1) / NWAVES;
   static_assert(KP % NWG == 0 && VP % NWG == 0, "piece split");
+  static_assert(QB * D * 2 <= TILE_BYTES, "the Q tile is staged in one tile buffer");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // NG groups x 2 buffers x TILE_BYTES (one array: no second
                                                                 // __shared__ object beside an LDS-DMA pipeline)
   if (p.kv_len_dev) p.Tk = *p.kv_len_dev + p.Tq;
@@ -78,21 +89,6 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
   const bf16_t* Kb = p.K + (size_t)b * p.k_batch + (size_t)h * D;
   const bf16_t* Vb = p.V + (size_t)b * p.v_batch + (size_t)h * D;
   char* gbuf = smem + grp * (2 * TILE_BYTES);
-
-  bf16x8 qf[KSTEPS];
-  {
-    const int qr = qi < p.Tq ? qi : p.Tq - 1;
-    const bf16_t* qrow = Qb + (size_t)qr * p.q_row + hi * 8;
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>((p.dbg & 64) ? Qb + lane * 8 : qrow + kk * 16);
-  }
-  float16v oacc[DB];
-#pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  const float sc2 = p.scale * 1.4426950408889634f;
 
   int kend = p.Tk;
   if (p.causal) {
@@ -125,7 +121,6 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
     char* dst = gbuf + buf * TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-      if (p.dbg & (j < KPW ? 2 : 1)) continue;
       int key = j0 + prow[j];
       if (key > p.Tk - 1) key = p.Tk - 1;
       const bf16_t* src = (j < KPW ? Kb + (size_t)key * p.k_row : Vb + (size_t)key * p.v_row) + pcol[j];
@@ -139,37 +134,70 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
   const int k_sw = a2_kswz<D>(ql);      // rows ql and ql + 32 share the swizzle (32 = 0 mod 16; (32 >> 1) = 0 mod 8)
   const int v_lane_off = K_BYTES + ((lane >> 4) & 1) * A2_VSUB + hi * 128 + (lane & 15) * 8;
 
+  // ---- Q tile: staged once by LDS-DMA (whole 256 / 128-byte rows per 16 / 8 lanes instead of one strided row per lane)
+  //      into group 0's second tile buffer, in the K image (row-major, swizzled slots), then read as B fragments ----
+  char* qlds = smem + TILE_BYTES;
+#pragma unroll
+  for (int j = 0; j < QPW; ++j) {
+    const int pq = wave + NWAVES * j;
+    if (pq < QP) {
+      const int row = pq * RPP + lane / SLOTS;
+      int qr = qblock + row;
+      if (qr > p.Tq - 1) qr = p.Tq - 1;
+      const bf16_t* src = Qb + (size_t)qr * p.q_row + ((lane % SLOTS) ^ a2_kswz<D>(row)) * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(qlds + pq * 1024), 16, 0, 0);
+    }
+  }
   if (grp < ntiles) issue(grp, 0);
-  for (int s = 0; s < nsteps; ++s) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 qf[KSTEPS];
+  {
+    const char* qrow = qlds + (wv * 32) * (D * 2) + k_row_off;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + (((kk * 2 + hi) ^ k_sw) << 4));
+  }
+  float16v oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sc2 = p.scale * 1.4426950408889634f;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();            // every wave holds its Q fragments: the staging buffer may be overwritten
+
+  // state carried from phase A to phase B of a step
+  float16v sacc[2];
+  float m_use = 0.f, alpha = 1.f, m_new = -INFINITY;
+  bool active = false;
+  auto phase_a = [&](int s) {
     const int tile = s * NG + grp;
     const int buf = s & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of step s have landed
-    __builtin_amdgcn_s_barrier();                          // ... everyone's; and everyone is done reading buffer buf ^ 1
-    if (tile + NG < ntiles) issue(tile + NG, buf ^ 1);
     const int j0 = tile * A2_KVB;
     // a wave skips tiles that are beyond the keys (ragged tail of the split) or entirely above its causal diagonal
-    if (tile < ntiles && !(p.causal && j0 > qw0 + 31 + off)) {
-      const char* kt = gbuf + buf * TILE_BYTES;
-      // ---- S^T = K Q^T for two 32-key blocks ----
-      float16v sacc[2];
+    active = tile < ntiles && !(p.causal && j0 > qw0 + 31 + off);
+    const char* kt = gbuf + buf * TILE_BYTES;
+    if (active) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
         const char* krow = kt + kb * 32 * (D * 2) + k_row_off;
-        if (p.dbg & 16) continue;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((kk * 2 + hi) ^ k_sw) << 4));
           sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sacc[kb], 0, 0, 0);
         }
       }
-      // ---- online softmax of this lane's query (keys j0 + kb*32 + (r&3) + 8*(r>>2) + 4*hi), log2 domain ----
+    }
+    if (tile + NG < ntiles) issue(tile + NG, buf ^ 1);     // the group's next tile (every wave carries its pieces)
+    if (active) {
+      // online softmax, first half: scores in the log2 domain, masks, row max
       const bool need_mask = (j0 + A2_KVB > p.Tk) || (p.causal && j0 + A2_KVB - 1 > qw0 + off);
       float mt = -INFINITY;
-      if (p.dbg & 4) {
-        mt = 0.f;
-      } else if (need_mask) {
+      if (need_mask) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -190,59 +218,81 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
           }
       }
       mt = fmaxf(mt, __shfl_xor(mt, 32));
-      const float m_new = fmaxf(m_run, mt);
-      const float m_use = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-      float rs = 0.f;
-      if (!(p.dbg & 4)) {
+      m_new = fmaxf(m_run, mt);
+      m_use = m_new == -INFINITY ? 0.f : m_new;
+      alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+    }
+  };
+  auto phase_b = [&](int s) {
+    if (!active) return;
+    const char* kt = gbuf + (s & 1) * TILE_BYTES;
+    float rs = 0.f;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(sacc[kb][r] - m_use);
-          sacc[kb][r] = e;
-          rs += e;
-        }
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sacc[kb][r] - m_use);
+        sacc[kb][r] = e;
+        rs += e;
       }
-      rs += __shfl_xor(rs, 32);
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
+    rs += __shfl_xor(rs, 32);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+    if (!__all(alpha == 1.f)) {          // the running max moved for some row of this wave: rescale O (wave-uniform branch)
 #pragma unroll
       for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-      // ---- O^T += V^T P^T : A operand = 4 + 4 keys of this lane's d through two transpose reads ----
-      const char* vt = kt + v_lane_off;
-      if (!(p.dbg & 8))
+    }
+    // O^T += V^T P^T : A operand = 4 + 4 keys of this lane's d through two transpose reads
+    const char* vt = kt + v_lane_off;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          uint4v pw;
-          pw.x = pack_bf16x2(sacc[kb][hf * 8 + 0], sacc[kb][hf * 8 + 1]);
-          pw.y = pack_bf16x2(sacc[kb][hf * 8 + 2], sacc[kb][hf * 8 + 3]);
-          pw.z = pack_bf16x2(sacc[kb][hf * 8 + 4], sacc[kb][hf * 8 + 5]);
-          pw.w = pack_bf16x2(sacc[kb][hf * 8 + 6], sacc[kb][hf * 8 + 7]);
-          const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+      for (int hf = 0; hf < 2; ++hf) {
+        uint4v pw;
+        pw.x = pack_bf16x2(sacc[kb][hf * 8 + 0], sacc[kb][hf * 8 + 1]);
+        pw.y = pack_bf16x2(sacc[kb][hf * 8 + 2], sacc[kb][hf * 8 + 3]);
+        pw.z = pack_bf16x2(sacc[kb][hf * 8 + 4], sacc[kb][hf * 8 + 5]);
+        pw.w = pack_bf16x2(sacc[kb][hf * 8 + 6], sacc[kb][hf * 8 + 7]);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
-          for (int d = 0; d < DB; ++d) {
-            const char* a = vt + d * 2 * A2_VSUB + (kb * 32 + hf * 16) * 32;
-            const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (short4v __attribute__((address_space(3)))*)(a));
-            const short4v up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (short4v __attribute__((address_space(3)))*)(a + 8 * 32));
-            const short8 vv = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
-            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[d], 0, 0, 0);
-          }
+        for (int d = 0; d < DB; ++d) {
+          const char* a = vt + d * 2 * A2_VSUB + (kb * 32 + hf * 16) * 32;
+          const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (short4v __attribute__((address_space(3)))*)(a));
+          const short4v up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (short4v __attribute__((address_space(3)))*)(a + 8 * 32));
+          const short8 vv = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[d], 0, 0, 0);
         }
+      }
+  };
+
+  if (PP) {
+    if (grp & 1) __builtin_amdgcn_s_barrier();             // odd groups run one phase behind
+    for (int s = 0; s < nsteps; ++s) {
+      phase_a(s);
+      __builtin_amdgcn_s_barrier();
+      phase_b(s);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the group's next tile has landed (issued in phase A)
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!(grp & 1)) __builtin_amdgcn_s_barrier();
+  } else {
+    for (int s = 0; s < nsteps; ++s) {
+      phase_a(s);
+      phase_b(s);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                        // everyone's pieces landed; everyone is done with this step's buffers
     }
   }
 
-  // ---- merge the NG partial states through LDS (the tile buffers are free after this barrier) ----
-  if (NG > 1 && !(p.dbg & 128)) {
-    __builtin_amdgcn_s_barrier();
+  // ---- merge the NG partial states through LDS (the tile buffers are free: every wave passed the last barrier) ----
+  constexpr int REGS = DB * 16 + 2;                        // O^T registers + m + l, per (group - 1, wave, lane)
+  constexpr int MERGE_BYTES = (NG - 1) * NWG * REGS * 64 * 4;
+  if (NG > 1) {
     float* mo = reinterpret_cast<float*>(smem);
-    constexpr int REGS = DB * 16 + 2;                      // O^T registers + m + l, per (group - 1, wave, lane)
     if (grp > 0) {
       float* dst = mo + ((size_t)((grp - 1) * NWG + wv) * REGS) * 64 + lane;
 #pragma unroll
@@ -258,11 +308,11 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
     for (int g = 1; g < NG; ++g) {
       const float* src = mo + ((size_t)((g - 1) * NWG + wv) * REGS) * 64 + lane;
       const float m_o = src[(DB * 16) * 64], l_o = src[(DB * 16 + 1) * 64];
-      const float m_new = fmaxf(m_run, m_o);
-      const float m_use = m_new == -INFINITY ? 0.f : m_new;
-      const float a_me = __builtin_amdgcn_exp2f(m_run - m_use), a_o = __builtin_amdgcn_exp2f(m_o - m_use);
+      const float mm = fmaxf(m_run, m_o);
+      const float mu = mm == -INFINITY ? 0.f : mm;
+      const float a_me = __builtin_amdgcn_exp2f(m_run - mu), a_o = __builtin_amdgcn_exp2f(m_o - mu);
       l_run = l_run * a_me + l_o * a_o;
-      m_run = m_new;
+      m_run = mm;
 #pragma unroll
       for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -270,27 +320,40 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
     }
   }
 
-  if (qi < p.Tq && !((p.dbg & 32) && l_run != 12345.f)) {
-    if (p.lse && hi == 0) p.lse[((size_t)b * p.H + h) * p.Tq + qi] = m_run + __log2f(l_run);
-    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    bf16_t* orow = p.O + (size_t)b * p.o_batch + (size_t)qi * p.o_row + (size_t)h * D;
+  // ---- normalise; O through LDS so that a wave instruction stores whole rows (a lane owns ONE query row: stored directly
+  //      it wrote 32 rows x 16 bytes per instruction) ----
+  if (p.lse && hi == 0 && qi < p.Tq) p.lse[((size_t)b * p.H + h) * p.Tq + qi] = m_run + __log2f(l_run);
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  constexpr int ORS = D * 2 + 16;                          // row stride of the O staging image (bytes)
+  char* olds = smem + MERGE_BYTES + (size_t)wv * 32 * ORS;  // this wave's 32 rows (behind the merge area)
 #pragma unroll
-    for (int d = 0; d < DB; ++d)
+  for (int d = 0; d < DB; ++d)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const uint2v w = {pack_bf16x2(oacc[d][g * 4] * inv, oacc[d][g * 4 + 1] * inv),
-                          pack_bf16x2(oacc[d][g * 4 + 2] * inv, oacc[d][g * 4 + 3] * inv)};
-        *reinterpret_cast<uint2v*>(orow + d * 32 + g * 8 + 4 * hi) = w;
-      }
+    for (int g = 0; g < 4; ++g) {
+      const uint2v w = {pack_bf16x2(oacc[d][g * 4] * inv, oacc[d][g * 4 + 1] * inv),
+                        pack_bf16x2(oacc[d][g * 4 + 2] * inv, oacc[d][g * 4 + 3] * inv)};
+      *reinterpret_cast<uint2v*>(olds + ql * ORS + (d * 32 + g * 8 + 4 * hi) * 2) = w;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave wrote and reads: in-order LDS, no barrier needed
+  constexpr int LPR = D / 8;                               // lanes per output row (16 bytes each)
+  constexpr int RPI = 64 / LPR;                            // rows per wave instruction
+#pragma unroll
+  for (int it = 0; it < 32 / RPI; ++it) {
+    const int r = it * RPI + lane / LPR;
+    const int qrow = qw0 + r;
+    const uint4v w = *reinterpret_cast<const uint4v*>(olds + r * ORS + (lane % LPR) * 16);
+    if (qrow < p.Tq)
+      *reinterpret_cast<uint4v*>(p.O + (size_t)b * p.o_batch + (size_t)qrow * p.o_row + (size_t)h * D + (lane % LPR) * 8) = w;
   }
 }
 
-template <int D, int NWG, int NG>
+template <int D, int NWG, int NG, bool PP = true>
 int launch_attn2(const Attn2Args& a, int B, hipStream_t st) {
   constexpr int LDS = NG * 2 * a2_tile_bytes<D>();
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static_assert(LDS >= (NG - 1) * NWG * (D / 32 * 16 + 2) * 64 * 4, "merge area fits the tile buffers");
-  auto kfn = flash_attn_fwd2_kernel<D, NWG, NG>;
+  static_assert(LDS >= (NG - 1) * NWG * (D / 32 * 16 + 2) * 64 * 4 + NWG * 32 * (D * 2 + 16),
+                "merge area + O staging fit the tile buffers");
+  auto kfn = flash_attn_fwd2_kernel<D, NWG, NG, PP>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -310,26 +373,28 @@ int g4r_attn2_dispatch(const void* Q, const void* K, const void* V, void* O, int
                        long o_batch, float scale, int causal, const int* kv_len_dev, float* lse, int variant,
                        void* stream) {
   Attn2Args a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_row, k_row, v_row, o_row,
-                 q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal, kv_len_dev, lse, variant / 1000};
-  variant %= 1000;
+                 q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal, kv_len_dev, lse};
   hipStream_t st = (hipStream_t)stream;
   int rc = G4R_OK;
+  // variant = NWG * 10 + NG; + 100 = the lock-step form (one barrier per step), which is what production runs: the
+  // phase-offset form measured the same or slower (T = 767: 21.7 vs 21.7 us; ViT S = 577: 10.7 vs 9.5 us)
   if (head_dim == 128) {
-    if (variant == 0) variant = 42;
+    if (variant == 0) variant = 142;
     if (variant == 42) rc = launch_attn2<128, 4, 2>(a, B, st);
-    else if (variant == 41) rc = launch_attn2<128, 4, 1>(a, B, st);
-    else if (variant == 22) rc = launch_attn2<128, 2, 2>(a, B, st);
+    else if (variant == 142) rc = launch_attn2<128, 4, 2, false>(a, B, st);
+    else if (variant == 41) rc = launch_attn2<128, 4, 1, false>(a, B, st);
     else return g4r_note_error(G4R_ERR_INVALID_ARG, "flash_attn_fwd2: unknown variant for head_dim 128");
   } else {
     if (variant == 0) {
       // few workgroups (the batch-1 ViT: 16 heads x 577 rows): 64-row blocks x 4 key groups; otherwise 128-row blocks
       const long wgs128 = (long)g4r_ceil_div(Tq, 128) * H * B;
-      variant = wgs128 < 256 ? 24 : 42;
+      variant = wgs128 < 256 ? 124 : 142;
     }
     if (variant == 24) rc = launch_attn2<64, 2, 4>(a, B, st);
+    else if (variant == 124) rc = launch_attn2<64, 2, 4, false>(a, B, st);
     else if (variant == 42) rc = launch_attn2<64, 4, 2>(a, B, st);
-    else if (variant == 44) rc = launch_attn2<64, 4, 4>(a, B, st);
-    else if (variant == 41) rc = launch_attn2<64, 4, 1>(a, B, st);
+    else if (variant == 142) rc = launch_attn2<64, 4, 2, false>(a, B, st);
+    else if (variant == 41) rc = launch_attn2<64, 4, 1, false>(a, B, st);
     else return g4r_note_error(G4R_ERR_INVALID_ARG, "flash_attn_fwd2: unknown variant for head_dim 64");
   }
   if (rc != G4R_OK) return rc;

@@ -1929,6 +1929,8 @@ int launch_tile(GemmArgs& p, hipStream_t stream) {
 
 template <int AMODE>
 int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
+  if (g_gemm_dbg == 9) p.n_fastest = 0;     // tools: force the tile order (A/B of the L2 sharing pattern)
+  if (g_gemm_dbg == 10) p.n_fastest = 1;
   switch (tile_cfg) {
     case 0: return launch_tile<128, 128, 2, 2, AMODE, true>(p, stream);
     case 1: return launch_tile<256, 128, 4, 2, AMODE, true>(p, stream);
