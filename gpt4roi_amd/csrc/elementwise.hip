@@ -118,13 +118,22 @@ struct ShuffleSrc {
   int H, W;
 };
 
+// the bilinear blend of the shuffle kernels with its contractions pinned (wy0 (wx0 p00 + wx1 p01) + wy1 (wx0 p10 + wx1 p11)):
+// the per-level and the merged kernel must round alike, whatever the compiler would fuse in either context
+__device__ __forceinline__ float blend4(float wy0, float wy1, float wx0, float wx1, float p00, float p01, float p10,
+                                        float p11) {
+  const float t0 = __builtin_fmaf(wx1, p01, wx0 * p00);
+  const float t1 = __builtin_fmaf(wx1, p11, wx0 * p10);
+  return __builtin_fmaf(wy1, t1, wy0 * t0);
+}
+
 __device__ __forceinline__ F8 gn_relu(const F8& x, const float* aff, int b, int C, int c0) {
   if (!aff) return x;
   const F8 a = ld8f(aff + (size_t)b * 2 * C + c0);
   const F8 s = ld8f(aff + (size_t)b * 2 * C + C + c0);
   F8 o;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) o.v[k] = fmaxf(a.v[k] * x.v[k] + s.v[k], 0.f);
+  for (int k = 0; k < 8; ++k) o.v[k] = fmaxf(__builtin_fmaf(a.v[k], x.v[k], s.v[k]), 0.f);
   return o;
 }
 
@@ -141,8 +150,7 @@ __device__ __forceinline__ F8 sample_src(const ShuffleSrc& s, int b, int y, int 
   const float wy1 = ly.w1, wy0 = 1.f - wy1, wx1 = lx.w1, wx0 = 1.f - wx1;
   F8 o;
 #pragma unroll
-  for (int k = 0; k < 8; ++k)
-    o.v[k] = wy0 * (wx0 * p00.v[k] + wx1 * p01.v[k]) + wy1 * (wx0 * p10.v[k] + wx1 * p11.v[k]);
+  for (int k = 0; k < 8; ++k) o.v[k] = blend4(wy0, wy1, wx0, wx1, p00.v[k], p01.v[k], p10.v[k], p11.v[k]);
   return o;
 }
 
@@ -193,7 +201,7 @@ __device__ __forceinline__ F8 affine_relu(const F8& x, const F8& ga, const F8& g
   if (!on) return x;
   F8 o;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) o.v[k] = fmaxf(ga.v[k] * x.v[k] + gs.v[k], 0.f);
+  for (int k = 0; k < 8; ++k) o.v[k] = fmaxf(__builtin_fmaf(ga.v[k], x.v[k], gs.v[k]), 0.f);
   return o;
 }
 
@@ -227,7 +235,8 @@ __global__ __launch_bounds__(256) void fuse_shuffle_mlvl_kernel(ShuffleLevels a,
   const int HW = H * W;
   int p1 = (chunk + 1) * ppb;
   if (p1 > HW) p1 = HW;
-  for (int p = chunk * ppb + plane; p < p1; p += pstep) {
+#pragma unroll 4
+  for (int p = chunk * ppb + plane; p < p1; p += pstep) {       // independent pixels: let several gathers be in flight
     const int y = p / W, x = p - y * W;
     F8 o;
     if (same) {
@@ -240,8 +249,7 @@ __global__ __launch_bounds__(256) void fuse_shuffle_mlvl_kernel(ShuffleLevels a,
       const F8 p11 = affine_relu(ld8(base + ((size_t)ly.i1 * src.W + lx.i1) * C), ga, gs, aff);
       const float wy1 = ly.w1, wy0 = 1.f - wy1, wx1 = lx.w1, wx0 = 1.f - wx1;
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        o.v[k] = wy0 * (wx0 * p00.v[k] + wx1 * p01.v[k]) + wy1 * (wx0 * p10.v[k] + wx1 * p11.v[k]);
+      for (int k = 0; k < 8; ++k) o.v[k] = blend4(wy0, wy1, wx0, wx1, p00.v[k], p01.v[k], p10.v[k], p11.v[k]);
     }
     st8(out + (size_t)p * C, o);
   }

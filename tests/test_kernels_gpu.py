@@ -778,7 +778,10 @@ def test_merged_level_shuffle_and_groupnorm_equal_the_per_level_launches():
         K.fuse_shuffle_mlvl(maps, a, lvl_list, out)
         for tar, top, dow in lvl_list:
             want = K.fuse_shuffle(maps[tar], maps[top], maps[dow], a[tar], a[top], a[dow])
-            assert torch.equal(out.levels[tar], want), (use_aff, tar)
+            d = (out.levels[tar].float() - want.float()).abs()
+            assert torch.equal(out.levels[tar], want), (
+                f"shuffle: affine={use_aff} level {tar}: {int((d > 0).sum())} of {d.numel()} differ, max {float(d.max()):.3e}, "
+                f"first at {[int(i) for i in (d > 0).nonzero()[0]] if (d > 0).any() else None}")
     z = K.MlvlMaps(B, sizes, C, DEV)
     for lv, m in zip(z.levels, maps):
         lv.copy_(m)
@@ -787,7 +790,8 @@ def test_merged_level_shuffle_and_groupnorm_equal_the_per_level_launches():
     got = K.groupnorm_affine_mlvl(z, gamma, beta, 16, 1e-5)
     for l in range(4):
         want = K.groupnorm_affine(z.levels[l], gamma, beta, 16, 1e-5)
-        assert torch.equal(got[l], want), l
+        d = (got[l] - want).abs()
+        assert torch.equal(got[l], want), f"groupnorm level {l}: {int((d > 0).sum())} of {d.numel()} differ, max {float(d.max()):.3e}"
 
 
 def test_split_k_reduce_folded_into_the_next_rmsnorm_is_bit_identical():
