@@ -194,6 +194,89 @@ __global__ __launch_bounds__(256) void rmsnorm_splitk_bf16_kernel(const float* _
   }
 }
 
+// LayerNorm of a row that is still a sum of split-K partials: x = sum_s partial[s][row] + bias (+ residual), rounded to bf16
+// and stored (the residual stream), then y = layernorm(x) -- splitk_reduce_kernel and layernorm_bf16_kernel in one pass,
+// same summation order and rounding points: bit-identical to the two launches (CLIP fc2 -> next block's layer_norm1).
+__global__ __launch_bounds__(256) void layernorm_splitk_bf16_kernel(const float* __restrict__ partials, int splits,
+                                                                    long slice_stride, const float* __restrict__ bias,
+                                                                    const bf16_t* __restrict__ residual, long ldr,
+                                                                    bf16_t* __restrict__ xout, long ldxo,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                                    long ldy, int cols, float eps) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const int nvec = cols >> 3;
+  float f[NORM_MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXV; ++i) {
+    const int v = threadIdx.x + i * 256;
+    if (v < nvec) {
+      float acc[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+      const float* src = partials + (size_t)row * cols + v * 8;
+      for (int sl = 0; sl < splits; ++sl) {
+        const float4v a = *reinterpret_cast<const float4v*>(src + (size_t)sl * slice_stride);
+        const float4v b = *reinterpret_cast<const float4v*>(src + (size_t)sl * slice_stride + 4);
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+      }
+      if (bias) {
+        const float4v b0 = *reinterpret_cast<const float4v*>(bias + v * 8), b1 = *reinterpret_cast<const float4v*>(bias + v * 8 + 4);
+        acc[0] += b0.x; acc[1] += b0.y; acc[2] += b0.z; acc[3] += b0.w;
+        acc[4] += b1.x; acc[5] += b1.y; acc[6] += b1.z; acc[7] += b1.w;
+      }
+      if (residual) {
+        const uint4v r = *reinterpret_cast<const uint4v*>(residual + (size_t)row * ldr + v * 8);
+        acc[0] += bf16lo(r.x); acc[1] += bf16hi(r.x); acc[2] += bf16lo(r.y); acc[3] += bf16hi(r.y);
+        acc[4] += bf16lo(r.z); acc[5] += bf16hi(r.z); acc[6] += bf16lo(r.w); acc[7] += bf16hi(r.w);
+      }
+      uint4v w;
+      w.x = pack_bf16x2(acc[0], acc[1]); w.y = pack_bf16x2(acc[2], acc[3]);
+      w.z = pack_bf16x2(acc[4], acc[5]); w.w = pack_bf16x2(acc[6], acc[7]);
+      *reinterpret_cast<uint4v*>(xout + (size_t)row * ldxo + v * 8) = w;
+      f[i][0] = bf16lo(w.x); f[i][1] = bf16hi(w.x); f[i][2] = bf16lo(w.y); f[i][3] = bf16hi(w.y);
+      f[i][4] = bf16lo(w.z); f[i][5] = bf16hi(w.z); f[i][6] = bf16lo(w.w); f[i][7] = bf16hi(w.w);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += f[i][k];
+    }
+  }
+  const float mean = block_sum(s, red) / (float)cols;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXV; ++i)
+    if (threadIdx.x + i * 256 < nvec) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float d = f[i][k] - mean;
+        s2 += d * d;
+      }
+    }
+  const float rstd = rsqrtf(block_sum(s2, red) / (float)cols + eps);
+  bf16_t* yr = y + (size_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXV; ++i) {
+    const int v = threadIdx.x + i * 256;
+    if (v < nvec) {
+      const float4v g0 = *reinterpret_cast<const float4v*>(gamma + v * 8);
+      const float4v g1 = *reinterpret_cast<const float4v*>(gamma + v * 8 + 4);
+      const float4v b0 = *reinterpret_cast<const float4v*>(beta + v * 8);
+      const float4v b1 = *reinterpret_cast<const float4v*>(beta + v * 8 + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (f[i][k] - mean) * rstd * g[k] + b[k];
+      uint4v w;
+      w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
+      w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+      *reinterpret_cast<uint4v*>(yr + v * 8) = w;
+    }
+  }
+}
+
 // GroupNorm statistics over NHWC bf16, two launches, no atomics:
 //   (1) partial[b][chunk][g] = (sum, sumsq) over a chunk of pixels   grid = (chunks, B)
 //   (2) reduce the chunks in fp64 and emit the per-(b, channel) affine y = a*x + s
@@ -449,6 +532,24 @@ int g4r_rmsnorm_bf16(const void* x, const float* gamma, void* y, int rows, int c
   hipLaunchKernelGGL(rmsnorm_bf16_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, gamma, (bf16_t*)y, rows, cols, ldx, ldy, eps);
   G4R_CHECK_LAUNCH("rmsnorm");
+  return G4R_OK;
+}
+
+/* x_out[row] = bf16(sum_s partials[s][row] + bias + residual[row]); y[row] = layernorm(x_out[row]; gamma, beta, eps): the
+ * K-slice reduce of CLIP's fc2 (+ bias, + residual) folded into the next block's layer_norm1.  Bit-identical to
+ * g4r_gemm_bf16_nt(splits, bias, residual) + g4r_layernorm_bf16. */
+int g4r_layernorm_splitk_bf16(const float* partials, int splits, const float* bias, const void* residual, long ldr,
+                              void* x_out, long ldxo, const float* gamma, const float* beta, void* y, long ldy, int rows,
+                              int cols, float eps, void* stream) {
+  G4R_REQUIRE(rows >= 0 && cols > 0 && (cols % 8) == 0 && splits >= 1, "layernorm_splitk: cols must be a multiple of 8");
+  if (rows == 0) return G4R_OK;
+  G4R_REQUIRE(partials && x_out && gamma && beta && y && (ldr % 8) == 0 && (ldxo % 8) == 0 && (ldy % 8) == 0,
+              "layernorm_splitk: bad pointer/stride");
+  G4R_REQUIRE(cols <= 256 * NORM_MAXV * 8, "layernorm_splitk: cols <= 8192");
+  hipLaunchKernelGGL(layernorm_splitk_bf16_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, partials, splits,
+                     (long)rows * cols, bias, (const bf16_t*)residual, ldr, (bf16_t*)x_out, ldxo, gamma, beta, (bf16_t*)y, ldy,
+                     cols, eps);
+  G4R_CHECK_LAUNCH("layernorm_splitk");
   return G4R_OK;
 }
 

@@ -79,6 +79,7 @@ _SIGS = {
     "g4r_gemm_qkv_rope_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_long, c_long, P, P, c_int,
                                c_int, P],
     "g4r_rmsnorm_splitk_bf16": [P, c_int, P, c_long, P, c_long, P, P, c_long, c_int, c_int, c_float, P],
+    "g4r_layernorm_splitk_bf16": [P, c_int, P, P, c_long, P, c_long, P, P, P, c_long, c_int, c_int, c_float, P],
     "g4r_fuse_shuffle_mlvl_nhwc_bf16": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
 }
 _bound = {}
@@ -287,6 +288,29 @@ def rmsnorm_splitk(partials, n_slices, residual, gamma, eps=1e-6):
     _launch("g4r_rmsnorm_splitk_bf16", (_p(partials), int(n_slices), _p(residual), residual.stride(0) if residual is not None else 0,
                                         _p(x), x.stride(0), _p(gamma), _p(y), y.stride(0), M, N, float(eps), _stream(x),),
             tag="g4r_rmsnorm_bf16")
+    return x, y
+
+
+def small_m_split_plan(M, N, K):
+    """(tile_cfg, K slices) when gemm() would run this shape as K slices on the 64x64 ring tile (CLIP fc2 at batch 1:
+    577 x 1024 x 4096), or None."""
+    if pick_tile(M, N, K) == 14 and K >= 4096 and -(-M // 64) * -(-N // 64) <= 256 and M > 64:
+        return 14, (4 if -(-M // 64) * -(-N // 64) <= 64 else 2)
+    return None
+
+
+def layernorm_splitk(partials, n_slices, bias, residual, gamma, beta, eps=1e-5):
+    """x = bf16(sum of the first n_slices partials + bias + residual); y = layernorm(x) -> (x, y) in one pass (bit-identical
+    to gemm(..., bias=, residual=) with K slices + layernorm())."""
+    _f32(partials, bias, gamma, beta)
+    _bf16(residual)
+    _, M, N = partials.shape
+    x = torch.empty((M, N), dtype=torch.bfloat16, device=partials.device)
+    y = torch.empty_like(x)
+    _launch("g4r_layernorm_splitk_bf16", (_p(partials), int(n_slices), _p(bias), _p(residual),
+                                          residual.stride(0) if residual is not None else 0, _p(x), x.stride(0), _p(gamma),
+                                          _p(beta), _p(y), y.stride(0), M, N, float(eps), _stream(x),),
+            tag="g4r_layernorm_bf16")
     return x, y
 
 

@@ -77,14 +77,25 @@ class ClipVisionTower:
         if 0 in wanted:
             keep[0] = x.view(B, T, C)
         scale = D ** -0.5
+        h = None                    # layer_norm1 output when the previous block's fc2 reduce already produced it
         for i, L in enumerate(self.layers):
-            h = K.layernorm(x, L['ln1'][0], L['ln1'][1], self.eps)
+            if h is None:
+                h = K.layernorm(x, L['ln1'][0], L['ln1'][1], self.eps)
             qkv = K.gemm(h, L['wqkv'], bias=L['bqkv']).view(B, T, 3 * C)
             a = K.flash_attn(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], H, scale, False)
             x = K.gemm(a.view(B * T, C), L['wo'], bias=L['bo'], residual=x)
             h = K.layernorm(x, L['ln2'][0], L['ln2'][1], self.eps)
             f = K.gemm(h, L['w1'], bias=L['b1'], act='quick_gelu')
-            x = K.gemm(f, L['w2'], bias=L['b2'], residual=x)
+            plan = K.small_m_split_plan(B * T, C, f.size(1)) if i + 1 < len(self.layers) else None
+            if plan is not None:
+                # batch-1 tower: fc2 runs as K slices; their reduce (+ bias, + residual) and the NEXT block's layer_norm1 are
+                # one pass over the row
+                part, ns = K.gemm_partials(f, L['w2'], plan[1], plan[0])
+                nxt = self.layers[i + 1]['ln1']
+                x, h = K.layernorm_splitk(part, ns, L['b2'], x, nxt[0], nxt[1], self.eps)
+            else:
+                x = K.gemm(f, L['w2'], bias=L['b2'], residual=x)
+                h = None
             if i + 1 in wanted:
                 keep[i + 1] = x.view(B, T, C)
         return keep

@@ -133,6 +133,9 @@ int g4r_gemm_bf16_nt_partials(const void* A, const void* W, float* workspace, in
                               int splits, int tile_cfg, int* splits_out, void* stream);
 int g4r_rmsnorm_splitk_bf16(const float* partials, int splits, const void* residual, long ldr, void* x_out, long ldxo,
                             const float* gamma, void* y, long ldy, int rows, int cols, float eps, void* stream);
+int g4r_layernorm_splitk_bf16(const float* partials, int splits, const float* bias, const void* residual, long ldr,
+                              void* x_out, long ldxo, const float* gamma, const float* beta, void* y, long ldy, int rows,
+                              int cols, float eps, void* stream);   /* CLIP fc2 (+bias, +residual) -> next layer_norm1 */
 
 /* Fused q|k|v projection + RoPE + KV-cache append (HF LlamaAttention.forward: q/k/v_proj, apply_rotary_pos_emb, cache update;
  * the arithmetic spi_llava.py:198-205 delegates to).  See csrc/gemm_bf16.hip for the argument contract. */

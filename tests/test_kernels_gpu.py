@@ -831,3 +831,20 @@ def test_qkv_projection_with_rope_and_cache_append_in_the_epilogue(B, T, pos0, t
     kc_got, vc_got = torch.full_like(kc_want, 7.0), torch.full_like(vc_want, 7.0)
     assert K.gemm_qkv_rope(h, w, B, T, heads, D, q_got, kc_got, vc_got, cos, sin, pos0, tile_cfg=tile) is not None
     assert torch.equal(q_got, q_want) and torch.equal(kc_got, kc_want) and torch.equal(vc_got, vc_want)
+
+
+def test_clip_fc2_reduce_folded_into_the_next_layernorm_is_bit_identical():
+    """g4r_gemm_bf16_nt_partials + g4r_layernorm_splitk_bf16 (CLIP fc2's K-slice reduce + bias + residual folded into the next
+    block's layer_norm1) against gemm(bias, residual) + layernorm(): bit for bit."""
+    M, N, K_ = 577, 1024, 4096
+    a, w = rnd(M, K_, scale=0.5, seed=410), rnd(N, K_, scale=0.02, seed=411)
+    res = rnd(M, N, seed=412)
+    g = torch.Generator().manual_seed(413)
+    bias = (0.1 * torch.randn(N, generator=g)).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(N, generator=g)).to(DEV), (0.1 * torch.randn(N, generator=g)).to(DEV)
+    tile, splits = K.small_m_split_plan(M, N, K_)
+    x_want = K.gemm(a, w, bias=bias, residual=res)
+    h_want = K.layernorm(x_want, gamma, beta, 1e-5)
+    part, ns = K.gemm_partials(a, w, splits, tile)
+    x_got, h_got = K.layernorm_splitk(part, ns, bias, res, gamma, beta, 1e-5)
+    assert ns == splits and torch.equal(x_got, x_want) and torch.equal(h_got, h_want)
