@@ -41,10 +41,29 @@ struct Attn2Args {
   int causal;
   const int* kv_len_dev;
   float* lse;
+  long long* probe;   // tools only: s_memtime stamps of step 2 of workgroup (0, 0, 0), waves 0 and NWG ([group][16])
 };
 
 constexpr int A2_KVB = 64;        // keys per tile
 constexpr int A2_VSUB = 64 * 32 + 128;   // bytes of one [64 keys][16 d] V sub-image + the bank offset pad
+
+// value of the lane 32 away (the other half-wave), without the LDS crossbar: __shfl_xor(x, 32) compiles to ds_bpermute_b32, an
+// LDS-queue instruction, and an LDS-queue instruction issued by a wave behind its own LDS-DMA pieces waits until they have
+// landed (tools/attn_probe2.py: the row-max exchange right after the piece issue cost 600-1200 cycles per step).
+// v_permlane32_swap is VALU: {x_lo, x_lo} / {x_hi, x_hi} from one instruction.
+__device__ __forceinline__ float a2_other_half(float x, bool want_max) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float lo = __uint_as_float(r[0]), hi = __uint_as_float(r[1]);
+  return want_max ? fmaxf(lo, hi) : lo + hi;
+}
+
+// one 1 KiB LDS-DMA piece as buffer_load_dwordx4 ... lds (a free __device__ function: written inside a lambda of the kernel
+// the builtins make hipcc drop the kernel's host handle, see gemm_bf16.hip g4r_buffer_piece)
+__device__ __forceinline__ void a2_buffer_piece(const void* base, unsigned bytes, void* lds, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
 
 template <int D>
 __device__ __forceinline__ int a2_kswz(int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); }
@@ -98,34 +117,48 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
   const int ntiles = (kend + A2_KVB - 1) / A2_KVB;
   const int nsteps = (ntiles + NG - 1) / NG;
 
-  // ---- this lane's part of the wave's pieces: row inside the tile and element offset inside the row ----
-  int prow[PPW], pcol[PPW], pdst[PPW];
+  // ---- this lane's part of the wave's pieces.  Buffer form (round 3b): a 32-bit per-lane byte offset computed ONCE and a
+  //      scalar tile offset per step -- one SALU add (M0) + one VMEM instruction per piece.  The global_load_lds form
+  //      rebuilt a clamped 64-bit address per piece per step (two v_mul_lo, a v_mad_u64, ...: ~100 cycles per piece,
+  //      800-1100 per step and wave, tools/attn_probe2.py). ----
+  const int k_row_b = (int)p.k_row * 2, v_row_b = (int)p.v_row * 2;       // row pitches in bytes
+  const long k_span = ((long)(p.Tk - 1) * p.k_row + D) * 2, v_span = ((long)(p.Tk - 1) * p.v_row + D) * 2;
+  if (k_span > 0x7fffffffL || v_span > 0x7fffffffL) __builtin_trap();    // the host routes such tensors to the first form
+  int pvoff[PPW], pdst[PPW];
+  auto piece_row = [&](int j) {                                           // key row (inside the tile) of piece j of this lane
+    return j < KPW ? (wv + NWG * j) * RPP + lane / SLOTS : ((wv + NWG * (j - KPW)) & 1) * 32 + (lane >> 1);
+  };
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
     if (j < KPW) {
       const int pk = wv + NWG * j;
       const int row = pk * RPP + lane / SLOTS;
-      prow[j] = row;
-      pcol[j] = ((lane % SLOTS) ^ a2_kswz<D>(row)) * 8;
+      pvoff[j] = row * k_row_b + (((lane % SLOTS) ^ a2_kswz<D>(row)) * 8) * 2;
       pdst[j] = pk * 1024;
     } else {
       const int pv = wv + NWG * (j - KPW);
       const int dd = pv >> 1, half = pv & 1;
-      prow[j] = half * 32 + (lane >> 1);
-      pcol[j] = dd * 16 + (lane & 1) * 8;
+      pvoff[j] = (half * 32 + (lane >> 1)) * v_row_b + (dd * 16 + (lane & 1) * 8) * 2;
       pdst[j] = K_BYTES + dd * A2_VSUB + half * 1024;
     }
   }
   auto issue = [&](int tile, int buf) {
     const int j0 = tile * A2_KVB;
     char* dst = gbuf + buf * TILE_BYTES;
+    if (j0 + A2_KVB <= p.Tk) {                       // whole tile inside the keys (wave-uniform): scalar tile offset
+      const int ks = j0 * k_row_b, vs = j0 * v_row_b;
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-      int key = j0 + prow[j];
-      if (key > p.Tk - 1) key = p.Tk - 1;
-      const bf16_t* src = (j < KPW ? Kb + (size_t)key * p.k_row : Vb + (size_t)key * p.v_row) + pcol[j];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + pdst[j]), 16, 0, 0);
+      for (int j = 0; j < PPW; ++j)
+        a2_buffer_piece(j < KPW ? Kb : Vb, (unsigned)(j < KPW ? k_span : v_span), dst + pdst[j], pvoff[j], j < KPW ? ks : vs);
+    } else {                                         // ragged last tile: rows beyond the keys re-read row Tk - 1 (masked later)
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) {
+        const int r = piece_row(j);
+        int key = j0 + r;
+        if (key > p.Tk - 1) key = p.Tk - 1;
+        a2_buffer_piece(j < KPW ? Kb : Vb, (unsigned)(j < KPW ? k_span : v_span), dst + pdst[j],
+                        pvoff[j] + (key - r) * (j < KPW ? k_row_b : v_row_b), 0);
+      }
     }
   };
 
@@ -150,7 +183,7 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
     }
   }
   if (grp < ntiles) issue(grp, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0); builtin, not inline asm: the compiler's counter model sees it
   __builtin_amdgcn_s_barrier();
   bf16x8 qf[KSTEPS];
   {
@@ -165,14 +198,26 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const float sc2 = p.scale * 1.4426950408889634f;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0)
   __builtin_amdgcn_s_barrier();            // every wave holds its Q fragments: the staging buffer may be overwritten
 
   // state carried from phase A to phase B of a step
   float16v sacc[2];
-  float m_use = 0.f, alpha = 1.f, m_new = -INFINITY;
+  float m_use = 0.f, alpha = 1.f, m_new = -INFINITY, rs_a = 0.f;
   bool active = false;
+  const bool probing = p.probe != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wv == 0 && lane == 0;
+  long long* stamps = p.probe ? p.probe + grp * 16 : nullptr;
+#define A2_STAMP(slot, s_, dep)                                                       \
+  if (p.probe) {                                                                      \
+    float tmp_;                                                                       \
+    asm volatile("v_mov_b32 %0, %1" : "=v"(tmp_) : "v"(dep));                          \
+    if (probing && (s_) == 2) stamps[slot] = __builtin_amdgcn_s_memtime();            \
+  }
+  // Both phases read ALL their LDS fragments before the first MFMA that needs them (a scheduling fence pins the order): the
+  // compiler's own order was read -> s_waitcnt lgkmcnt(0) -> MFMA, sixteen times per phase, i.e. an LDS round trip in front
+  // of every MFMA of the first chain (QK: 1076 cycles for 16 MFMAs = 512 with the other wave of the SIMD in its VALU phase).
   auto phase_a = [&](int s) {
+    A2_STAMP(0, s, m_run);
     const int tile = s * NG + grp;
     const int buf = s & 1;
     const int j0 = tile * A2_KVB;
@@ -180,62 +225,113 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
     active = tile < ntiles && !(p.causal && j0 > qw0 + 31 + off);
     const char* kt = gbuf + buf * TILE_BYTES;
     if (active) {
+      // The 2 x KSTEPS K fragments go out back to back and every MFMA pair waits for ITS two reads only (counted lgkmcnt):
+      // QK = max(LDS time, MFMA time) instead of their sum.  The reads are inline asm because the compiler, given plain
+      // loads, puts s_waitcnt lgkmcnt(0) in front of every MFMA that consumes one (never a counted wait on ds_read_b128
+      // here), i.e. the first MFMA waited for all sixteen reads: 1076-1108 cycles for 16 MFMAs = 512.  Each wait is tied
+      // ("+v") to the fragments it releases, so the MFMA cannot move above it.
+      bf16x8 kf[2][KSTEPS];
+      const unsigned kbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(kt + k_row_off);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        const unsigned ka = kbase + ((unsigned)((kk * 2 + hi) ^ k_sw) << 4);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0][kk]) : "v"(ka) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[1][kk]) : "v"(ka), "n"(32 * D * 2) : "memory");
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-        const char* krow = kt + kb * 32 * (D * 2) + k_row_off;
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((kk * 2 + hi) ^ k_sw) << 4));
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sacc[kb], 0, 0, 0);
-        }
+      for (int kk = 0; kk < KSTEPS; ++kk) {            // two independent accumulator chains, interleaved
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(kf[0][kk]), "+v"(kf[1][kk]) : "n"(2 * (KSTEPS - 1 - kk)));
+        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][kk], qf[kk], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][kk], qf[kk], sacc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);             // ... and the next wait cannot move above it
       }
     }
-    if (tile + NG < ntiles) issue(tile + NG, buf ^ 1);     // the group's next tile (every wave carries its pieces)
+    if (active) { A2_STAMP(1, s, sacc[1][15]); }
+    A2_STAMP(2, s, m_run);
     if (active) {
-      // online softmax, first half: scores in the log2 domain, masks, row max
+      // online softmax, first half: masks and the row max of the RAW scores; the softmax scale (log2 domain) is applied to
+      // the max here and to the scores inside the exp2 argument (one fused multiply-add per score in phase B)
       const bool need_mask = (j0 + A2_KVB > p.Tk) || (p.causal && j0 + A2_KVB - 1 > qw0 + off);
-      float mt = -INFINITY;
+      float mt0 = -INFINITY, mt1 = -INFINITY;
       if (need_mask) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float sv = sacc[kb][r] * sc2;
-            if (key >= p.Tk || (p.causal && key > qi + off)) sv = -INFINITY;
-            sacc[kb][r] = sv;
-            mt = fmaxf(mt, sv);
-          }
-      } else {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            sacc[kb][r] *= sc2;
-            mt = fmaxf(mt, sacc[kb][r]);
+            if (key >= p.Tk || (p.causal && key > qi + off)) sacc[kb][r] = -INFINITY;
           }
       }
-      mt = fmaxf(mt, __shfl_xor(mt, 32));
-      m_new = fmaxf(m_run, mt);
-      m_use = m_new == -INFINITY ? 0.f : m_new;
-      alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-    }
-  };
-  auto phase_b = [&](int s) {
-    if (!active) return;
-    const char* kt = gbuf + (s & 1) * TILE_BYTES;
-    float rs = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(sacc[kb][r] - m_use);
-        sacc[kb][r] = e;
-        rs += e;
+        mt0 = fmaxf(mt0, sacc[0][r]);
+        mt1 = fmaxf(mt1, sacc[1][r]);
       }
-    rs += __shfl_xor(rs, 32);
+      const float mt = a2_other_half(fmaxf(mt0, mt1), true);
+      m_new = fmaxf(m_run, mt * sc2);
+      m_use = m_new == -INFINITY ? 0.f : m_new;
+      alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+      // the exponentials of the first 32 keys belong to phase A: with them the two phases carry about the same VALU time
+      // (A: QK MFMAs, max, 16 exp; B: 16 exp, sums, rescale, PV MFMAs), and on a SIMD one wave's MFMAs face the other's VALU
+      const float nm = -m_use;
+      float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[0][r], sc2, nm));
+        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[0][r + 1], sc2, nm));
+        sacc[0][r] = e0;
+        sacc[0][r + 1] = e1;
+        r0 += e0;
+        r1 += e1;
+      }
+      rs_a = r0 + r1;
+    }
+    A2_STAMP(3, s, alpha);
+  };
+  auto v_frag = [&](const char* vt, int kb, int hf, int d) {
+    const char* a = vt + d * 2 * A2_VSUB + (kb * 32 + hf * 16) * 32;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(a));
+    const short4v up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(a + 8 * 32));
+    const short8 vv = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+    return __builtin_bit_cast(bf16x8, vv);
+  };
+  auto phase_b = [&](int s) {
+    A2_STAMP(4, s, alpha);
+    const int tile = s * NG + grp;
+    const char* vt = gbuf + (s & 1) * TILE_BYTES + v_lane_off;
+    // every V^T fragment of the tile goes out BEFORE the exponentials, whose VALU time covers the LDS round trip; the pieces
+    // of the group's NEXT tile are issued behind them: the compiler puts s_waitcnt vmcnt(0) in front of any LDS read that
+    // follows an LDS-DMA instruction in program order (it cannot see that the DMA writes the other buffer), so the pieces
+    // must come after the step's last LDS read.  They land during exp / PV / the barrier (~1400 cycles).
+    bf16x8 vf[2][2][DB];
+    if (active) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int d = 0; d < DB; ++d) vf[kb][hf][d] = v_frag(vt, kb, hf, d);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (tile + NG < ntiles) issue(tile + NG, (s & 1) ^ 1);     // every wave carries its share of the pieces
+    A2_STAMP(9, s, m_run);
+    if (!active) return;
+    float rs0 = 0.f, rs1 = 0.f;
+    const float nm = -m_use;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[1][r], sc2, nm));
+      const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[1][r + 1], sc2, nm));
+      sacc[1][r] = e0;
+      sacc[1][r + 1] = e1;
+      rs0 += e0;
+      rs1 += e1;
+    }
+    const float rs = a2_other_half(rs_a + (rs0 + rs1), false);
     l_run = l_run * alpha + rs;
     m_run = m_new;
     if (!__all(alpha == 1.f)) {          // the running max moved for some row of this wave: rescale O (wave-uniform branch)
@@ -244,8 +340,9 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
     }
+    A2_STAMP(5, s, oacc[0][0]);
     // O^T += V^T P^T : A operand = 4 + 4 keys of this lane's d through two transpose reads
-    const char* vt = kt + v_lane_off;
+    bf16x8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -255,18 +352,17 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
         pw.y = pack_bf16x2(sacc[kb][hf * 8 + 2], sacc[kb][hf * 8 + 3]);
         pw.z = pack_bf16x2(sacc[kb][hf * 8 + 4], sacc[kb][hf * 8 + 5]);
         pw.w = pack_bf16x2(sacc[kb][hf * 8 + 6], sacc[kb][hf * 8 + 7]);
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-          const char* a = vt + d * 2 * A2_VSUB + (kb * 32 + hf * 16) * 32;
-          const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (short4v __attribute__((address_space(3)))*)(a));
-          const short4v up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (short4v __attribute__((address_space(3)))*)(a + 8 * 32));
-          const short8 vv = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
-          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, oacc[d], 0, 0, 0);
-        }
+        pf[kb][hf] = __builtin_bit_cast(bf16x8, pw);
       }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kb][hf][d], pf[kb][hf], oacc[d], 0, 0, 0);
+    A2_STAMP(6, s, oacc[DB - 1][15]);
   };
 
   if (PP) {
@@ -275,16 +371,21 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
       phase_a(s);
       __builtin_amdgcn_s_barrier();
       phase_b(s);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the group's next tile has landed (issued in phase A)
+      __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0): the group's next tile has landed.  The
+                                                           // builtin, not inline asm: the compiler's counter model sees it
+      A2_STAMP(7, s, m_run);
       __builtin_amdgcn_s_barrier();
+      A2_STAMP(8, s, m_run);
     }
     if (!(grp & 1)) __builtin_amdgcn_s_barrier();
   } else {
     for (int s = 0; s < nsteps; ++s) {
       phase_a(s);
       phase_b(s);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0x0070);
+      A2_STAMP(7, s, m_run);
       __builtin_amdgcn_s_barrier();                        // everyone's pieces landed; everyone is done with this step's buffers
+      A2_STAMP(8, s, m_run);
     }
   }
 
@@ -334,7 +435,7 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
                         pack_bf16x2(oacc[d][g * 4 + 2] * inv, oacc[d][g * 4 + 3] * inv)};
       *reinterpret_cast<uint2v*>(olds + ql * ORS + (d * 32 + g * 8 + 4 * hi) * 2) = w;
     }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave wrote and reads: in-order LDS, no barrier needed
+  __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): same wave wrote and reads, in-order LDS, no barrier needed
   constexpr int LPR = D / 8;                               // lanes per output row (16 bytes each)
   constexpr int RPI = 64 / LPR;                            // rows per wave instruction
 #pragma unroll
@@ -367,13 +468,16 @@ int launch_attn2(const Attn2Args& a, int B, hipStream_t st) {
 
 }  // namespace
 
+static long long* g_attn2_probe = nullptr;   // tools: device buffer for the phase stamps (tools/attn_probe2.py)
+extern "C" void g4r_attn2_debug_probe(void* ptr) { g_attn2_probe = (long long*)ptr; }
+
 // variant: 0 = production choice; otherwise NWG * 10 + NG of an instantiated form (tools / tests)
 int g4r_attn2_dispatch(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk, int head_dim,
                        long q_row, long k_row, long v_row, long o_row, long q_batch, long k_batch, long v_batch,
                        long o_batch, float scale, int causal, const int* kv_len_dev, float* lse, int variant,
                        void* stream) {
   Attn2Args a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_row, k_row, v_row, o_row,
-                 q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal, kv_len_dev, lse};
+                 q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal, kv_len_dev, lse, g_attn2_probe};
   hipStream_t st = (hipStream_t)stream;
   int rc = G4R_OK;
   // variant = NWG * 10 + NG; + 100 = the lock-step form (one barrier per step), which is what production runs: the

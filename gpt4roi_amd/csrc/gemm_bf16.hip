@@ -68,6 +68,28 @@ struct GemmArgs {
 constexpr int BK = 64;
 static int g_gemm_dbg = 0;   // tools only: ablation / A-B probe modes (g4r_gemm_debug_mode)
 
+// Workgroup -> (output tile, K slice).  The dispatcher deals consecutive linear workgroup ids (x fastest, then y) round robin
+// to the 8 XCDs; each XCD has its own L2.  The map hands every XCD one CONTIGUOUS run of the virtual ids
+// [slice][tile] (cdna_hip_programming.md 5.5 T1, bijective for any count): without K slices that is a run of neighbouring
+// tiles; with K slices an XCD works on as few slices as possible -- many tiles of ONE K window share the A rows and the W rows
+// of that window in its L2.  (Round 2 mapped tiles only and gave every XCD all the slices of a few tiles: on the LLaMA
+// down_proj, 64 tiles x 4 slices, every L2 then streamed the whole A matrix, 8 x 17 MB, and the K tile ran 1.7x the qkv's.)
+__device__ __forceinline__ void g4r_workgroup_tile_slice(int nwg, bool tile_major, int& tile, int& slice) {
+  if (tile_major) {                        // tools only (debug mode 11): the round-2 map, for A/B runs
+    const int wg = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    slice = blockIdx.y;
+    return;
+  }
+  const int total = nwg * (int)gridDim.y;
+  const int lin = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+  const int q = total >> 3, r = total & 7, xcd = lin & 7, idx = lin >> 3;
+  const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  slice = v / nwg;
+  tile = v - slice * nwg;
+}
+
 // waves per SIMD the kernel is allowed to assume = workgroups that fit the 160 KB LDS (<= 3)
 constexpr int gemm_waves_per_eu(int bm, int bn, int nw, int stages, int bk) {
   int blocks = (160 * 1024) / (stages * (bm + bn) * bk * 2);
@@ -431,11 +453,8 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
 
   // ---- XCD-aware bijective remap of the 1-D grid (cdna_hip_programming.md 5.5 T1) ----
   const int nwg = p.tiles_m * p.tiles_n;
-  int wg = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  int wg, split;
+  g4r_workgroup_tile_slice(nwg, p.dbg == 11, wg, split);
   // Tile order = which operand the co-scheduled workgroups of one XCD share through its L2:
   //   M fastest: same W panel (weights are the big operand when M << N: LLaMA / ViT projections);
   //   N fastest: same A tile (activations are the big operand when M >> N: the implicit-GEMM convs,
@@ -444,7 +463,6 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
   const int tile_m = p.n_fastest ? wg / p.tiles_n : wg % p.tiles_m;
   const int tile_n = p.n_fastest ? wg % p.tiles_n : wg / p.tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int split = blockIdx.y;
   const int t_begin = split * p.tiles_per_split;
   int t_end = t_begin + p.tiles_per_split;
   const int nt_total = p.K / BKT;
@@ -987,15 +1005,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   const int wm = wave >> 2, wn = wave & 3;
   const int grp = wm;  // waves w and w+4 share a SIMD
   const int nwg = p.tiles_m * p.tiles_n;
-  int wg = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  int wg, split;
+  g4r_workgroup_tile_slice(nwg, p.dbg == 11, wg, split);
   const int tile_m = p.n_fastest ? wg / p.tiles_n : wg % p.tiles_m;
   const int tile_n = p.n_fastest ? wg % p.tiles_n : wg / p.tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int split = blockIdx.y;
   const int t_begin = split * p.tiles_per_split;
   int t_end = t_begin + p.tiles_per_split;
   const int nt_total = p.K / BKT;
@@ -1268,15 +1282,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   const int wm = wave >> 2, wn = wave & 3;
   const int grp = wm;
   const int nwg = p.tiles_m * p.tiles_n;
-  int wg = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  int wg, split;
+  g4r_workgroup_tile_slice(nwg, p.dbg == 11, wg, split);
   const int tile_m = p.n_fastest ? wg / p.tiles_n : wg % p.tiles_m;
   const int tile_n = p.n_fastest ? wg % p.tiles_n : wg / p.tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int split = blockIdx.y;
   const int t_begin = split * p.tiles_per_split;
   int t_end = t_begin + p.tiles_per_split;
   const int nt_total = p.K / BKT;
@@ -1584,15 +1594,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nwg = p.tiles_m * p.tiles_n;
-  int wg = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  int wg, split;
+  g4r_workgroup_tile_slice(nwg, p.dbg == 11, wg, split);
   const int tile_m = p.n_fastest ? wg / p.tiles_n : wg % p.tiles_m;
   const int tile_n = p.n_fastest ? wg % p.tiles_n : wg / p.tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int split = blockIdx.y;
   const int t_begin = split * p.tiles_per_split;
   int t_end = t_begin + p.tiles_per_split;
   const int nt_total = p.K / BKT;
