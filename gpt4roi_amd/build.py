@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "lib", "libgpt4roi_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(os.path.dirname(HERE), "include"),
-         "-I", CSRC]
+         "-I", CSRC] + os.environ.get("G4R_EXTRA_HIPCC_FLAGS", "").split()      # tools: e.g. -DG4R_ATTN2_PROBE
 
 
 def _newest_header():

@@ -517,7 +517,10 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
   // (LLaMA prefill of one or two prompts); beyond that the first form is as fast or faster (8 x 699 tokens: 90.9 vs 94.0 us)
   const long wgs128 = (long)g4r_ceil_div(Tq, 128) * H * B;
   const bool second_form = g_attn_variant >= 10 || (g_attn_variant == 0 && Tq >= 32 && (head_dim == 64 || wgs128 <= 512));
-  if (second_form && o_row % 8 == 0 && o_batch % 8 == 0)   // 16-byte O rows
+  // the second form addresses K / V through 32-bit buffer offsets: a head's rows must span < 2 GiB (it traps otherwise)
+  const long kv_row = k_row > v_row ? k_row : v_row;
+  const bool spans_ok = ((long)(Tk > 0 ? Tk - 1 : 0) * kv_row + head_dim) * 2 < 0x7fffffffL;
+  if (second_form && spans_ok && o_row % 8 == 0 && o_batch % 8 == 0)   // 16-byte O rows
     return g4r_attn2_dispatch(Q, K, V, O, B, H, Tq, Tk, head_dim, q_row, k_row, v_row, o_row, q_batch, k_batch, v_batch,
                               o_batch, scale, causal, kv_len_dev, lse, g_attn_variant >= 10 ? g_attn_variant : 0, stream);
   AttnArgs a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_row, k_row, v_row, o_row,

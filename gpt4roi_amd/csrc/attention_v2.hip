@@ -205,6 +205,8 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
   float16v sacc[2];
   float m_use = 0.f, alpha = 1.f, m_new = -INFINITY, rs_a = 0.f;
   bool active = false;
+  // tools only (tools/attn_probe2.py; build with G4R_EXTRA_HIPCC_FLAGS=-DG4R_ATTN2_PROBE): s_memtime stamps of step 2
+#ifdef G4R_ATTN2_PROBE
   const bool probing = p.probe != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wv == 0 && lane == 0;
   long long* stamps = p.probe ? p.probe + grp * 16 : nullptr;
 #define A2_STAMP(slot, s_, dep)                                                       \
@@ -213,6 +215,9 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
     asm volatile("v_mov_b32 %0, %1" : "=v"(tmp_) : "v"(dep));                          \
     if (probing && (s_) == 2) stamps[slot] = __builtin_amdgcn_s_memtime();            \
   }
+#else
+#define A2_STAMP(slot, s_, dep)
+#endif
   // Both phases read ALL their LDS fragments before the first MFMA that needs them (a scheduling fence pins the order): the
   // compiler's own order was read -> s_waitcnt lgkmcnt(0) -> MFMA, sixteen times per phase, i.e. an LDS round trip in front
   // of every MFMA of the first chain (QK: 1076 cycles for 16 MFMAs = 512 with the other wave of the SIMD in its VALU phase).
@@ -481,7 +486,8 @@ int g4r_attn2_dispatch(const void* Q, const void* K, const void* V, void* O, int
   hipStream_t st = (hipStream_t)stream;
   int rc = G4R_OK;
   // variant = NWG * 10 + NG; + 100 = the lock-step form (one barrier per step), which is what production runs: the
-  // phase-offset form measured the same or slower (T = 767: 21.7 vs 21.7 us; ViT S = 577: 10.7 vs 9.5 us)
+  // phase-offset form measures the same or slower (T = 767: 21.2 vs 21.1 us; ViT S = 577: 10.4 vs 9.5 us; T = 2048: 81.4 vs
+  // 79.8, profiles/r03_attention_stamps.txt) -- the step is bound by the LDS reads of K and V, which both forms issue alike
   if (head_dim == 128) {
     if (variant == 0) variant = 142;
     if (variant == 42) rc = launch_attn2<128, 4, 2>(a, B, st);

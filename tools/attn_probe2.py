@@ -1,4 +1,6 @@
-"""Phase stamps (s_memtime) of one wave per key group inside csrc/attention_v2.hip, step 2 of the heaviest workgroup."""
+"""Phase stamps (s_memtime) of one wave per key group inside csrc/attention_v2.hip, step 2 of the heaviest workgroup.
+The stamps are compiled in only with  G4R_EXTRA_HIPCC_FLAGS=-DG4R_ATTN2_PROBE python -m gpt4roi_amd.build --force
+(rebuild without the flag afterwards: the production library carries no probe code)."""
 import math, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
