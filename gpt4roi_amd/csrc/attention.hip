@@ -513,10 +513,9 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
   G4R_REQUIRE(!causal || Tk >= Tq, "flash_attn: causal needs Tk >= Tq");
   // the prefill shapes of the path go to the second form; a handful of query rows against a long cache (the host-loop
   // decode, Tq < 32) stays on the first form, whose 2 x 64-row workgroups waste less on an almost empty query block
-  // second form: every head_dim-64 launch of the path, and head_dim 128 while the 128-row query blocks number at most 512
-  // (LLaMA prefill of one or two prompts); beyond that the first form is as fast or faster (8 x 699 tokens: 90.9 vs 94.0 us)
-  const long wgs128 = (long)g4r_ceil_div(Tq, 128) * H * B;
-  const bool second_form = g_attn_variant >= 10 || (g_attn_variant == 0 && Tq >= 32 && (head_dim == 64 || wgs128 <= 512));
+  // second form: every launch with Tq >= 32 (since its second pass it also wins the many-block launches of the training
+  // batch: 8 x 699 tokens 89.4 vs 93.2 us, profiles/r03_attention_time_final.txt)
+  const bool second_form = g_attn_variant >= 10 || (g_attn_variant == 0 && Tq >= 32);
   // the second form addresses K / V through 32-bit buffer offsets: a head's rows must span < 2 GiB (it traps otherwise)
   const long kv_row = k_row > v_row ? k_row : v_row;
   const bool spans_ok = ((long)(Tk > 0 ? Tk - 1 : 0) * kv_row + head_dim) * 2 < 0x7fffffffL;

@@ -471,6 +471,7 @@ int launch_attn2(const Attn2Args& a, int B, hipStream_t st) {
   return G4R_OK;
 }
 
+
 }  // namespace
 
 static long long* g_attn2_probe = nullptr;   // tools: device buffer for the phase stamps (tools/attn_probe2.py)
