@@ -46,8 +46,6 @@ def timeit(fn, iters=20, warm=3):
 
 R = lambda *s: (torch.randn(*s, device=dev) * 0.7).to(torch.bfloat16)
 VARS = {128: [42, 142, 41], 64: [24, 124, 42, 142, 41]}
-if "--v3" in sys.argv:                                 # + the third form (64 rows per wave): 300 + NWG * 10 + NG
-    VARS = {128: [142, 322], 64: [124, 142, 314, 322]}
 ok = True
 if "--time-only" not in sys.argv:
     cases = [(1, 32, 128, 767, 767, True), (1, 16, 64, 577, 577, False), (2, 4, 128, 33, 33, True), (1, 8, 128, 100, 300, True),

@@ -1,7 +1,7 @@
 // tools/probe/attn_fwd3_experiment.hip -- NOT built into the library: the third form of the attention forward tried in round 3
 // (64 query rows per wave, one wave per SIMD, the softmax of one row block interleaved with the MFMAs of the other; lazy
-// reference maximum so that O is not rescaled every step).  It is correct (tools/attn_v2_check.py --v3 of commit "third form
-// experiment": ALL OK) and SLOWER than the second form: T = 767 28.6 vs 20.4 us, T = 2048 110 vs 76.5, ViT 13.2 vs 8.9
+// reference maximum so that O is not rescaled every step).  It is correct (tools/attn_v2_check.py with the variants 322 / 314 added,
+// in the tree of commit cff7a94^: ALL OK) and SLOWER than the second form: T = 767 28.6 vs 20.4 us, T = 2048 110 vs 76.5, ViT 13.2 vs 8.9
 // (profiles/r03_attention_third_form.txt).  Reason, from the ISA: above 256 registers hipcc produces MFMA results in AGPR form
 // and VALU instructions cannot read AGPRs, so every step carries 445 (D = 128) / 288 (D = 64) v_accvgpr_read / _write
 // copies between the two halves of the register file (128 of them for the O accumulators at the loop top) -- ~40 % more VALU
