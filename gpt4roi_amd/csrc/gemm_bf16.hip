@@ -596,6 +596,39 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
       }
+    } else if constexpr (STYLE == 3) {
+      // every fragment read of the K tile goes out back to back and each k-step's MFMAs wait for THEIR reads only (counted
+      // lgkmcnt).  The reads are inline asm: given plain loads the compiler orders them read, read, s_waitcnt lgkmcnt(0),
+      // MFMA -- an LDS round trip in front of every k-step (the interleaved style above: ~150 cycles x KK per K tile against
+      // 32 x KK of MFMA on a 64 x 64 tile) -- and the burst style below makes the first MFMA wait for ALL the reads.  Each
+      // wait is tied ("+v") to the fragments it releases so that their MFMAs cannot move above it.
+      bf16x8 af[KK][TM], wf[KK][TN];
+      const unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(sa + a_row_off);
+      const unsigned lb = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(sb + b_row_off);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const unsigned slot = (unsigned)(((kk * 2 + fhi) ^ fsw) << 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[kk][i]) : "v"(la + slot), "n"(i * 32 * ROWB) : "memory");
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[kk][j]) : "v"(lb + slot), "n"(j * 32 * ROWB) : "memory");
+      }
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[kk][0]) : "n"((TM + TN) * (KK - 1 - kk)));
+#pragma unroll
+        for (int i = 1; i < TM; ++i) asm volatile("" : "+v"(af[kk][i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(wf[kk][j]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else {
       // one workgroup per CU: request every fragment of the K tile up front, then one MFMA burst
       bf16x8 af[KK][TM], wf[KK][TN];
@@ -1944,7 +1977,7 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 4: return launch_tile<64, 128, 1, 4, AMODE, true>(p, stream);
     case 5: return launch_tile<128, 128, 2, 2, AMODE, true, 3>(p, stream);   // 96 KB ring
     case 6: return launch_tile<128, 128, 2, 2, AMODE, true, 4>(p, stream);   // 128 KB ring
-    case 7: return launch_tile<128, 128, 2, 4, AMODE, true, 4>(p, stream);   // 8 waves, 64x32 wave tiles
+    case 7: return launch_tile<128, 128, 2, 4, AMODE, true, 4, 64, 3>(p, stream);   // 8 waves, 64x32 wave tiles; counted-wait fragment pipeline
     case 8: return launch_tile<256, 128, 4, 2, AMODE, true, 3>(p, stream);   // 144 KB ring, 8 waves
     case 9: return launch_tile<256, 256, 2, 4, AMODE, true, 2>(p, stream);   // 128 KB, wave tile 128x64
     case 10: return launch_tile<128, 128, 2, 4, AMODE, true, 2>(p, stream);  // 8 waves x (64x32), 2 wg/CU
@@ -1953,9 +1986,16 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     // were removed.)  Small-M shapes (CLIP ViT, M = 577; K = 1024 is only 16 K tiles): fewer workgroups than CUs, so
     // what matters is ONE workgroup's latency -> deep LDS-DMA rings instead of co-resident workgroups.
     case 12: return launch_tile<64, 128, 1, 4, AMODE, true, 4>(p, stream);   // 96 KB ring of 4
-    case 13: return launch_tile<64, 128, 1, 4, AMODE, true, 3>(p, stream);   // 72 KB ring of 3: 2 wg/CU
-    case 14: return launch_tile<64, 64, 2, 2, AMODE, true, 4>(p, stream);    // 64 KB ring of 4: 2 wg/CU
+    case 13: return launch_tile<64, 128, 1, 4, AMODE, true, 3, 64, 3>(p, stream);   // 72 KB ring of 3: 2 wg/CU; counted-wait fragment pipeline
+    case 14: return launch_tile<64, 64, 2, 2, AMODE, true, 4, 64, 3>(p, stream);    // 64 KB ring of 4: 2 wg/CU; counted-wait fragment pipeline
     case 15: return launch_tile<128, 64, 2, 2, AMODE, true, 4>(p, stream);   // 96 KB ring of 4
+    // A/B arms of round 3c (dense GEMM only): tiles 13 / 14 / 7 with the compiler's own read order (STYLE 0; the counted-wait
+    // fragment pipeline, STYLE 3, is their production form: ViT qkv 10.9 -> 10.8 us, o 8.2 -> 7.9, fc1 15.5 -> 14.6, fc2 21.1 ->
+    // 20.4, LLaMA o_proj 41.7 -> 40.2), and the two-stage 128 x 128 tile WITH the pipeline (no gain: 68.3 vs 69.6 us)
+    case 40: if constexpr (AMODE == 0) return launch_tile<128, 128, 2, 2, AMODE, true, 2, 64, 3>(p, stream); else break;
+    case 43: if constexpr (AMODE == 0) return launch_tile<64, 128, 1, 4, AMODE, true, 3>(p, stream); else break;
+    case 44: if constexpr (AMODE == 0) return launch_tile<64, 64, 2, 2, AMODE, true, 4>(p, stream); else break;
+    case 47: if constexpr (AMODE == 0) return launch_tile<128, 128, 2, 4, AMODE, true, 4>(p, stream); else break;
     case 26: return launch_w4<AMODE>(p, stream);                                 // 256x256, 4 waves x (128x128): one wave per SIMD, K 32 ring of 4
     case 22: return launch_pp<AMODE>(p, stream);                                 // 256x256 ping-pong (4 barriers / K tile)
     case 24:                                                                     // 256x256 ping-pong, K 32 ring of 4
@@ -1970,8 +2010,9 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 31: return launch_pp32<AMODE, false, 256, 256, true, 1>(p, stream);     // rotated single-barrier schedule (A/B arm for dense)
     case 33: return launch_pp32<AMODE, false, 256, 256, true, 0>(p, stream);     // two-barrier schedule (A/B arm for the convs)
     case 23: return launch_pp<AMODE, true>(p, stream);                           // same + s_memtime stamps into ws (tools only)
-    default: return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");
+    default: break;
   }
+  return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");
 }
 
 }  // namespace
