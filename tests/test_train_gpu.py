@@ -668,6 +668,32 @@ def test_sharded_stage2_trainer_equals_unsharded_on_one_rank():
     assert tb.steps == 3 and len(sd["buckets"]) == len(tb.sharded.buckets)
 
 
+def test_sharded_stage2_trainer_steps_on_a_region_less_batch():
+    """The same region-less batch through ShardedFullTrainer: every bucket's reduce-scatter must be fed -- a rank
+    that reported no `spi_module.*` gradient would raise in `_wait()` while the other ranks block in the collective.  The step
+    runs, the region module's masters do not move, the decoder's do."""
+    from gpt4roi_amd.train import ShardedFullTrainer
+    model, (_, img, _, _) = _tiny_stage2(seed=21)
+    ids = syn.token_ids(vocab_base=990)
+    g = torch.Generator().manual_seed(5)
+    P = 8
+    prompt = torch.stack([syn.prompt_ids(ids, P, 0, g, sys_len=6, question_len=9, vocab_base=990) for _ in range(2)]).to(DEV)
+    labels = prompt.clone()
+    labels[:, :8 + P * P] = -100
+    labels[labels >= 990] = -100
+    none = [torch.zeros(0, 4, device=DEV), torch.zeros(0, 4, device=DEV)]
+    tr = ShardedFullTrainer(model, lr=1e-4, max_grad_norm=1.0, bucket_bytes=1 << 20)
+    spi_before = {k: p.detach().clone() for k, p in model.spi_module.named_parameters()}
+    wo_before = model.llama.layers[0]["wo"].clone()
+    loss = tr.step(prompt, img, none, labels)
+    assert torch.isfinite(loss).all() and tr.steps == 1
+    for k, p in model.spi_module.named_parameters():
+        assert float((p.detach() - spi_before[k]).abs().max()) == 0.0, k
+    assert not torch.equal(model.llama.layers[0]["wo"], wo_before)
+    loss2 = tr.step(prompt, img, none, labels)
+    assert torch.isfinite(loss2).all() and float(loss2) < float(loss) + 1e-2
+
+
 def test_region_less_batch_steps_with_zero_region_gradients():
     """A batch without any region (text-only / image-only sample): the reference keeps training through a zero dummy term
     (gpt4roi/models/layers.py:314-317, spi_llava.py:94-108).  RegionTrainer must report a ZERO gradient for every region-
