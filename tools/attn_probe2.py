@@ -8,10 +8,10 @@ from gpt4roi_amd import kernels as K, _lib
 lib = _lib.lib()
 import ctypes
 R = lambda *s: (torch.randn(*s, device="cuda") * 0.7).to(torch.bfloat16)
-# stamp slots of A2_STAMP in program order: 0 A start, 1 QK done, 2 V reads + pieces issued, 3 max / alpha / first 16 exp done,
-# 4 B start, 5 last 16 exp / sums / rescale done, 6 PV done, 7 vmcnt(0) done, 8 barrier passed
-order = [0, 1, 2, 3, 4, 5, 6, 7, 8]
-names = {1: "QK done", 2: "V reads + pieces issued", 3: "max/alpha/exp16 done (A end)", 4: "B start", 5: "exp16/rescale done", 6: "PV done",
+# stamp slots of A2_STAMP in program order: 0 A start, 1 QK done, 2 (unused), 3 max/alpha done, 4 B start, 9 V reads + pieces issued,
+# 5 exp/rescale done, 6 PV done, 7 vmcnt(0) done, 8 barrier passed
+order = [0, 1, 3, 4, 9, 5, 6, 7, 8]
+names = {1: "QK done", 3: "max/alpha done (A end)", 4: "B start", 9: "V reads + pieces issued", 5: "exp/rescale done", 6: "PV done",
          7: "vmcnt(0) done", 8: "barrier passed"}
 for (B, H, D, T, c, var) in [(1, 32, 128, 767, True, 142), (1, 32, 128, 767, True, 42), (1, 16, 64, 577, False, 124), (1, 16, 64, 577, False, 24)]:
     q, k, v = R(B, T, H * D), R(B, T, H * D), R(B, T, H * D)
