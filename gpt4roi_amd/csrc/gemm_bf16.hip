@@ -2021,6 +2021,9 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
 extern "C" {
 
 // tools/ only: ablation switch for the GEMM main loop (0 = normal).  Not declared in include/.
+//   1 / 2: skip the staging / the compute of the generic kernel's loop;  7: taps-outermost K order of the conv (A/B arm);
+//   8: pieces by global_load_lds instead of buffer loads;  9 / 10: force the M-fastest / N-fastest tile order;
+//   11: the round-2 workgroup -> tile map (tiles only, every XCD sees all K slices);  100 + v: GEMV variant v.
 void g4r_gemm_debug_mode(int mode) { g_gemm_dbg = mode; }
 
 // See include/g4r_kernels.h for the contract.
