@@ -261,6 +261,20 @@ def long_k_plan(M, N, K):
     return None
 
 
+def partial_wave_plan(M, N, K):
+    """(tile_cfg, K slices) for a long-K shape that covers a quarter to a half of one wave of 256 x 256 tiles -- the column
+    remainder `wave_split` leaves behind in the training batch (5592 x 1280 x {11008, 12288, 22016}: 110 tiles) -- or None.
+    K slices on the ring ping-pong kernel until tiles x slices fills the 256 CUs: 153 vs 186 us at K = 11008, 169 vs 215 at
+    12288, 300 vs 377 at 22016 against the two-stage 128 x 128 tile (profiles/r03_gemm_partial_wave.txt).  Not for K = 4096
+    (equal) and not for fp32 outputs (lm_head remainder: 118 vs 91 us -- the fp32 partials cost more than the wave gains)."""
+    if not (K >= 8192 and K % 64 == 0 and (-(-M // 256) * 256) <= 1.1 * M):
+        return None
+    t256 = -(-M // 256) * -(-N // 256)
+    if 64 < t256 <= 128:
+        return 24, 256 // t256
+    return None
+
+
 def gemm_partials(a, w, splits, tile_cfg):
     """a [M,K] @ w[N,K]^T as fp32 K-slice partials [n_slices, M, N] WITHOUT the reduce launch (the consumer combines them:
     rmsnorm_splitk).  Returns (partials, n_slices)."""
@@ -368,6 +382,8 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
         # round 3: with the pieces as buffer loads the 192x256 ring ping-pong tile x 4 K-slices (64 x 4 = 256 workgroups) is
         # the best form: 85.0 us vs 88.0 (256x256 x 5) and 87.6 (one wave per SIMD x 5), reduce included
         tile_cfg, splits = long_k_plan(M, N, K)
+    if tile_cfg is None and splits == 1 and out.dtype != torch.float32 and partial_wave_plan(M, N, K) is not None:
+        tile_cfg, splits = partial_wave_plan(M, N, K)
     if tile_cfg is None:
         tile_cfg = pick_tile(M, N, K)
         if splits == 1 and tile_cfg == 4 and K >= 2048 and K % 64 == 0 and M > 1:

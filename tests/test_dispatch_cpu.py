@@ -21,6 +21,17 @@ def test_gemm_tile_dispatch(M, N, Kd, tile, main):
     assert K.wave_split(M, N, Kd) == main
 
 
+@pytest.mark.parametrize("M,N,Kd,want", [
+    (5592, 1280, 11008, (24, 2)), (5592, 1280, 22016, (24, 2)), (5592, 1280, 12288, (24, 2)),   # training-batch column remainders
+    (5592, 1280, 4096, None),          # K = 4096: the two-stage tile is as fast
+    (767, 4096, 11008, None),          # down_proj at batch 1: long_k_plan's shape (48 tiles), not this one
+    (767, 10246, 4096, None),          # lm_head remainder
+    (5592, 2816, 11008, None),         # 242 tiles: a full wave on its own
+])
+def test_partial_wave_plan(M, N, Kd, want):
+    assert K.partial_wave_plan(M, N, Kd) == want
+
+
 @pytest.mark.parametrize("M,Cout,Kd,want", [
     (36864, 1024, 9216, (24, 1)),      # a 192^2 level on its own (the fuse rounds use conv3x3_mlvl: one launch for all levels)
     (2304, 1024, 9216, (4, 1)),
