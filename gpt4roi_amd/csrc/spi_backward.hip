@@ -136,10 +136,9 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const bf16_t* _
   float db[8], dg[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) db[k] = dg[k] = 0.f;
-  for (int p = p0 + pl; p < p1; p += plc) {
-    const size_t off = ((size_t)b * HW + p) * C + cv * 8;
-    const F8 zv = ld8(z + off);
-    const F8 d = ld8f(dy + off);
+  // four pixels' loads (4 x 48 B per lane) go out before the first is used: with one load pair in flight the pass ran at
+  // ~1.2 TB/s (profiles/r03_train_step_kernel_stats.csv: 565 us average per launch), i.e. on the HBM latency, not its bandwidth
+  auto accumulate = [&](const F8& zv, const F8& d) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float dyh = (a.v[k] * zv.v[k] + s.v[k] > 0.f) ? d.v[k] : 0.f;
@@ -149,11 +148,53 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const bf16_t* _
       s1 += gm.v[k] * dyh;
       s2 += gm.v[k] * dyh * xh;
     }
-  }
+  };
+  int p = p0 + pl;
+  for (; p + 3 * plc < p1; p += 4 * plc) {
+    F8 zv[4], d[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    unsafeAtomicAdd(dgamma + cv * 8 + k, dg[k]);
-    unsafeAtomicAdd(dbeta + cv * 8 + k, db[k]);
+    for (int u = 0; u < 4; ++u) {
+      const size_t off = ((size_t)b * HW + p + u * plc) * C + cv * 8;
+      zv[u] = ld8(z + off);
+      d[u] = ld8f(dy + off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) accumulate(zv[u], d[u]);
+  }
+  for (; p < p1; p += plc) {
+    const size_t off = ((size_t)b * HW + p) * C + cv * 8;
+    accumulate(ld8(z + off), ld8f(dy + off));
+  }
+  // the workgroup's pixel lanes are combined in LDS before the atomics, and the launch uses ~512 workgroups instead of 2048:
+  // 8.4 M fp32 atomics onto 2 x 1024 addresses per launch were the cost of this pass, not its 1.8 GB of input
+  __shared__ float comb[2][2048];
+  const bool combine = plc > 1 && C <= 2048;          // wave-uniform
+  if (combine) {
+    for (int l = 1; l < plc; ++l) {                   // lanes pl = 1 .. plc-1 hand their sums to lane pl = 0, one at a time
+      if (pl == l) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          comb[0][cv * 8 + k] = dg[k];
+          comb[1][cv * 8 + k] = db[k];
+        }
+      }
+      __syncthreads();
+      if (pl == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          dg[k] += comb[0][cv * 8 + k];
+          db[k] += comb[1][cv * 8 + k];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (!combine || pl == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      unsafeAtomicAdd(dgamma + cv * 8 + k, dg[k]);
+      unsafeAtomicAdd(dbeta + cv * 8 + k, db[k]);
+    }
   }
   red[0][tid] = s1;
   red[1][tid] = s2;
@@ -423,7 +464,9 @@ int g4r_gn_relu_bwd_nhwc_bf16(const void* z, const float* dy, const float* affin
   const int nvec = C / 8;
   G4R_REQUIRE(nvec <= 256 && 256 % nvec == 0 && G <= 256, "gn_relu_bwd: C/8 must divide 256");
   G4R_REQUIRE(z && dy && affine && gamma && stats && dgamma && dbeta && gsum && dz, "gn_relu_bwd: null pointer");
-  int chunks = 256;
+  int chunks = 512 / B;                               // ~512 workgroups per launch (two per CU): few atomics, enough loads in flight
+  if (chunks < 16) chunks = 16;
+  if (chunks > 256) chunks = 256;
   int ppb = g4r_ceil_div(HW, chunks);
   if (ppb < 32) ppb = 32;
   chunks = g4r_ceil_div(HW, ppb);
