@@ -937,11 +937,14 @@ def swiglu_il_bwd(gu, dy):
     return dgu
 
 
-def rope_qkv_bwd(dq, dk, dv, cos, sin, heads, head_dim, pos0=0):
-    """dq, dk, dv [T, heads*D] (row-strided ok) -> d(qkv) [T, 3*heads*D]."""
+def rope_qkv_bwd(dq, dk, dv, cos, sin, heads, head_dim, pos0=0, out=None):
+    """dq, dk, dv [T, heads*D] (row-strided ok) -> d(qkv) [T, 3*heads*D] (`out`: a dense [T, 3*heads*D] view to fill)."""
     _bf16(dq, dk, dv)
     T, HD = dq.shape
-    out = torch.empty((T, 3 * HD), dtype=torch.bfloat16, device=dq.device)
+    if out is None:
+        out = torch.empty((T, 3 * HD), dtype=torch.bfloat16, device=dq.device)
+    _bf16(out)
+    assert out.shape == (T, 3 * HD) and out.is_contiguous()
     _launch("g4r_rope_qkv_bwd_bf16", (_p(dq), _p(dk), _p(dv), _p(cos), _p(sin), _p(out), T, heads, head_dim, pos0,
                                       dq.stride(0), dk.stride(0), dv.stride(0), _stream(dq),),
             tag="g4r_rope_qkv_bwd_bf16")

@@ -180,10 +180,12 @@ class LlamaDecoder:
         L = self.layers[li]
         C, H, D = self.hidden, self.heads, self.head_dim
         h = K.rmsnorm(x, L['n1'], self.eps)
-        qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
         q = torch.empty((B, T, C), dtype=torch.bfloat16, device=x.device)
-        for b in range(B):
-            K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, 0)
+        # RoPE and the K/V writes ride in the projection's epilogue (as in `forward`: one launch instead of 1 + B, same bits)
+        if K.gemm_qkv_rope(h, L['wqkv'], B, T, H, D, q, self.kc[li, :B], self.vc[li, :B], self.cos, self.sin, 0) is None:
+            qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
+            for b in range(B):
+                K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, 0)
         lse = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
         a = K.flash_attn(q, self.kc[li, :B, :T], self.vc[li, :B, :T], H, 1.0 / math.sqrt(D), True, lse=lse)
         x1 = K.gemm(a.view(B * T, C), L['wo'], residual=x)
@@ -256,8 +258,9 @@ class LlamaDecoder:
             da = K.gemm(dx1, L['wo_t']).view(B, T, C)
             dq, dk, dv = K.flash_attn_bwd(S['q'], self.kc[li, :B, :T], self.vc[li, :B, :T], S['a'], da, S['lse'], H,
                                           scale, True)
-            dqkv = torch.cat([K.rope_qkv_bwd(dq[b], dk[b], dv[b], self.cos, self.sin, H, D, 0) for b in range(B)], 0) \
-                if B > 1 else K.rope_qkv_bwd(dq[0], dk[0], dv[0], self.cos, self.sin, H, D, 0)
+            dqkv = torch.empty((B * T, 3 * C), dtype=torch.bfloat16, device=dq.device)
+            for b in range(B):                               # every sequence's rows written in place (no concatenation pass)
+                K.rope_qkv_bwd(dq[b], dk[b], dv[b], self.cos, self.sin, H, D, 0, out=dqkv[b * T:(b + 1) * T])
             dh = K.gemm(dqkv, L['wqkv_t'])
             if tw:
                 grads[f"{li}.wo"] = K.linear_wgrad(dx1, S['a'].view(B * T, C))

@@ -810,7 +810,7 @@ def test_split_k_reduce_folded_into_the_next_rmsnorm_is_bit_identical():
     assert torch.equal(x_got, x_want) and torch.equal(h_got, h_want)
 
 
-@pytest.mark.parametrize("B,T,pos0,tile", [(1, 767, 0, 28), (1, 767, 0, 24), (2, 300, 17, 28)])
+@pytest.mark.parametrize("B,T,pos0,tile", [(1, 767, 0, 28), (1, 767, 0, 24), (2, 300, 17, 28), (3, 211, 5, 24)])
 def test_qkv_projection_with_rope_and_cache_append_in_the_epilogue(B, T, pos0, tile):
     """g4r_gemm_qkv_rope_bf16 against the two launches it replaces (g4r_gemm_bf16_nt + g4r_rope_qkv_bf16 per sequence): the
     rotated queries and the appended cache rows must be bit-identical, cache rows outside [pos0, pos0 + T) untouched."""
