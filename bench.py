@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent batch-1 requests in flight per GPU, one HIP stream each (1 = strictly serial)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="batch-1 requests merged into ONE launch sequence per step (continuous batching: the weights are "
+                         "streamed once for all of them); value counts every request's region tokens")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--train-steps", type=int, default=4,
                     help="extra (not part of `value`): timed stage-1 training steps (SURVEY.md 8d config 3: batch 8 per GPU, "
@@ -87,9 +90,10 @@ def make_inputs(args, ids, device, seed):
     from gpt4roi_amd import synthetic as syn
     g = torch.Generator().manual_seed(seed)
     P = args.image_size // 14
-    image = torch.randn(1, 3, args.image_size, args.image_size, generator=g).to(device)
-    boxes = [syn.boxes(args.rois, g).to(device)]
-    prompt = syn.prompt_ids(ids, P, args.rois, g)[None].to(device)
+    B = max(1, args.batch)
+    image = torch.randn(B, 3, args.image_size, args.image_size, generator=g).to(device)
+    boxes = [syn.boxes(args.rois, g).to(device) for _ in range(B)]
+    prompt = torch.stack([syn.prompt_ids(ids, P, args.rois, g) for _ in range(B)]).to(device)
     return image, boxes, prompt
 
 
@@ -301,7 +305,7 @@ def main():
     seg0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     dt_local = replicas.timed_steps(step, args.steps, torch.cuda.synchronize, dist)
     device_allocs_in_timed_region = torch.cuda.memory_stats(device).get("num_device_alloc", 0) - seg0
-    _, dt = replicas.aggregate(args.rois * args.steps, dt_local, dist, device=device if backend == "nccl" else "cpu")
+    _, dt = replicas.aggregate(args.rois * args.batch * args.steps, dt_local, dist, device=device if backend == "nccl" else "cpu")
     # the same K steps strictly serial on one stream (per-image latency), reported beside the headline
     serial_step()
     dt_serial = replicas.timed_steps(serial_step, args.steps, torch.cuda.synchronize, dist) if len(ctxs) > 1 else dt_local
@@ -389,7 +393,7 @@ def main():
     if rank == 0 and args.decode_tokens > 0:
         # configs[1] continues with greedy decode from the KV cache; reported beside the headline,
         # never inside it (weight-streaming bound: 13.5 GB of bf16 weights per token)
-        emb = model.embed_inputs(prompt, image, reqs[0])
+        emb = model.embed_inputs(prompt[:1], image[:1], model.prepare_boxes(boxes[:1], args.image_size))
         model.llama.greedy_graph(emb, 8)                                  # warm-up + graph capture
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -463,7 +467,7 @@ def main():
 
     if rank == 0:
         P = args.image_size // 14
-        total_regions = args.rois * args.steps * world
+        total_regions = args.rois * args.batch * args.steps * world
         line = {
             "metric": "region-tokens/sec (336^2 img, 32 RoIs, CLIP ViT-L/14 + region module + LLaMA-7B fwd)",
             "value": round(total_regions / dt, 2), "unit": "region-tokens/s", "n_gpus": world, "steps": args.steps,
@@ -472,8 +476,9 @@ def main():
             "value_per_gpu": round(total_regions / dt / world, 2),
             "in_flight_requests_per_gpu": n_ctx, "hipMalloc_calls_in_timed_region": device_allocs_in_timed_region,
             "hipgraph": graph_ok, "hipgraph_error": last.get("graph_error"),
-            "single_stream": {"ms_per_image": round(1e3 * dt_serial / args.steps, 3),
-                              "region_tokens_per_s_per_gpu": round(args.rois * args.steps / dt_serial, 2)},
+            "requests_per_step": args.batch,
+            "single_stream": {"ms_per_image": round(1e3 * dt_serial / args.steps / args.batch, 3),
+                              "region_tokens_per_s_per_gpu": round(args.rois * args.batch * args.steps / dt_serial, 2)},
             "config": {"workload": f"configs[1]: 1x{args.image_size}^2 image, {args.rois} RoIs, batch 1 per GPU, "
                                    f"ViT-L/14(23 blocks) + SPI(P={P}) + LLaMA-7B({args.llama_layers} layers) prefill "
                                    f"T={prompt.size(1)} with full logits",

@@ -3,7 +3,9 @@
     python -m gpt4roi_amd.build [-v] [--force]
 
 One object per .hip file under gpt4roi_amd/csrc (rebuilt when the source or any header is
-newer), linked into ONE shared library with a plain C ABI (include/*.h).  The .so is built
+newer), linked into ONE shared library with a plain C ABI (include/*.h).  The files of the inference path
+(F16_SOURCES) are compiled a second time with -DG4R_F16: the same kernels storing IEEE half instead of bfloat16 -- the
+reference's serving dtype (gpt4roi/app.py:74-98) -- under the entry-point names of include/g4r_f16_names.h.  The .so is built
 in-tree so that it travels with the repository snapshot to the GPU box.
 """
 import os
@@ -19,6 +21,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(os.path.dirname(HERE), "include"),
          "-I", CSRC] + os.environ.get("G4R_EXTRA_HIPCC_FLAGS", "").split()      # tools: e.g. -DG4R_ATTN2_PROBE
+
+
+# the inference path (ViT, region module, projector, splice, LLaMA prefill + decode); training-only files stay bf16
+F16_SOURCES = ("gemm_bf16.hip", "attention.hip", "attention_v2.hip", "norm.hip", "elementwise.hip", "roi_align.hip")
+F16_NAMES = os.path.join(os.path.dirname(HERE), "include", "g4r_f16_names.h")
 
 
 def _newest_header():
@@ -41,6 +48,11 @@ def build(verbose=False, force=False):
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
             jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+        if s in F16_SOURCES:
+            obj16 = os.path.join(OBJ, s[:-4] + ".f16.o")
+            objs.append(obj16)
+            if force or not os.path.exists(obj16) or os.path.getmtime(obj16) < max(os.path.getmtime(src), hdr_t):
+                jobs.append([HIPCC, *FLAGS, "-DG4R_F16", "-include", F16_NAMES, "-c", src, "-o", obj16])
 
     def run(cmd):
         if verbose:

@@ -101,7 +101,7 @@ class ClipImageProcessor:
         return K.image_preprocess(image_u8_hwc, size or self.size)
 
 
-def load_vision_tower(source, device="cuda", select_layer=-2):
+def load_vision_tower(source, device="cuda", select_layer=-2, dtype=torch.bfloat16):
     """`CLIPVisionModel.from_pretrained(config.mm_vision_tower)` (llava.py:48,61): `source` is a local HF CLIP directory
     (config.json with a `vision_config` or flat vision fields) or an HF-keyed state dict."""
     from .vit import ClipVisionTower
@@ -119,7 +119,7 @@ def load_vision_tower(source, device="cuda", select_layer=-2):
         raise FileNotFoundError(
             f"vision tower {source!r}: a hub name cannot be resolved here (no network); pass a local directory or state dict")
     pre = "vision_model." if "vision_model.pre_layrnorm.weight" in sd else ""
-    tower = ClipVisionTower(sd, heads=heads, eps=eps, device=device, select_layer=select_layer)
+    tower = ClipVisionTower(sd, heads=heads, eps=eps, device=device, select_layer=select_layer, dtype=dtype)
     n_pos = sd[pre + "embeddings.position_embedding.weight"].shape[0]
     tower.image_size = image_size or int(round((n_pos - 1) ** 0.5)) * tower.patch
     return tower
@@ -133,7 +133,8 @@ def model_config(model, extra=None):
     cfg = dict(architectures=["SPILlavaMPTForCausalLM"], model_type="llava", hidden_size=dec.hidden,
                intermediate_size=dec.inter, num_attention_heads=dec.heads, num_hidden_layers=len(dec.layers),
                vocab_size=dec.vocab, rms_norm_eps=dec.eps, max_position_embeddings=dec.max_positions,
-               rope_theta=getattr(dec, "theta", 10000.0), torch_dtype="bfloat16", use_mm_proj=True,
+               rope_theta=getattr(dec, "theta", 10000.0),
+               torch_dtype="float16" if getattr(dec, "dtype", None) is torch.float16 else "bfloat16", use_mm_proj=True,
                mm_hidden_size=model.model.mm_projector.in_features,
                mm_vision_tower=getattr(mc, "mm_vision_tower", None),
                mm_vision_select_layer=getattr(mc, "mm_vision_select_layer", -2),
@@ -154,8 +155,11 @@ def save_pretrained(model, path, safe_serialization=True, max_shard_bytes=5 << 3
 
 def from_pretrained(cls, path, device="cuda", vision_tower=None, tokenizer=None, max_positions=None, torch_dtype=None,
                     low_cpu_mem_usage=None, use_cache=None, **_):
-    """Builds the MI355X model from an HF-layout directory.  `torch_dtype` / `low_cpu_mem_usage` / `use_cache` are accepted
-    for call compatibility (app.py:70-75); the kernels compute in bf16 with fp32 accumulation whatever the stored dtype."""
+    """Builds the MI355X model from an HF-layout directory.  `torch_dtype` selects the 16-bit storage type of the kernels:
+    torch.float16 as app.py:70-75 passes it (the reference serves in fp16), torch.bfloat16 (the default, and what anything
+    else maps to) as the training scripts use; accumulation is fp32 either way.  `low_cpu_mem_usage` / `use_cache` are
+    accepted for call compatibility."""
+    dtype = torch.float16 if torch_dtype in (torch.float16, "float16", "fp16", "half") else torch.bfloat16
     from . import synthetic as syn
     from .llama import LlamaDecoder
     from .spi_llava import SPILlavaLlamaModel
@@ -165,19 +169,24 @@ def from_pretrained(cls, path, device="cuda", vision_tower=None, tokenizer=None,
     dec = LlamaDecoder(sd, heads=cfg["num_attention_heads"], eps=cfg.get("rms_norm_eps", 1e-6),
                        theta=cfg.get("rope_theta", 10000.0),
                        max_positions=max_positions or min(cfg.get("max_position_embeddings", 2048), 4096), device=device,
-                       num_layers=cfg.get("num_hidden_layers"))
+                       num_layers=cfg.get("num_hidden_layers"), dtype=dtype)
     dec.theta = cfg.get("rope_theta", 10000.0)
     src = vision_tower if vision_tower is not None else cfg.get("mm_vision_tower")
-    tower = load_vision_tower(src, device=device, select_layer=cfg.get("mm_vision_select_layer", -2)) \
+    tower = load_vision_tower(src, device=device, select_layer=cfg.get("mm_vision_select_layer", -2), dtype=dtype) \
         if src is not None else None
     # token ids: from the config when it carries them (checkpoints this path wrote), else the positions
     # initialize_vision_tokenizer gives them (spi_llava.py:248-258) at the END of the vocabulary; a tokenizer, when
     # given, is authoritative (app.py:84-104 reads the ids off the tokenizer).
-    ids = syn.token_ids(vocab - 5)      # the LAST five rows: <im_patch>, <bbox>, <point>, <im_start>, <im_end> (after [PAD])
+    # with mm_use_im_start_end the tokenizer appends <im_patch>, <bbox>, <point>, <im_start>, <im_end> (five rows
+    # at the end of the vocabulary); without it only <im_patch>, <bbox>, <point> (three rows) -- read the flag FIRST
+    use_se = bool(cfg.get("mm_use_im_start_end", True))
+    ids = syn.token_ids(vocab - 5 if use_se else vocab - 3)
+    if not use_se:
+        ids.im_start_token = ids.im_end_token = -1          # never present in a prompt of such a checkpoint
     for k in ("im_patch_token", "im_start_token", "im_end_token", "bbox_token", "point_token"):
         if k in cfg:
             setattr(ids, k, int(cfg[k]))
-    ids.use_im_start_end = bool(cfg.get("mm_use_im_start_end", True))
+    ids.use_im_start_end = use_se
     ids.vocab = vocab
     ids.mm_vision_tower = cfg.get("mm_vision_tower")
     ids.mm_vision_select_layer = cfg.get("mm_vision_select_layer", -2)

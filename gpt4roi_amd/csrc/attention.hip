@@ -18,16 +18,15 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int KVB = 64;       // keys per tile
 constexpr int VT_LD = 68;     // Vt row stride in elements (136 B: conflict-free ds_read_b64)
 
 struct AttnArgs {
-  const bf16_t* Q;
-  const bf16_t* K;
-  const bf16_t* V;
-  bf16_t* O;
+  const h16_t* Q;
+  const h16_t* K;
+  const h16_t* V;
+  h16_t* O;
   long q_row, k_row, v_row, o_row;      // row strides (elements)
   long q_batch, k_batch, v_batch, o_batch;
   int Tq, Tk, H;
@@ -56,8 +55,8 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p) 
   constexpr int NVU = 16 * SLOTS / NT;    // V units (4 keys x one 8-wide d slot) per thread
   static_assert(KVB * SLOTS % NT == 0 && 16 * SLOTS % NT == 0, "staging split");
   if (p.kv_len_dev) p.Tk = *p.kv_len_dev + p.Tq;  // cached positions before this call + the new rows
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[KVB * D];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[D * VT_LD];
+  __shared__ __attribute__((aligned(16))) h16_t Ks[KVB * D];
+  __shared__ __attribute__((aligned(16))) h16_t Vt[D * VT_LD];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, ql = lane & 31;
@@ -65,17 +64,17 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p) 
   const int qblock = blockIdx.x * QB;
   const int qi = qblock + wave * 32 + ql;
   const int off = p.Tk - p.Tq;
-  const bf16_t* Qb = p.Q + (size_t)b * p.q_batch + (size_t)h * D;
-  const bf16_t* Kb = p.K + (size_t)b * p.k_batch + (size_t)h * D;
-  const bf16_t* Vb = p.V + (size_t)b * p.v_batch + (size_t)h * D;
+  const h16_t* Qb = p.Q + (size_t)b * p.q_batch + (size_t)h * D;
+  const h16_t* Kb = p.K + (size_t)b * p.k_batch + (size_t)h * D;
+  const h16_t* Vb = p.V + (size_t)b * p.v_batch + (size_t)h * D;
 
   // Q fragments (B operand: lane holds Q[q = lane&31][d = kk*16 + hi*8 .. +7])
-  bf16x8 qf[KSTEPS];
+  h16x8 qf[KSTEPS];
   {
     const int qr = qi < p.Tq ? qi : p.Tq - 1;
-    const bf16_t* qrow = Qb + (size_t)qr * p.q_row + hi * 8;
+    const h16_t* qrow = Qb + (size_t)qr * p.q_row + hi * 8;
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
+    for (int kk = 0; kk < KSTEPS; ++kk) qf[kk] = *reinterpret_cast<const h16x8*>(qrow + kk * 16);
   }
 
   float16v oacc[DB];
@@ -157,8 +156,8 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p) 
       const int sw = k_swz<D>(row);
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((kk * 2 + hi) ^ sw) << 4));
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sacc[kb], 0, 0, 0);
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(krow + (((kk * 2 + hi) ^ sw) << 4));
+        sacc[kb] = G4R_MFMA_32X32X16(kf, qf[kk], sacc[kb], 0, 0, 0);
       }
     }
 
@@ -213,19 +212,19 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p) 
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         uint4v pw;
-        pw.x = pack_bf16x2(sacc[kb][hf * 8 + 0], sacc[kb][hf * 8 + 1]);
-        pw.y = pack_bf16x2(sacc[kb][hf * 8 + 2], sacc[kb][hf * 8 + 3]);
-        pw.z = pack_bf16x2(sacc[kb][hf * 8 + 4], sacc[kb][hf * 8 + 5]);
-        pw.w = pack_bf16x2(sacc[kb][hf * 8 + 6], sacc[kb][hf * 8 + 7]);
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+        pw.x = pack_h16x2(sacc[kb][hf * 8 + 0], sacc[kb][hf * 8 + 1]);
+        pw.y = pack_h16x2(sacc[kb][hf * 8 + 2], sacc[kb][hf * 8 + 3]);
+        pw.z = pack_h16x2(sacc[kb][hf * 8 + 4], sacc[kb][hf * 8 + 5]);
+        pw.w = pack_h16x2(sacc[kb][hf * 8 + 6], sacc[kb][hf * 8 + 7]);
+        const h16x8 pf = __builtin_bit_cast(h16x8, pw);
         const int kbase = kb * 32 + hf * 16 + 4 * hi;
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
-          const bf16_t* vrow = Vt + (d * 32 + ql) * VT_LD + kbase;
+          const h16_t* vrow = Vt + (d * 32 + ql) * VT_LD + kbase;
           const uint2v lo = *reinterpret_cast<const uint2v*>(vrow);
           const uint2v hi2 = *reinterpret_cast<const uint2v*>(vrow + 8);
           const uint4v vw = {lo.x, lo.y, hi2.x, hi2.y};
-          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, oacc[d], 0, 0, 0);
+          oacc[d] = G4R_MFMA_32X32X16(__builtin_bit_cast(h16x8, vw), pf, oacc[d], 0, 0, 0);
         }
       }
     __syncthreads();
@@ -235,13 +234,13 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p) 
   if (qi < p.Tq) {
     if (p.lse && hi == 0) p.lse[((size_t)b * p.H + h) * p.Tq + qi] = m_run + __log2f(l_run);
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    bf16_t* orow = p.O + (size_t)b * p.o_batch + (size_t)qi * p.o_row + (size_t)h * D;
+    h16_t* orow = p.O + (size_t)b * p.o_batch + (size_t)qi * p.o_row + (size_t)h * D;
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const uint2v w = {pack_bf16x2(oacc[d][g * 4] * inv, oacc[d][g * 4 + 1] * inv),
-                          pack_bf16x2(oacc[d][g * 4 + 2] * inv, oacc[d][g * 4 + 3] * inv)};
+        const uint2v w = {pack_h16x2(oacc[d][g * 4] * inv, oacc[d][g * 4 + 1] * inv),
+                          pack_h16x2(oacc[d][g * 4 + 2] * inv, oacc[d][g * 4 + 3] * inv)};
         *reinterpret_cast<uint2v*>(orow + d * 32 + g * 8 + 4 * hi) = w;
       }
   }
@@ -263,14 +262,14 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_fwd_kernel(AttnArgs p) 
 // p is kept in fp32 for the PV product (the tiled kernel rounds it to bf16 for the MFMA).
 // ---------------------------------------------------------------------------------------------
 struct DecodeAttnArgs {
-  const bf16_t* Q;     // [H * D] (already rotated), or null when `qkv` is given
-  const bf16_t* qkv;   // optional raw projection row [3 * H * D] (q | k | v) of the new token: RoPE is applied here, the
+  const h16_t* Q;     // [H * D] (already rotated), or null when `qkv` is given
+  const h16_t* qkv;   // optional raw projection row [3 * H * D] (q | k | v) of the new token: RoPE is applied here, the
                        // rotated k and the v are appended to the caches at row Tk - 1 (what g4r_rope_qkv_bf16 would do)
   const float* cs;     // cos / sin tables [maxT][D / 2] (with qkv)
   const float* sn;
-  bf16_t* K;           // [Tmax][k_row]
-  bf16_t* V;
-  bf16_t* O;           // [H * D]
+  h16_t* K;           // [Tmax][k_row]
+  h16_t* V;
+  h16_t* O;           // [H * D]
   float* ws;           // [H][S][D + 2]
   unsigned* cnt;       // [H], zero before the first call; left zero by every call
   long k_row, v_row;
@@ -282,8 +281,8 @@ struct DecodeAttnArgs {
 };
 
 __device__ __forceinline__ void unpack8(const uint4v& r, float* f) {
-  f[0] = bf16lo(r.x); f[1] = bf16hi(r.x); f[2] = bf16lo(r.y); f[3] = bf16hi(r.y);
-  f[4] = bf16lo(r.z); f[5] = bf16hi(r.z); f[6] = bf16lo(r.w); f[7] = bf16hi(r.w);
+  f[0] = h16lo(r.x); f[1] = h16hi(r.x); f[2] = h16lo(r.y); f[3] = h16hi(r.y);
+  f[4] = h16lo(r.z); f[5] = h16hi(r.z); f[6] = h16lo(r.w); f[7] = h16hi(r.w);
 }
 
 template <int D>
@@ -315,8 +314,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeAttnArgs p) {
   const int j_begin = s * chunk;
   const int j_end = j_begin + chunk < Tk ? j_begin + chunk : Tk;
   const float sc2 = p.scale * 1.4426950408889634f;
-  const bf16_t* Kb = p.K + (size_t)h * D + sub * 8;
-  const bf16_t* Vb = p.V + (size_t)h * D + sub * 8;
+  const h16_t* Kb = p.K + (size_t)h * D + sub * 8;
+  const h16_t* Vb = p.V + (size_t)h * D + sub * 8;
   uint4v kv[NB], vv[NB];
   auto load_block = [&](int j0) {
 #pragma unroll
@@ -356,14 +355,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeAttnArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = second ? __builtin_fmaf(a[e], c[e], b[e] * sn[e]) : __builtin_fmaf(a[e], c[e], -(b[e] * sn[e]));
     {
-      const uint4v qr = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+      const uint4v qr = {pack_h16x2(o[0], o[1]), pack_h16x2(o[2], o[3]), pack_h16x2(o[4], o[5]), pack_h16x2(o[6], o[7])};
       unpack8(qr, q);
     }
     unpack8(*reinterpret_cast<const uint4v*>(p.qkv + HD + own), a);
     unpack8(*reinterpret_cast<const uint4v*>(p.qkv + HD + oth), b);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = second ? __builtin_fmaf(a[e], c[e], b[e] * sn[e]) : __builtin_fmaf(a[e], c[e], -(b[e] * sn[e]));
-    k_new = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+    k_new = {pack_h16x2(o[0], o[1]), pack_h16x2(o[2], o[3]), pack_h16x2(o[4], o[5]), pack_h16x2(o[6], o[7])};
     v_new = *reinterpret_cast<const uint4v*>(p.qkv + 2 * HD + own);
     if (s == 0 && wave == 0 && ks == 0) {                      // append the new row for the tokens to come
       *reinterpret_cast<uint4v*>(p.K + (size_t)pos * p.k_row + own) = k_new;
@@ -424,7 +423,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeAttnArgs p) {
     }
   }
   if (S == 1 && !p.defer) {
-    if (tid < D) p.O[(size_t)h * D + tid] = f32_to_bf16(acc / L);
+    if (tid < D) p.O[(size_t)h * D + tid] = f32_to_h16(acc / L);
     return;
   }
   if (p.defer) {                      // the consumer merges: plain stores, the kernel boundary publishes them
@@ -477,7 +476,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeAttnArgs p) {
         }
       }
     }
-    p.O[(size_t)h * D + tid] = f32_to_bf16(a2 / Lt);
+    p.O[(size_t)h * D + tid] = f32_to_h16(a2 / Lt);
   }
   if (tid == 0) __hip_atomic_store(p.cnt + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -495,7 +494,9 @@ int g4r_attn2_dispatch(const void* Q, const void* K, const void* V, void* O, int
 
 extern "C" {
 
+#ifndef G4R_F16
 void g4r_attn_debug_variant(int v) { g_attn_variant = v; }
+#endif
 
 // Q [B][Tq][H*D-strided rows], K/V [B][Tk][...], O [B][Tq][...]; all bf16; row/batch strides in
 // elements (multiples of 8).  head_dim 64 or 128.  causal: query i attends keys <= i + (Tk - Tq).
@@ -522,7 +523,7 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
   if (second_form && spans_ok && o_row % 8 == 0 && o_batch % 8 == 0)   // 16-byte O rows
     return g4r_attn2_dispatch(Q, K, V, O, B, H, Tq, Tk, head_dim, q_row, k_row, v_row, o_row, q_batch, k_batch, v_batch,
                               o_batch, scale, causal, kv_len_dev, lse, g_attn_variant >= 10 ? g_attn_variant : 0, stream);
-  AttnArgs a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_row, k_row, v_row, o_row,
+  AttnArgs a = {(const h16_t*)Q, (const h16_t*)K, (const h16_t*)V, (h16_t*)O, q_row, k_row, v_row, o_row,
                 q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal, kv_len_dev, lse};
   // 64 query rows per workgroup (2 waves): ~2x the workgroups of a 128-row block for the short
   // sequences of this path (577 / ~800 tokens) and finer causal load balance
@@ -571,7 +572,7 @@ int g4r_attn_decode_bf16(const void* Q, const void* qkv, const float* cos_tab, c
   G4R_REQUIRE(splits == 1 || defer_merge || (workspace && counters), "attn_decode: split keys need workspace and counters");
   G4R_REQUIRE(k_row % 8 == 0 && v_row % 8 == 0 && q_batch % 8 == 0 && k_batch % 8 == 0 && v_batch % 8 == 0 &&
                   o_batch % 8 == 0, "attn_decode: strides must keep 16-byte alignment");
-  DecodeAttnArgs a = {(const bf16_t*)Q, (const bf16_t*)qkv, cos_tab, sin_tab, (bf16_t*)K, (bf16_t*)V, (bf16_t*)O,
+  DecodeAttnArgs a = {(const h16_t*)Q, (const h16_t*)qkv, cos_tab, sin_tab, (h16_t*)K, (h16_t*)V, (h16_t*)O,
                       workspace, counters, k_row, v_row, Tk, splits, H, scale, kv_len_dev, defer_merge,
                       q_batch, k_batch, v_batch, o_batch};
   dim3 grid(splits, H, batch);

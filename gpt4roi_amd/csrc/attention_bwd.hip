@@ -17,14 +17,13 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int TB = 64;     // rows of the streamed tile (keys for dQ, queries for dK/dV)
 constexpr int T_LD = 68;   // row stride of a transposed tile (136 B: conflict-free 8-byte reads)
 
 struct AttnBwdArgs {
-  const bf16_t *Q, *K, *V, *O, *dO;
-  bf16_t *dQ, *dK, *dV;
+  const h16_t *Q, *K, *V, *O, *dO;
+  h16_t *dQ, *dK, *dV;
   const float* lse;  // [B][H][Tq], log2 domain (forward)
   float* delta;      // [B][H][Tq]
   long q_row, k_row, v_row, o_row, do_row, dq_row, dk_row, dv_row;
@@ -41,7 +40,7 @@ __device__ __forceinline__ int row_swz(int row) {
 
 // 64 rows x D of a [rows, H*D]-strided matrix -> LDS, row-major with the 16-byte slots of a row XOR-swizzled
 template <int D, int NT>
-__device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, long row_stride, int r0, int rmax,
+__device__ __forceinline__ void stage_rows(h16_t* dst, const h16_t* src, long row_stride, int r0, int rmax,
                                            int tid) {
   constexpr int SLOTS = D / 8;
 #pragma unroll
@@ -58,7 +57,7 @@ __device__ __forceinline__ void stage_rows(bf16_t* dst, const bf16_t* src, long 
 // the same 64 rows TRANSPOSED: dst[d][row], stride T_LD.  A thread takes 4 consecutive rows x 8 columns and
 // writes, for each column, the 4 rows as one 8-byte store.
 template <int D, int NT>
-__device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src, long row_stride, int r0,
+__device__ __forceinline__ void stage_transposed(h16_t* dst, const h16_t* src, long row_stride, int r0,
                                                  int rmax, int tid) {
   constexpr int SLOTS = D / 8;
 #pragma unroll
@@ -84,25 +83,25 @@ __device__ __forceinline__ void stage_transposed(bf16_t* dst, const bf16_t* src,
 }
 
 template <int D>
-__device__ __forceinline__ bf16x8 frag_rows(const bf16_t* tile, int row, int kk, int hi) {
-  return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(tile) + row * (D * 2) +
+__device__ __forceinline__ h16x8 frag_rows(const h16_t* tile, int row, int kk, int hi) {
+  return *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(tile) + row * (D * 2) +
                                           (((kk * 2 + hi) ^ row_swz<D>(row)) << 4));
 }
 
 // A operand from a transposed tile: row (= head-dim index), 8 of the 16 contraction indices of this MFMA
 // step in the permuted order the C-layout registers of the other operand already have.
-__device__ __forceinline__ bf16x8 frag_transposed(const bf16_t* tile, int row, int base) {
-  const bf16_t* r = tile + row * T_LD + base;
+__device__ __forceinline__ h16x8 frag_transposed(const h16_t* tile, int row, int base) {
+  const h16_t* r = tile + row * T_LD + base;
   const uint2v lo = *reinterpret_cast<const uint2v*>(r);
   const uint2v hi2 = *reinterpret_cast<const uint2v*>(r + 8);
   const uint4v w = {lo.x, lo.y, hi2.x, hi2.y};
-  return __builtin_bit_cast(bf16x8, w);
+  return __builtin_bit_cast(h16x8, w);
 }
 
-__device__ __forceinline__ bf16x8 pack8(const float* v) {
-  const uint4v w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                    pack_bf16x2(v[6], v[7])};
-  return __builtin_bit_cast(bf16x8, w);
+__device__ __forceinline__ h16x8 pack8(const float* v) {
+  const uint4v w = {pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]),
+                    pack_h16x2(v[6], v[7])};
+  return __builtin_bit_cast(h16x8, w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -124,9 +123,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnBwdArgs p, int B) {
     {
       const uint4v o = *reinterpret_cast<const uint4v*>(p.O + (size_t)b * p.o_batch + (size_t)q * p.o_row + h * D + l * 8);
       const uint4v g = *reinterpret_cast<const uint4v*>(p.dO + (size_t)b * p.do_batch + (size_t)q * p.do_row + h * D + l * 8);
-      acc = bf16lo(o.x) * bf16lo(g.x) + bf16hi(o.x) * bf16hi(g.x) + bf16lo(o.y) * bf16lo(g.y) +
-            bf16hi(o.y) * bf16hi(g.y) + bf16lo(o.z) * bf16lo(g.z) + bf16hi(o.z) * bf16hi(g.z) +
-            bf16lo(o.w) * bf16lo(g.w) + bf16hi(o.w) * bf16hi(g.w);
+      acc = h16lo(o.x) * h16lo(g.x) + h16hi(o.x) * h16hi(g.x) + h16lo(o.y) * h16lo(g.y) +
+            h16hi(o.y) * h16hi(g.y) + h16lo(o.z) * h16lo(g.z) + h16hi(o.z) * h16hi(g.z) +
+            h16lo(o.w) * h16lo(g.w) + h16hi(o.w) * h16hi(g.w);
     }
 #pragma unroll
     for (int s = LPR / 2; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
@@ -143,9 +142,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(AttnBwdArgs p) 
   constexpr int QB = NW * 32;
   constexpr int KSTEPS = D / 16;
   constexpr int DB = D / 32;
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[TB * D];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[TB * D];
-  __shared__ __attribute__((aligned(16))) bf16_t Kt[D * T_LD];
+  __shared__ __attribute__((aligned(16))) h16_t Ks[TB * D];
+  __shared__ __attribute__((aligned(16))) h16_t Vs[TB * D];
+  __shared__ __attribute__((aligned(16))) h16_t Kt[D * T_LD];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, ql = lane & 31;
@@ -153,18 +152,18 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(AttnBwdArgs p) 
   const int qblock = blockIdx.x * QB;
   const int qi = qblock + wave * 32 + ql;
   const int off = p.Tk - p.Tq;
-  const bf16_t* Kb = p.K + (size_t)b * p.k_batch + (size_t)h * D;
-  const bf16_t* Vb = p.V + (size_t)b * p.v_batch + (size_t)h * D;
+  const h16_t* Kb = p.K + (size_t)b * p.k_batch + (size_t)h * D;
+  const h16_t* Vb = p.V + (size_t)b * p.v_batch + (size_t)h * D;
   const int qr = qi < p.Tq ? qi : p.Tq - 1;
 
-  bf16x8 qf[KSTEPS], dof[KSTEPS];
+  h16x8 qf[KSTEPS], dof[KSTEPS];
   {
-    const bf16_t* qrow = p.Q + (size_t)b * p.q_batch + (size_t)qr * p.q_row + (size_t)h * D + hi * 8;
-    const bf16_t* grow = p.dO + (size_t)b * p.do_batch + (size_t)qr * p.do_row + (size_t)h * D + hi * 8;
+    const h16_t* qrow = p.Q + (size_t)b * p.q_batch + (size_t)qr * p.q_row + (size_t)h * D + hi * 8;
+    const h16_t* grow = p.dO + (size_t)b * p.do_batch + (size_t)qr * p.do_row + (size_t)h * D + hi * 8;
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
-      qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + kk * 16);
-      dof[kk] = *reinterpret_cast<const bf16x8*>(grow + kk * 16);
+      qf[kk] = *reinterpret_cast<const h16x8*>(qrow + kk * 16);
+      dof[kk] = *reinterpret_cast<const h16x8*>(grow + kk * 16);
     }
   }
   const float lse_i = p.lse[((size_t)b * p.H + h) * p.Tq + qr];
@@ -195,8 +194,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(AttnBwdArgs p) 
       const int row = kb * 32 + ql;
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Ks, row, kk, hi), qf[kk], sacc, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Vs, row, kk, hi), dof[kk], dpacc, 0, 0, 0);
+        sacc = G4R_MFMA_32X32X16(frag_rows<D>(Ks, row, kk, hi), qf[kk], sacc, 0, 0, 0);
+        dpacc = G4R_MFMA_32X32X16(frag_rows<D>(Vs, row, kk, hi), dof[kk], dpacc, 0, 0, 0);
       }
       float ds[16];
 #pragma unroll
@@ -208,23 +207,23 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(AttnBwdArgs p) 
       }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 pf = pack8(ds + hf * 8);
+        const h16x8 pf = pack8(ds + hf * 8);
         const int kbase = kb * 32 + hf * 16 + 4 * hi;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
-          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(Kt, d * 32 + ql, kbase), pf, oacc[d], 0, 0, 0);
+          oacc[d] = G4R_MFMA_32X32X16(frag_transposed(Kt, d * 32 + ql, kbase), pf, oacc[d], 0, 0, 0);
       }
     }
     __syncthreads();
   }
   if (qi < p.Tq) {
-    bf16_t* orow = p.dQ + (size_t)b * p.dq_batch + (size_t)qi * p.dq_row + (size_t)h * D;
+    h16_t* orow = p.dQ + (size_t)b * p.dq_batch + (size_t)qi * p.dq_row + (size_t)h * D;
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const uint2v w = {pack_bf16x2(oacc[d][g * 4], oacc[d][g * 4 + 1]),
-                          pack_bf16x2(oacc[d][g * 4 + 2], oacc[d][g * 4 + 3])};
+        const uint2v w = {pack_h16x2(oacc[d][g * 4], oacc[d][g * 4 + 1]),
+                          pack_h16x2(oacc[d][g * 4 + 2], oacc[d][g * 4 + 3])};
         *reinterpret_cast<uint2v*>(orow + d * 32 + g * 8 + 4 * hi) = w;
       }
   }
@@ -240,10 +239,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnBwdArgs p)
   constexpr int KSTEPS = D / 16;
   constexpr int DB = D / 32;
   extern __shared__ __attribute__((aligned(16))) char dkv_smem[];  // 67.5 KB at D = 128: dynamic
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(dkv_smem);
-  bf16_t* Gs = Qs + TB * D;        // dO rows
-  bf16_t* Qt = Gs + TB * D;
-  bf16_t* Gt = Qt + D * T_LD;      // dO transposed
+  h16_t* Qs = reinterpret_cast<h16_t*>(dkv_smem);
+  h16_t* Gs = Qs + TB * D;        // dO rows
+  h16_t* Qt = Gs + TB * D;
+  h16_t* Gt = Qt + D * T_LD;      // dO transposed
   float* lse_s = reinterpret_cast<float*>(Gt + D * T_LD);
   float* delta_s = lse_s + TB;
 
@@ -253,18 +252,18 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnBwdArgs p)
   const int kblock = blockIdx.x * KB;
   const int kj = kblock + wave * 32 + ql;  // this lane's key
   const int off = p.Tk - p.Tq;
-  const bf16_t* Qb = p.Q + (size_t)b * p.q_batch + (size_t)h * D;
-  const bf16_t* Gb = p.dO + (size_t)b * p.do_batch + (size_t)h * D;
+  const h16_t* Qb = p.Q + (size_t)b * p.q_batch + (size_t)h * D;
+  const h16_t* Gb = p.dO + (size_t)b * p.do_batch + (size_t)h * D;
   const int kr = kj < p.Tk ? kj : p.Tk - 1;
 
-  bf16x8 kf[KSTEPS], vf[KSTEPS];
+  h16x8 kf[KSTEPS], vf[KSTEPS];
   {
-    const bf16_t* krow = p.K + (size_t)b * p.k_batch + (size_t)kr * p.k_row + (size_t)h * D + hi * 8;
-    const bf16_t* vrow = p.V + (size_t)b * p.v_batch + (size_t)kr * p.v_row + (size_t)h * D + hi * 8;
+    const h16_t* krow = p.K + (size_t)b * p.k_batch + (size_t)kr * p.k_row + (size_t)h * D + hi * 8;
+    const h16_t* vrow = p.V + (size_t)b * p.v_batch + (size_t)kr * p.v_row + (size_t)h * D + hi * 8;
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
-      kf[kk] = *reinterpret_cast<const bf16x8*>(krow + kk * 16);
-      vf[kk] = *reinterpret_cast<const bf16x8*>(vrow + kk * 16);
+      kf[kk] = *reinterpret_cast<const h16x8*>(krow + kk * 16);
+      vf[kk] = *reinterpret_cast<const h16x8*>(vrow + kk * 16);
     }
   }
   const float sc2 = p.scale * 1.4426950408889634f;
@@ -302,8 +301,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnBwdArgs p)
       const int row = qb * 32 + ql;
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Qs, row, kk, hi), kf[kk], sacc, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Gs, row, kk, hi), vf[kk], dpacc, 0, 0, 0);
+        sacc = G4R_MFMA_32X32X16(frag_rows<D>(Qs, row, kk, hi), kf[kk], sacc, 0, 0, 0);
+        dpacc = G4R_MFMA_32X32X16(frag_rows<D>(Gs, row, kk, hi), vf[kk], dpacc, 0, 0, 0);
       }
       float pr[16], ds[16];
 #pragma unroll
@@ -322,29 +321,29 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnBwdArgs p)
       }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const bf16x8 pf = pack8(pr + hf * 8);
-        const bf16x8 sf = pack8(ds + hf * 8);
+        const h16x8 pf = pack8(pr + hf * 8);
+        const h16x8 sf = pack8(ds + hf * 8);
         const int ibase = qb * 32 + hf * 16 + 4 * hi;
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
-          dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(Gt, d * 32 + ql, ibase), pf, dvacc[d], 0, 0, 0);
-          dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(Qt, d * 32 + ql, ibase), sf, dkacc[d], 0, 0, 0);
+          dvacc[d] = G4R_MFMA_32X32X16(frag_transposed(Gt, d * 32 + ql, ibase), pf, dvacc[d], 0, 0, 0);
+          dkacc[d] = G4R_MFMA_32X32X16(frag_transposed(Qt, d * 32 + ql, ibase), sf, dkacc[d], 0, 0, 0);
         }
       }
     }
     __syncthreads();
   }
   if (kj < p.Tk) {
-    bf16_t* krow = p.dK + (size_t)b * p.dk_batch + (size_t)kj * p.dk_row + (size_t)h * D;
-    bf16_t* vrow = p.dV + (size_t)b * p.dv_batch + (size_t)kj * p.dv_row + (size_t)h * D;
+    h16_t* krow = p.dK + (size_t)b * p.dk_batch + (size_t)kj * p.dk_row + (size_t)h * D;
+    h16_t* vrow = p.dV + (size_t)b * p.dv_batch + (size_t)kj * p.dv_row + (size_t)h * D;
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const uint2v wk = {pack_bf16x2(dkacc[d][g * 4], dkacc[d][g * 4 + 1]),
-                           pack_bf16x2(dkacc[d][g * 4 + 2], dkacc[d][g * 4 + 3])};
-        const uint2v wv = {pack_bf16x2(dvacc[d][g * 4], dvacc[d][g * 4 + 1]),
-                           pack_bf16x2(dvacc[d][g * 4 + 2], dvacc[d][g * 4 + 3])};
+        const uint2v wk = {pack_h16x2(dkacc[d][g * 4], dkacc[d][g * 4 + 1]),
+                           pack_h16x2(dkacc[d][g * 4 + 2], dkacc[d][g * 4 + 3])};
+        const uint2v wv = {pack_h16x2(dvacc[d][g * 4], dvacc[d][g * 4 + 1]),
+                           pack_h16x2(dvacc[d][g * 4 + 2], dvacc[d][g * 4 + 3])};
         *reinterpret_cast<uint2v*>(krow + d * 32 + g * 8 + 4 * hi) = wk;
         *reinterpret_cast<uint2v*>(vrow + d * 32 + g * 8 + 4 * hi) = wv;
       }
@@ -397,8 +396,8 @@ int g4r_flash_attn_bwd_bf16(const void* Q, const void* K, const void* V, const v
   const long strides[] = {q_row,   k_row,   v_row,   o_row,   do_row,   dq_row,   dk_row,   dv_row,
                           q_batch, k_batch, v_batch, o_batch, do_batch, dq_batch, dk_batch, dv_batch};
   for (long s : strides) G4R_REQUIRE(s % 8 == 0, "flash_attn_bwd: strides must keep 16-byte alignment");
-  AttnBwdArgs a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)O, (const bf16_t*)dO,
-                   (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, lse, delta,
+  AttnBwdArgs a = {(const h16_t*)Q, (const h16_t*)K, (const h16_t*)V, (const h16_t*)O, (const h16_t*)dO,
+                   (h16_t*)dQ, (h16_t*)dK, (h16_t*)dV, lse, delta,
                    q_row, k_row, v_row, o_row, do_row, dq_row, dk_row, dv_row,
                    q_batch, k_batch, v_batch, o_batch, do_batch, dq_batch, dk_batch, dv_batch,
                    Tq, Tk, H, scale, causal};

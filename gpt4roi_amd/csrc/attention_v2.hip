@@ -27,13 +27,12 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct Attn2Args {
-  const bf16_t* Q;
-  const bf16_t* K;
-  const bf16_t* V;
-  bf16_t* O;
+  const h16_t* Q;
+  const h16_t* K;
+  const h16_t* V;
+  h16_t* O;
   long q_row, k_row, v_row, o_row;
   long q_batch, k_batch, v_batch, o_batch;
   int Tq, Tk, H;
@@ -104,9 +103,9 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
   const int qw0 = qblock + wv * 32;
   const int qi = qw0 + ql;
   const int off = p.Tk - p.Tq;
-  const bf16_t* Qb = p.Q + (size_t)b * p.q_batch + (size_t)h * D;
-  const bf16_t* Kb = p.K + (size_t)b * p.k_batch + (size_t)h * D;
-  const bf16_t* Vb = p.V + (size_t)b * p.v_batch + (size_t)h * D;
+  const h16_t* Qb = p.Q + (size_t)b * p.q_batch + (size_t)h * D;
+  const h16_t* Kb = p.K + (size_t)b * p.k_batch + (size_t)h * D;
+  const h16_t* Vb = p.V + (size_t)b * p.v_batch + (size_t)h * D;
   char* gbuf = smem + grp * (2 * TILE_BYTES);
 
   int kend = p.Tk;
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
       const int row = pq * RPP + lane / SLOTS;
       int qr = qblock + row;
       if (qr > p.Tq - 1) qr = p.Tq - 1;
-      const bf16_t* src = Qb + (size_t)qr * p.q_row + ((lane % SLOTS) ^ a2_kswz<D>(row)) * 8;
+      const h16_t* src = Qb + (size_t)qr * p.q_row + ((lane % SLOTS) ^ a2_kswz<D>(row)) * 8;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(qlds + pq * 1024), 16, 0, 0);
     }
@@ -185,11 +184,11 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
   if (grp < ntiles) issue(grp, 0);
   __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0); builtin, not inline asm: the compiler's counter model sees it
   __builtin_amdgcn_s_barrier();
-  bf16x8 qf[KSTEPS];
+  h16x8 qf[KSTEPS];
   {
     const char* qrow = qlds + (wv * 32) * (D * 2) + k_row_off;
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + (((kk * 2 + hi) ^ k_sw) << 4));
+    for (int kk = 0; kk < KSTEPS; ++kk) qf[kk] = *reinterpret_cast<const h16x8*>(qrow + (((kk * 2 + hi) ^ k_sw) << 4));
   }
   float16v oacc[DB];
 #pragma unroll
@@ -235,7 +234,7 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
       // loads, puts s_waitcnt lgkmcnt(0) in front of every MFMA that consumes one (never a counted wait on ds_read_b128
       // here), i.e. the first MFMA waited for all sixteen reads: 1076-1108 cycles for 16 MFMAs = 512.  Each wait is tied
       // ("+v") to the fragments it releases, so the MFMA cannot move above it.
-      bf16x8 kf[2][KSTEPS];
+      h16x8 kf[2][KSTEPS];
       const unsigned kbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(kt + k_row_off);
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
@@ -250,8 +249,8 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {            // two independent accumulator chains, interleaved
         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(kf[0][kk]), "+v"(kf[1][kk]) : "n"(2 * (KSTEPS - 1 - kk)));
-        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][kk], qf[kk], sacc[0], 0, 0, 0);
-        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][kk], qf[kk], sacc[1], 0, 0, 0);
+        sacc[0] = G4R_MFMA_32X32X16(kf[0][kk], qf[kk], sacc[0], 0, 0, 0);
+        sacc[1] = G4R_MFMA_32X32X16(kf[1][kk], qf[kk], sacc[1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);             // ... and the next wait cannot move above it
       }
     }
@@ -302,7 +301,7 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
     const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(a));
     const short4v up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(a + 8 * 32));
     const short8 vv = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
-    return __builtin_bit_cast(bf16x8, vv);
+    return __builtin_bit_cast(h16x8, vv);
   };
   auto phase_b = [&](int s) {
     A2_STAMP(4, s, alpha);
@@ -312,7 +311,7 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
     // of the group's NEXT tile are issued behind them: the compiler puts s_waitcnt vmcnt(0) in front of any LDS read that
     // follows an LDS-DMA instruction in program order (it cannot see that the DMA writes the other buffer), so the pieces
     // must come after the step's last LDS read.  They land during exp / PV / the barrier (~1400 cycles).
-    bf16x8 vf[2][2][DB];
+    h16x8 vf[2][2][DB];
     if (active) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -347,17 +346,17 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
     }
     A2_STAMP(5, s, oacc[0][0]);
     // O^T += V^T P^T : A operand = 4 + 4 keys of this lane's d through two transpose reads
-    bf16x8 pf[2][2];
+    h16x8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         uint4v pw;
-        pw.x = pack_bf16x2(sacc[kb][hf * 8 + 0], sacc[kb][hf * 8 + 1]);
-        pw.y = pack_bf16x2(sacc[kb][hf * 8 + 2], sacc[kb][hf * 8 + 3]);
-        pw.z = pack_bf16x2(sacc[kb][hf * 8 + 4], sacc[kb][hf * 8 + 5]);
-        pw.w = pack_bf16x2(sacc[kb][hf * 8 + 6], sacc[kb][hf * 8 + 7]);
-        pf[kb][hf] = __builtin_bit_cast(bf16x8, pw);
+        pw.x = pack_h16x2(sacc[kb][hf * 8 + 0], sacc[kb][hf * 8 + 1]);
+        pw.y = pack_h16x2(sacc[kb][hf * 8 + 2], sacc[kb][hf * 8 + 3]);
+        pw.z = pack_h16x2(sacc[kb][hf * 8 + 4], sacc[kb][hf * 8 + 5]);
+        pw.w = pack_h16x2(sacc[kb][hf * 8 + 6], sacc[kb][hf * 8 + 7]);
+        pf[kb][hf] = __builtin_bit_cast(h16x8, pw);
       }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -366,7 +365,7 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
       for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int d = 0; d < DB; ++d)
-          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kb][hf][d], pf[kb][hf], oacc[d], 0, 0, 0);
+          oacc[d] = G4R_MFMA_32X32X16(vf[kb][hf][d], pf[kb][hf], oacc[d], 0, 0, 0);
     A2_STAMP(6, s, oacc[DB - 1][15]);
   };
 
@@ -436,8 +435,8 @@ __global__ __launch_bounds__(NWG* NG * 64) void flash_attn_fwd2_kernel(Attn2Args
   for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const uint2v w = {pack_bf16x2(oacc[d][g * 4] * inv, oacc[d][g * 4 + 1] * inv),
-                        pack_bf16x2(oacc[d][g * 4 + 2] * inv, oacc[d][g * 4 + 3] * inv)};
+      const uint2v w = {pack_h16x2(oacc[d][g * 4] * inv, oacc[d][g * 4 + 1] * inv),
+                        pack_h16x2(oacc[d][g * 4 + 2] * inv, oacc[d][g * 4 + 3] * inv)};
       *reinterpret_cast<uint2v*>(olds + ql * ORS + (d * 32 + g * 8 + 4 * hi) * 2) = w;
     }
   __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): same wave wrote and reads, in-order LDS, no barrier needed
@@ -475,14 +474,16 @@ int launch_attn2(const Attn2Args& a, int B, hipStream_t st) {
 }  // namespace
 
 static long long* g_attn2_probe = nullptr;   // tools: device buffer for the phase stamps (tools/attn_probe2.py)
+#ifndef G4R_F16
 extern "C" void g4r_attn2_debug_probe(void* ptr) { g_attn2_probe = (long long*)ptr; }
+#endif
 
 // variant: 0 = production choice; otherwise NWG * 10 + NG of an instantiated form (tools / tests)
 int g4r_attn2_dispatch(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk, int head_dim,
                        long q_row, long k_row, long v_row, long o_row, long q_batch, long k_batch, long v_batch,
                        long o_batch, float scale, int causal, const int* kv_len_dev, float* lse, int variant,
                        void* stream) {
-  Attn2Args a = {(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, q_row, k_row, v_row, o_row,
+  Attn2Args a = {(const h16_t*)Q, (const h16_t*)K, (const h16_t*)V, (h16_t*)O, q_row, k_row, v_row, o_row,
                  q_batch, k_batch, v_batch, o_batch, Tq, Tk, H, scale, causal, kv_len_dev, lse, g_attn2_probe};
   hipStream_t st = (hipStream_t)stream;
   int rc = G4R_OK;

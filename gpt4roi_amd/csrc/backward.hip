@@ -45,17 +45,17 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 struct F8 {
   float v[8];
 };
-__device__ __forceinline__ F8 ld8(const bf16_t* p) {
+__device__ __forceinline__ F8 ld8(const h16_t* p) {
   const uint4v r = *reinterpret_cast<const uint4v*>(p);
   F8 a;
-  a.v[0] = bf16lo(r.x); a.v[1] = bf16hi(r.x); a.v[2] = bf16lo(r.y); a.v[3] = bf16hi(r.y);
-  a.v[4] = bf16lo(r.z); a.v[5] = bf16hi(r.z); a.v[6] = bf16lo(r.w); a.v[7] = bf16hi(r.w);
+  a.v[0] = h16lo(r.x); a.v[1] = h16hi(r.x); a.v[2] = h16lo(r.y); a.v[3] = h16hi(r.y);
+  a.v[4] = h16lo(r.z); a.v[5] = h16hi(r.z); a.v[6] = h16lo(r.w); a.v[7] = h16hi(r.w);
   return a;
 }
-__device__ __forceinline__ void st8(bf16_t* p, const F8& a) {
+__device__ __forceinline__ void st8(h16_t* p, const F8& a) {
   uint4v w;
-  w.x = pack_bf16x2(a.v[0], a.v[1]); w.y = pack_bf16x2(a.v[2], a.v[3]);
-  w.z = pack_bf16x2(a.v[4], a.v[5]); w.w = pack_bf16x2(a.v[6], a.v[7]);
+  w.x = pack_h16x2(a.v[0], a.v[1]); w.y = pack_h16x2(a.v[2], a.v[3]);
+  w.z = pack_h16x2(a.v[4], a.v[5]); w.w = pack_h16x2(a.v[6], a.v[7]);
   *reinterpret_cast<uint4v*>(p) = w;
 }
 __device__ __forceinline__ F8 ld8f(const float* p) {
@@ -79,9 +79,9 @@ constexpr int NORM_MAXV = 4;  // rows up to 8192 elements
 // ---- RMSNorm backward: y = bf16(x * rstd) * gamma -------------------------------------------------
 //   dx = dres + rstd * (gamma*dy - xhat * mean(gamma*dy*xhat)),  xhat = x * rstd
 //   dgamma[c] += dy * xhat  (fp32 atomics, only when dgamma != null: stage 2)
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
-                                                          const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dres,
-                                                          bf16_t* __restrict__ dx, float* __restrict__ dgamma,
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const h16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                          const h16_t* __restrict__ dy, const h16_t* __restrict__ dres,
+                                                          h16_t* __restrict__ dx, float* __restrict__ dgamma,
                                                           int rows, int cols, long ldx, long lddy, long lddr, long lddx,
                                                           float eps, int rows_per_block) {
   __shared__ float red[4];
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 }
 
 // ---- LayerNorm backward: y = (relu?(x) - mean) * rstd * gamma + beta ---------------------------------
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
-                                                            const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const h16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                            const h16_t* __restrict__ dy, h16_t* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int cols, long ldx, long lddy, long lddx, float eps,
                                                             int relu_in) {
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
 }
 
 // ---- SwiGLU over interleaved (gate, up) columns: gu [T, 2F] with column 2c = gate_c, 2c+1 = up_c ----
-__global__ __launch_bounds__(256) void swiglu_il_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, int T,
+__global__ __launch_bounds__(256) void swiglu_il_kernel(const h16_t* __restrict__ gu, h16_t* __restrict__ out, int T,
                                                         int F) {
   const int nvec = F >> 2;  // 4 outputs = 8 interleaved inputs per thread
   const long total = (long)T * nvec;
@@ -241,13 +241,13 @@ __global__ __launch_bounds__(256) void swiglu_il_kernel(const bf16_t* __restrict
       const float g = a.v[2 * k], u = a.v[2 * k + 1];
       o[k] = g / (1.f + __expf(-g)) * u;
     }
-    const uint2v w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+    const uint2v w = {pack_h16x2(o[0], o[1]), pack_h16x2(o[2], o[3])};
     *reinterpret_cast<uint2v*>(out + t * F + v * 4) = w;
   }
 }
 
-__global__ __launch_bounds__(256) void swiglu_il_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dy,
-                                                            bf16_t* __restrict__ dgu, int T, int F) {
+__global__ __launch_bounds__(256) void swiglu_il_bwd_kernel(const h16_t* __restrict__ gu, const h16_t* __restrict__ dy,
+                                                            h16_t* __restrict__ dgu, int T, int F) {
   const int nvec = F >> 2;
   const long total = (long)T * nvec;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void swiglu_il_bwd_kernel(const bf16_t* __rest
     const long t = i / nvec;
     const F8 a = ld8(gu + t * 2 * F + v * 8);
     const uint2v dw = *reinterpret_cast<const uint2v*>(dy + t * F + v * 4);
-    const float d[4] = {bf16lo(dw.x), bf16hi(dw.x), bf16lo(dw.y), bf16hi(dw.y)};
+    const float d[4] = {h16lo(dw.x), h16hi(dw.x), h16lo(dw.y), h16hi(dw.y)};
     F8 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -270,9 +270,9 @@ __global__ __launch_bounds__(256) void swiglu_il_bwd_kernel(const bf16_t* __rest
 }
 
 // ---- rotary backward: d(qkv)[t] = [R^-1 dq, R^-1 dk, dv] ---------------------------------------------
-__global__ __launch_bounds__(256) void rope_qkv_bwd_kernel(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk,
-                                                           const bf16_t* __restrict__ dv, const float* __restrict__ cs,
-                                                           const float* __restrict__ sn, bf16_t* __restrict__ dqkv,
+__global__ __launch_bounds__(256) void rope_qkv_bwd_kernel(const h16_t* __restrict__ dq, const h16_t* __restrict__ dk,
+                                                           const h16_t* __restrict__ dv, const float* __restrict__ cs,
+                                                           const float* __restrict__ sn, h16_t* __restrict__ dqkv,
                                                            int T, int Hh, int D, int pos0, long ldq, long ldk, long ldv) {
   const int half = D >> 1;
   const int hv = half >> 3;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void rope_qkv_bwd_kernel(const bf16_t* __restr
     const F8 c = ld8f(cs + (size_t)pos * half + v * 8);
     const F8 s = ld8f(sn + (size_t)pos * half + v * 8);
     const size_t off = (size_t)h * D + v * 8;
-    bf16_t* out = dqkv + (size_t)t * 3 * HD;
+    h16_t* out = dqkv + (size_t)t * 3 * HD;
     {
       const F8 a = ld8(dq + (size_t)t * ldq + off), b = ld8(dq + (size_t)t * ldq + off + half);
       F8 o1, o2;
@@ -319,13 +319,13 @@ __global__ __launch_bounds__(256) void rope_qkv_bwd_kernel(const bf16_t* __restr
 //   label < 0 (HF ignore_index -100): no loss, zero gradient.
 //   loss_sum += lse - logit[label];  dlogits = (softmax - onehot) * *grad_scale, zero in the pad columns.
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, const long* __restrict__ labels,
-                                                            bf16_t* __restrict__ dlogits, float* __restrict__ loss_sum,
+                                                            h16_t* __restrict__ dlogits, float* __restrict__ loss_sum,
                                                             const float* __restrict__ grad_scale, int N, long ld,
                                                             long ldd, int n_pad) {
   __shared__ float red[4];
   const int row = blockIdx.x;
   const float* lr = logits + (size_t)row * ld;
-  bf16_t* dr = dlogits ? dlogits + (size_t)row * ldd : nullptr;
+  h16_t* dr = dlogits ? dlogits + (size_t)row * ldd : nullptr;
   const long label = labels[row];
   if (label < 0 || label >= N) {
     if (dr)
@@ -346,19 +346,19 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
   for (int c = threadIdx.x; c < n_pad; c += 256) {
     float g = 0.f;
     if (c < N) g = (__expf(lr[c] - m) * inv - (c == label ? 1.f : 0.f)) * gs;
-    dr[c] = f32_to_bf16(g);
+    dr[c] = f32_to_h16(g);
   }
 }
 
 // ---- transpose: out[c][r] = in[r][c]; rows R..R_pad of the (transposed) output are zero -----------------
-__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R,
+__global__ __launch_bounds__(256) void transpose_kernel(const h16_t* __restrict__ in, h16_t* __restrict__ out, int R,
                                                         int C, long ld_in, long ld_out, int R_pad) {
-  __shared__ bf16_t tile[64][66];
+  __shared__ h16_t tile[64][66];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int j = ty; j < 64; j += 4) {
     const int r = r0 + j, c = c0 + tx;
-    tile[j][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : (bf16_t)0;
+    tile[j][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : (h16_t)0;
   }
   __syncthreads();
   for (int j = ty; j < 64; j += 4) {
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
 }
 
 // ---- column sums of a bf16 [M, N] matrix -> fp32 [N] (bias gradients); accumulates ----------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int M, int N,
+__global__ __launch_bounds__(256) void colsum_kernel(const h16_t* __restrict__ x, float* __restrict__ out, int M, int N,
                                                      long ld, int rows_per_block) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= N) return;
@@ -376,13 +376,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   int r1 = r0 + rows_per_block;
   if (r1 > M) r1 = M;
   float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += bf16_to_f32(x[(size_t)r * ld + c]);
+  for (int r = r0; r < r1; ++r) s += h16_to_f32(x[(size_t)r * ld + c]);
   unsafeAtomicAdd(out + c, s);
 }
 
 // ---- dx = dy where y > 0 else 0 ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict__ y, const bf16_t* __restrict__ dy,
-                                                       bf16_t* __restrict__ dx, long n8) {
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const h16_t* __restrict__ y, const h16_t* __restrict__ dy,
+                                                       h16_t* __restrict__ dx, long n8) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
     const F8 a = ld8(y + i * 8), d = ld8(dy + i * 8);
     F8 o;
@@ -393,8 +393,8 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict_
 }
 
 // ---- dst[i] = src[idx[i]] (rows of C bf16): gradient of the <bbox> / image-patch splice ------------------
-__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx,
-                                                          bf16_t* __restrict__ dst, int n, int C, long ld_src,
+__global__ __launch_bounds__(256) void gather_rows_kernel(const h16_t* __restrict__ src, const int* __restrict__ idx,
+                                                          h16_t* __restrict__ dst, int n, int C, long ld_src,
                                                           long ld_dst) {
   const int nvec = C >> 3;
   const long total = (long)n * nvec;
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restri
 }
 
 // ---- out[idx[r]] += src[r] (fp32 accumulation of bf16 rows; idx < 0 = skip): embedding-table gradient -------------
-__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx,
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const h16_t* __restrict__ src, const int* __restrict__ idx,
                                                                float* __restrict__ out, int n, int C, long ld_src,
                                                                long ld_out) {
   const int nvec = C >> 3;
@@ -429,12 +429,12 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const bf16_t* __r
 // ---- AdamW (decoupled weight decay, torch.optim.AdamW semantics) ----------------------------------------
 template <typename G>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n, float lr,
+                                                    float* __restrict__ v, h16_t* __restrict__ p_bf16, long n, float lr,
                                                     float b1, float b2, float eps, float wd, float bc1, float bc2,
                                                     float gscale) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float gi;
-    if (sizeof(G) == 2) gi = bf16_to_f32(reinterpret_cast<const bf16_t*>(g)[i]);
+    if (sizeof(G) == 2) gi = h16_to_f32(reinterpret_cast<const h16_t*>(g)[i]);
     else gi = reinterpret_cast<const float*>(g)[i];
     gi *= gscale;
     float pi = p[i] * (1.f - lr * wd);
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
-    if (p_bf16) p_bf16[i] = f32_to_bf16(pi);
+    if (p_bf16) p_bf16[i] = f32_to_h16(pi);
   }
 }
 
@@ -461,7 +461,7 @@ int g4r_rmsnorm_bwd_bf16(const void* x, const float* gamma, const void* dy, cons
   G4R_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && lddres % 8 == 0, "rmsnorm_bwd: bad stride");
   const int rpb = dgamma ? 8 : 1;
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(g4r_ceil_div(rows, rpb)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, gamma, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dgamma, rows, cols, ldx,
+                     (const h16_t*)x, gamma, (const h16_t*)dy, (const h16_t*)dres, (h16_t*)dx, dgamma, rows, cols, ldx,
                      lddy, lddres, lddx, eps, rpb);
   G4R_CHECK_LAUNCH("rmsnorm_bwd");
   return G4R_OK;
@@ -473,8 +473,8 @@ int g4r_layernorm_bwd_bf16(const void* x, const float* gamma, const void* dy, vo
   if (rows == 0) return G4R_OK;
   G4R_REQUIRE(x && gamma && dy, "layernorm_bwd: null pointer");
   G4R_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "layernorm_bwd: bad stride");
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma,
-                     (const bf16_t*)dy, (bf16_t*)dx, dgamma, dbeta, cols, ldx, lddy, lddx, eps, relu_in);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, gamma,
+                     (const h16_t*)dy, (h16_t*)dx, dgamma, dbeta, cols, ldx, lddy, lddx, eps, relu_in);
   G4R_CHECK_LAUNCH("layernorm_bwd");
   return G4R_OK;
 }
@@ -484,7 +484,7 @@ int g4r_swiglu_il_bf16(const void* gate_up, void* out, int T, int F, void* strea
   if (T == 0) return G4R_OK;
   G4R_REQUIRE(gate_up && out, "swiglu_il: null pointer");
   hipLaunchKernelGGL(swiglu_il_kernel, dim3(grid_for((long)T * (F / 4))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)gate_up, (bf16_t*)out, T, F);
+                     (const h16_t*)gate_up, (h16_t*)out, T, F);
   G4R_CHECK_LAUNCH("swiglu_il");
   return G4R_OK;
 }
@@ -494,7 +494,7 @@ int g4r_swiglu_il_bwd_bf16(const void* gate_up, const void* dy, void* dgate_up, 
   if (T == 0) return G4R_OK;
   G4R_REQUIRE(gate_up && dy && dgate_up, "swiglu_il_bwd: null pointer");
   hipLaunchKernelGGL(swiglu_il_bwd_kernel, dim3(grid_for((long)T * (F / 4))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)gate_up, (const bf16_t*)dy, (bf16_t*)dgate_up, T, F);
+                     (const h16_t*)gate_up, (const h16_t*)dy, (h16_t*)dgate_up, T, F);
   G4R_CHECK_LAUNCH("swiglu_il_bwd");
   return G4R_OK;
 }
@@ -507,8 +507,8 @@ int g4r_rope_qkv_bwd_bf16(const void* dq, const void* dk, const void* dv, const 
   G4R_REQUIRE(dq && dk && dv && cos_tab && sin_tab && dqkv, "rope_qkv_bwd: null pointer");
   G4R_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "rope_qkv_bwd: bad stride");
   const long total = (long)T * heads * (head_dim / 16);
-  hipLaunchKernelGGL(rope_qkv_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dq,
-                     (const bf16_t*)dk, (const bf16_t*)dv, cos_tab, sin_tab, (bf16_t*)dqkv, T, heads, head_dim, pos0,
+  hipLaunchKernelGGL(rope_qkv_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)dq,
+                     (const h16_t*)dk, (const h16_t*)dv, cos_tab, sin_tab, (h16_t*)dqkv, T, heads, head_dim, pos0,
                      ldq, ldk, ldv);
   G4R_CHECK_LAUNCH("rope_qkv_bwd");
   return G4R_OK;
@@ -521,7 +521,7 @@ int g4r_cross_entropy_f32(const float* logits, const long* labels, void* dlogits
   G4R_REQUIRE(logits && labels && loss_sum, "cross_entropy: null pointer");
   G4R_REQUIRE(!dlogits || (grad_scale && ldd >= n_pad), "cross_entropy: dlogits needs grad_scale and ldd >= n_pad");
   hipLaunchKernelGGL(cross_entropy_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, labels,
-                     (bf16_t*)dlogits, loss_sum, grad_scale, N, ld, ldd, n_pad);
+                     (h16_t*)dlogits, loss_sum, grad_scale, N, ld, ldd, n_pad);
   G4R_CHECK_LAUNCH("cross_entropy");
   return G4R_OK;
 }
@@ -531,7 +531,7 @@ int g4r_transpose_bf16(const void* in, void* out, int R, int C, long ld_in, long
   if (R_pad == 0 || C == 0) return G4R_OK;
   G4R_REQUIRE(in && out, "transpose: null pointer");
   hipLaunchKernelGGL(transpose_kernel, dim3(g4r_ceil_div(C, 64), g4r_ceil_div(R_pad, 64)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, R, C, ld_in, ld_out, R_pad);
+                     (hipStream_t)stream, (const h16_t*)in, (h16_t*)out, R, C, ld_in, ld_out, R_pad);
   G4R_CHECK_LAUNCH("transpose");
   return G4R_OK;
 }
@@ -542,7 +542,7 @@ int g4r_colsum_bf16(const void* x, float* out, int M, int N, long ld, void* stre
   G4R_REQUIRE(x && out, "colsum: null pointer");
   const int rpb = 256;
   hipLaunchKernelGGL(colsum_kernel, dim3(g4r_ceil_div(N, 256), g4r_ceil_div(M, rpb)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, out, M, N, ld, rpb);
+                     (const h16_t*)x, out, M, N, ld, rpb);
   G4R_CHECK_LAUNCH("colsum");
   return G4R_OK;
 }
@@ -551,8 +551,8 @@ int g4r_relu_bwd_bf16(const void* y, const void* dy, void* dx, long n, void* str
   G4R_REQUIRE(n >= 0 && n % 8 == 0, "relu_bwd: n must be a multiple of 8");
   if (n == 0) return G4R_OK;
   G4R_REQUIRE(y && dy && dx, "relu_bwd: null pointer");
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y,
-                     (const bf16_t*)dy, (bf16_t*)dx, n / 8);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)y,
+                     (const h16_t*)dy, (h16_t*)dx, n / 8);
   G4R_CHECK_LAUNCH("relu_bwd");
   return G4R_OK;
 }
@@ -563,7 +563,7 @@ int g4r_gather_rows_bf16(const void* src, const int* idx, void* dst, int n, int 
   if (n == 0) return G4R_OK;
   G4R_REQUIRE(src && idx && dst, "gather_rows: null pointer");
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)n * (C / 8))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)src, idx, (bf16_t*)dst, n, C, ld_src, ld_dst);
+                     (const h16_t*)src, idx, (h16_t*)dst, n, C, ld_src, ld_dst);
   G4R_CHECK_LAUNCH("gather_rows");
   return G4R_OK;
 }
@@ -574,7 +574,7 @@ int g4r_scatter_add_rows_f32(const void* src, const int* idx, float* out, int n,
   if (n == 0) return G4R_OK;
   G4R_REQUIRE(src && idx && out, "scatter_add_rows: null pointer");
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for((long)n * (C / 8))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)src, idx, out, n, C, ld_src, ld_out);
+                     (const h16_t*)src, idx, out, n, C, ld_src, ld_out);
   G4R_CHECK_LAUNCH("scatter_add_rows");
   return G4R_OK;
 }
@@ -587,12 +587,12 @@ int g4r_adamw_f32(float* param, const void* grad, int grad_is_bf16, float* exp_a
   G4R_REQUIRE(param && grad && exp_avg && exp_avg_sq, "adamw: null pointer");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   if (grad_is_bf16)
-    hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param,
-                       (const bf16_t*)grad, exp_avg, exp_avg_sq, (bf16_t*)param_bf16, n, lr, beta1, beta2, eps,
+    hipLaunchKernelGGL(adamw_kernel<h16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param,
+                       (const h16_t*)grad, exp_avg, exp_avg_sq, (h16_t*)param_bf16, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, bc2, grad_scale);
   else
     hipLaunchKernelGGL(adamw_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param,
-                       (const float*)grad, exp_avg, exp_avg_sq, (bf16_t*)param_bf16, n, lr, beta1, beta2, eps,
+                       (const float*)grad, exp_avg, exp_avg_sq, (h16_t*)param_bf16, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, bc2, grad_scale);
   G4R_CHECK_LAUNCH("adamw");
   return G4R_OK;

@@ -8,17 +8,17 @@ namespace {
 struct F8 {
   float v[8];
 };
-__device__ __forceinline__ F8 ld8(const bf16_t* p) {
+__device__ __forceinline__ F8 ld8(const h16_t* p) {
   const uint4v r = *reinterpret_cast<const uint4v*>(p);
   F8 o;
-  o.v[0] = bf16lo(r.x); o.v[1] = bf16hi(r.x); o.v[2] = bf16lo(r.y); o.v[3] = bf16hi(r.y);
-  o.v[4] = bf16lo(r.z); o.v[5] = bf16hi(r.z); o.v[6] = bf16lo(r.w); o.v[7] = bf16hi(r.w);
+  o.v[0] = h16lo(r.x); o.v[1] = h16hi(r.x); o.v[2] = h16lo(r.y); o.v[3] = h16hi(r.y);
+  o.v[4] = h16lo(r.z); o.v[5] = h16hi(r.z); o.v[6] = h16lo(r.w); o.v[7] = h16hi(r.w);
   return o;
 }
-__device__ __forceinline__ void st8(bf16_t* p, const F8& a) {
+__device__ __forceinline__ void st8(h16_t* p, const F8& a) {
   uint4v w;
-  w.x = pack_bf16x2(a.v[0], a.v[1]); w.y = pack_bf16x2(a.v[2], a.v[3]);
-  w.z = pack_bf16x2(a.v[4], a.v[5]); w.w = pack_bf16x2(a.v[6], a.v[7]);
+  w.x = pack_h16x2(a.v[0], a.v[1]); w.y = pack_h16x2(a.v[2], a.v[3]);
+  w.z = pack_h16x2(a.v[4], a.v[5]); w.w = pack_h16x2(a.v[6], a.v[7]);
   *reinterpret_cast<uint4v*>(p) = w;
 }
 __device__ __forceinline__ F8 ld8f(const float* p) {
@@ -66,8 +66,8 @@ __device__ __forceinline__ Lerp lerp_ac(int dst, int in_size, int out_size) {
 // The interpolation result is rounded to bf16 before the coordinate concat, as F.interpolate on
 // a bf16 tensor does.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void upsample_coord_kernel(const bf16_t* __restrict__ in,
-                                                             bf16_t* __restrict__ out, int B, int Hin,
+__global__ __launch_bounds__(256) void upsample_coord_kernel(const h16_t* __restrict__ in,
+                                                             h16_t* __restrict__ out, int B, int Hin,
                                                              int Win, long in_batch_stride, int ldin,
                                                              int H, int W, int C, int Cpad) {
   const int nvec = Cpad >> 3;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void upsample_coord_kernel(const bf16_t* __res
     F8 o;
     if (v * 8 < C) {
       const Lerp ly = lerp_ac(y, Hin, H), lx = lerp_ac(x, Win, W);
-      const bf16_t* base = in + (size_t)b * in_batch_stride + v * 8;
+      const h16_t* base = in + (size_t)b * in_batch_stride + v * 8;
       const F8 p00 = ld8(base + ((size_t)ly.i0 * Win + lx.i0) * ldin);
       const F8 p01 = ld8(base + ((size_t)ly.i0 * Win + lx.i1) * ldin);
       const F8 p10 = ld8(base + ((size_t)ly.i1 * Win + lx.i0) * ldin);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void upsample_coord_kernel(const bf16_t* __res
 // All maps NHWC bf16; result rounded to bf16 once (the conv input cast under autocast).
 // ---------------------------------------------------------------------------------------------
 struct ShuffleSrc {
-  const bf16_t* x;
+  const h16_t* x;
   const float* affine;  // [B, 2, C] or null
   int H, W;
 };
@@ -139,7 +139,7 @@ __device__ __forceinline__ F8 gn_relu(const F8& x, const float* aff, int b, int 
 
 __device__ __forceinline__ F8 sample_src(const ShuffleSrc& s, int b, int y, int x, int H, int W, int C,
                                          int c0) {
-  const bf16_t* base = s.x + (size_t)b * s.H * s.W * C + c0;
+  const h16_t* base = s.x + (size_t)b * s.H * s.W * C + c0;
   if (s.H == H && s.W == W)  // identity resize (level is its own neighbour at the ends)
     return gn_relu(ld8(base + ((size_t)y * W + x) * C), s.affine, b, C, c0);
   const Lerp ly = lerp_ac(y, s.H, H), lx = lerp_ac(x, s.W, W);
@@ -155,7 +155,7 @@ __device__ __forceinline__ F8 sample_src(const ShuffleSrc& s, int b, int y, int 
 }
 
 __device__ __forceinline__ void shuffle_item(const ShuffleSrc& own, const ShuffleSrc& top, const ShuffleSrc& down,
-                                             bf16_t* __restrict__ out, int C, long i) {
+                                             h16_t* __restrict__ out, int C, long i) {
   const int H = own.H, W = own.W;
   const int nvec = C >> 3;
   const int R = C >> 1, S = C >> 2;
@@ -176,7 +176,7 @@ __device__ __forceinline__ void shuffle_item(const ShuffleSrc& own, const Shuffl
 }
 
 __global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShuffleSrc own, ShuffleSrc top, ShuffleSrc down,
-                                                           bf16_t* __restrict__ out, int B, int C) {
+                                                           h16_t* __restrict__ out, int B, int C) {
   const long total = (long)B * own.H * own.W * (C >> 3);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
     shuffle_item(own, top, down, out, C, i);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShuffleSrc own, Shuff
 #define G4R_SHUFFLE_MAX_LEVELS 4
 struct ShuffleLevels {
   ShuffleSrc own[G4R_SHUFFLE_MAX_LEVELS], top[G4R_SHUFFLE_MAX_LEVELS], down[G4R_SHUFFLE_MAX_LEVELS];
-  bf16_t* out[G4R_SHUFFLE_MAX_LEVELS];
+  h16_t* out[G4R_SHUFFLE_MAX_LEVELS];
   int chunks[G4R_SHUFFLE_MAX_LEVELS];    // pixel chunks per image on level l
   int blk_end[G4R_SHUFFLE_MAX_LEVELS];   // running workgroup count: level l owns [blk_end[l-1], blk_end[l]) = B * chunks[l]
   int n;
@@ -229,9 +229,9 @@ __global__ __launch_bounds__(256) void fuse_shuffle_mlvl_kernel(ShuffleLevels a,
     ga = ld8f(src.affine + (size_t)b * 2 * C + cs);
     gs = ld8f(src.affine + (size_t)b * 2 * C + C + cs);
   }
-  const bf16_t* base = src.x + (size_t)b * src.H * src.W * C + cs;
+  const h16_t* base = src.x + (size_t)b * src.H * src.W * C + cs;
   const bool same = src.H == H && src.W == W;
-  bf16_t* out = a.out[l] + (size_t)b * H * W * C + c;
+  h16_t* out = a.out[l] + (size_t)b * H * W * C + c;
   const int HW = H * W;
   int p1 = (chunk + 1) * ppb;
   if (p1 > HW) p1 = HW;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void fuse_shuffle_mlvl_kernel(ShuffleLevels a,
 // img [B,3,S,S] float32 NCHW -> patches [B*P*P, Kpad] bf16, k = c*196 + ky*14 + kx (conv weight
 // flatten order), zero padded to Kpad.
 __global__ __launch_bounds__(256) void im2col_patch14_kernel(const float* __restrict__ img,
-                                                             bf16_t* __restrict__ out, int B, int S,
+                                                             h16_t* __restrict__ out, int B, int S,
                                                              int P, int Kpad) {
   const long total = (long)B * P * P * Kpad;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -273,15 +273,15 @@ __global__ __launch_bounds__(256) void im2col_patch14_kernel(const float* __rest
       const int px = (int)(t % P), py = (int)((t / P) % P), b = (int)(t / ((long)P * P));
       v = img[(((size_t)b * 3 + c) * S + py * 14 + ky) * S + px * 14 + kx];
     }
-    out[i] = f32_to_bf16(v);
+    out[i] = f32_to_h16(v);
   }
 }
 
 // tokens[b, 0] = cls + pos[0]; tokens[b, 1+i] = patch[b*n+i] + pos[1+i]      (bf16, C % 8 == 0)
-__global__ __launch_bounds__(256) void vit_assemble_kernel(const bf16_t* __restrict__ patch,
-                                                           const bf16_t* __restrict__ cls,
-                                                           const bf16_t* __restrict__ pos,
-                                                           bf16_t* __restrict__ tok, int B, int n, int C) {
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const h16_t* __restrict__ patch,
+                                                           const h16_t* __restrict__ cls,
+                                                           const h16_t* __restrict__ pos,
+                                                           h16_t* __restrict__ tok, int B, int n, int C) {
   const int nvec = C >> 3;
   const long total = (long)B * (n + 1) * nvec;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const bf16_t* __restr
     const F8 p = ld8(pos + (size_t)s * C + v * 8);
     F8 o;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o.v[k] = bf16_to_f32(f32_to_bf16(a.v[k])) + p.v[k];
+    for (int k = 0; k < 8; ++k) o.v[k] = h16_to_f32(f32_to_h16(a.v[k])) + p.v[k];
     st8(tok + row * C + v * 8, o);
   }
 }
@@ -303,12 +303,12 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const bf16_t* __restr
 // qkv [T, 3*Hh*D] bf16 (q | k | v) -> RoPE(q) in place layout qout [T, Hh*D]; RoPE(k) and v appended
 // to the caches at rows pos0.. : kcache/vcache [maxT, Hh*D].  cos/sin [maxT, D/2] fp32.
 // rotate_half convention: x' = x*cos + rot(x)*sin, rot(x) = cat(-x[D/2:], x[:D/2]).
-__global__ __launch_bounds__(256) void rope_qkv_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256) void rope_qkv_kernel(const h16_t* __restrict__ qkv,
                                                        const float* __restrict__ cs,
                                                        const float* __restrict__ sn,
-                                                       bf16_t* __restrict__ qout,
-                                                       bf16_t* __restrict__ kcache,
-                                                       bf16_t* __restrict__ vcache, int T, int Hh, int D,
+                                                       h16_t* __restrict__ qout,
+                                                       h16_t* __restrict__ kcache,
+                                                       h16_t* __restrict__ vcache, int T, int Hh, int D,
                                                        int pos0, const int* __restrict__ pos_dev) {
   if (pos_dev) pos0 = *pos_dev;  // decode loop replayed from a hipGraph: the position lives on the device
   const int half = D >> 1;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(const bf16_t* __restrict_
     const F8 c = ld8f(cs + (size_t)pos * half + v * 8);
     const F8 s = ld8f(sn + (size_t)pos * half + v * 8);
     const size_t off = (size_t)h * D + v * 8;
-    const bf16_t* row = qkv + (size_t)t * 3 * HD;
+    const h16_t* row = qkv + (size_t)t * 3 * HD;
     {
       const F8 a = ld8(row + off), b = ld8(row + off + half);
       F8 o1, o2;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(const bf16_t* __restrict_
 }
 
 // gu [T, 2*F] bf16 (gate | up) -> out [T, F] = silu(gate) * up
-__global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void swiglu_kernel(const h16_t* __restrict__ gu, h16_t* __restrict__ out,
                                                      int T, int F) {
   const int nvec = F >> 3;
   const long total = (long)T * nvec;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ 
     F8 o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float sg = bf16_to_f32(f32_to_bf16(g.v[k] / (1.f + __expf(-g.v[k]))));  // silu rounds to bf16
+      const float sg = h16_to_f32(f32_to_h16(g.v[k] / (1.f + __expf(-g.v[k]))));  // silu rounds to bf16
       o.v[k] = sg * u.v[k];
     }
     st8(out + t * F + v * 8, o);
@@ -384,11 +384,11 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ 
 // (T is ~1-2k ids) and then gathers `tok_per_block` token rows; chunk 0 writes status.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void splice_embed_kernel(const long* __restrict__ ids,
-                                                           const bf16_t* __restrict__ embed,
-                                                           const bf16_t* __restrict__ img,
-                                                           const bf16_t* __restrict__ spi,
+                                                           const h16_t* __restrict__ embed,
+                                                           const h16_t* __restrict__ img,
+                                                           const h16_t* __restrict__ spi,
                                                            const int* __restrict__ spi_offset,
-                                                           bf16_t* __restrict__ out, int* __restrict__ status,
+                                                           h16_t* __restrict__ out, int* __restrict__ status,
                                                            int T, int C, int n_patch, long patch_id,
                                                            long bbox_id, long im_start_id, long im_end_id,
                                                            int vocab, int tok_per_block) {
@@ -451,8 +451,9 @@ __global__ __launch_bounds__(256) void splice_embed_kernel(const long* __restric
     const int want = spi_offset ? spi_offset[b + 1] - spi_offset[b] : 0;
     if (nb != want) st |= 2;                                       // #<bbox> != #regions
     if (np > 0) {
-      if (first < 1 || row[first - 1] != im_start_id) st |= 4;    // <im_start> must precede
-      if (first + n_patch >= T || row[first + n_patch] != im_end_id) st |= 8;  // <im_end> must follow
+      // ids < 0: a checkpoint without mm_use_im_start_end -- the patch run stands alone (spi_llava.py:158-196)
+      if (im_start_id >= 0 && (first < 1 || row[first - 1] != im_start_id)) st |= 4;    // <im_start> must precede
+      if (im_end_id >= 0 && (first + n_patch >= T || row[first + n_patch] != im_end_id)) st |= 8;  // <im_end> must follow
     }
     status[b] = st;
   }
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256) void splice_embed_kernel(const long* __restric
   const int t1 = min(T, t0 + tok_per_block);
   for (int i = t0 * nvec + tid; i < t1 * nvec; i += 256) {
     const int t = i / nvec, v = i % nvec;
-    const bf16_t* src;
+    const h16_t* src;
     if (prank[t] >= 0 && prank[t] < n_patch)
       src = img + ((size_t)b * n_patch + prank[t]) * C;
     else if (brank[t] >= 0 && brank[t] < n_region && spi)
@@ -587,8 +588,8 @@ __global__ __launch_bounds__(64) void batch_advance_kernel(const long* __restric
 }
 
 // y[i] = a[i] + b[row(i) % brows]  (bf16; used for "+ pos_embedd" style adds), C % 8 == 0
-__global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ a,
-                                                       const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void add_rows_kernel(const h16_t* __restrict__ a,
+                                                       const h16_t* __restrict__ b, h16_t* __restrict__ y,
                                                        long rows, int C, long brows) {
   const int nvec = C >> 3;
   const long total = rows * nvec;
@@ -604,10 +605,10 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict_
 }
 
 // float32 -> bf16 and bf16 -> float32 casts (weights / feature hand-over)
-__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, h16_t* __restrict__ y,
                                                             long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-    y[i] = f32_to_bf16(x[i]);
+    y[i] = f32_to_h16(x[i]);
 }
 
 inline int grid_for(long work_items) {
@@ -667,7 +668,7 @@ int g4r_upsample_coord_nhwc_bf16(const void* in, void* out, int B, int Hin, int 
   G4R_REQUIRE(in && out, "upsample_coord: null pointer");
   const long total = (long)B * H * W * (Cpad / 8);
   hipLaunchKernelGGL(upsample_coord_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)in, (bf16_t*)out, B, Hin, Win, in_batch_stride, ldin, H, W, C, Cpad);
+                     (const h16_t*)in, (h16_t*)out, B, Hin, Win, in_batch_stride, ldin, H, W, C, Cpad);
   G4R_CHECK_LAUNCH("upsample_coord");
   return G4R_OK;
 }
@@ -692,10 +693,10 @@ int g4r_fuse_shuffle_mlvl_nhwc_bf16(const void* const* maps, const float* const*
     const int tp = top_idx[l], dn = down_idx[l];
     G4R_REQUIRE(tp >= 0 && tp < n_levels && dn >= 0 && dn < n_levels && maps[l] && outs[l] && heights[l] > 0 &&
                     widths[l] > 0, "fuse_shuffle_mlvl: bad level");
-    a.own[t] = ShuffleSrc{(const bf16_t*)maps[l], affines ? affines[l] : nullptr, heights[l], widths[l]};
-    a.top[t] = ShuffleSrc{(const bf16_t*)maps[tp], affines ? affines[tp] : nullptr, heights[tp], widths[tp]};
-    a.down[t] = ShuffleSrc{(const bf16_t*)maps[dn], affines ? affines[dn] : nullptr, heights[dn], widths[dn]};
-    a.out[t] = (bf16_t*)outs[l];
+    a.own[t] = ShuffleSrc{(const h16_t*)maps[l], affines ? affines[l] : nullptr, heights[l], widths[l]};
+    a.top[t] = ShuffleSrc{(const h16_t*)maps[tp], affines ? affines[tp] : nullptr, heights[tp], widths[tp]};
+    a.down[t] = ShuffleSrc{(const h16_t*)maps[dn], affines ? affines[dn] : nullptr, heights[dn], widths[dn]};
+    a.out[t] = (h16_t*)outs[l];
     a.chunks[t] = g4r_ceil_div((long)heights[l] * widths[l], ppb);
     if (t < n_levels) blocks += B * a.chunks[t];
     a.blk_end[t] = blocks;
@@ -713,12 +714,12 @@ int g4r_fuse_shuffle_nhwc_bf16(const void* own, const float* own_affine, int H, 
   G4R_REQUIRE(B > 0 && H > 0 && W > 0 && Ht > 0 && Wt > 0 && Hd > 0 && Wd > 0, "fuse_shuffle: bad shape");
   G4R_REQUIRE(C % 32 == 0, "fuse_shuffle: C must be a multiple of 32");
   G4R_REQUIRE(own && top && down && out, "fuse_shuffle: null pointer");
-  ShuffleSrc so = {(const bf16_t*)own, own_affine, H, W};
-  ShuffleSrc st = {(const bf16_t*)top, top_affine, Ht, Wt};
-  ShuffleSrc sd = {(const bf16_t*)down, down_affine, Hd, Wd};
+  ShuffleSrc so = {(const h16_t*)own, own_affine, H, W};
+  ShuffleSrc st = {(const h16_t*)top, top_affine, Ht, Wt};
+  ShuffleSrc sd = {(const h16_t*)down, down_affine, Hd, Wd};
   const long total = (long)B * H * W * (C / 8);
   hipLaunchKernelGGL(fuse_shuffle_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, so, st,
-                     sd, (bf16_t*)out, B, C);
+                     sd, (h16_t*)out, B, C);
   G4R_CHECK_LAUNCH("fuse_shuffle");
   return G4R_OK;
 }
@@ -729,7 +730,7 @@ int g4r_im2col_patch14_f32(const float* img, void* out, int B, int S, int Kpad, 
   const int P = S / 14;
   const long total = (long)B * P * P * Kpad;
   hipLaunchKernelGGL(im2col_patch14_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img,
-                     (bf16_t*)out, B, S, P, Kpad);
+                     (h16_t*)out, B, S, P, Kpad);
   G4R_CHECK_LAUNCH("im2col_patch14");
   return G4R_OK;
 }
@@ -740,7 +741,7 @@ int g4r_vit_assemble_bf16(const void* patch, const void* cls, const void* pos, v
   G4R_REQUIRE(patch && cls && pos && tok, "vit_assemble: null pointer");
   const long total = (long)B * (n + 1) * (C / 8);
   hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)patch, (const bf16_t*)cls, (const bf16_t*)pos, (bf16_t*)tok, B, n, C);
+                     (const h16_t*)patch, (const h16_t*)cls, (const h16_t*)pos, (h16_t*)tok, B, n, C);
   G4R_CHECK_LAUNCH("vit_assemble");
   return G4R_OK;
 }
@@ -752,7 +753,7 @@ int g4r_rope_qkv_bf16(const void* qkv, const float* cos_tab, const float* sin_ta
   G4R_REQUIRE(qkv && cos_tab && sin_tab && q_out && k_cache && v_cache, "rope_qkv: null pointer");
   const long total = (long)T * heads * (head_dim / 16);
   hipLaunchKernelGGL(rope_qkv_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)qkv, cos_tab, sin_tab, (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache, T,
+                     (const h16_t*)qkv, cos_tab, sin_tab, (h16_t*)q_out, (h16_t*)k_cache, (h16_t*)v_cache, T,
                      heads, head_dim, pos0, pos_dev);
   G4R_CHECK_LAUNCH("rope_qkv");
   return G4R_OK;
@@ -763,7 +764,7 @@ int g4r_swiglu_bf16(const void* gate_up, void* out, int T, int F, void* stream) 
   if (T == 0) return G4R_OK;
   G4R_REQUIRE(gate_up && out, "swiglu: null pointer");
   hipLaunchKernelGGL(swiglu_kernel, dim3(grid_for((long)T * (F / 8))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)gate_up, (bf16_t*)out, T, F);
+                     (const h16_t*)gate_up, (h16_t*)out, T, F);
   G4R_CHECK_LAUNCH("swiglu");
   return G4R_OK;
 }
@@ -778,13 +779,14 @@ int g4r_splice_embed_bf16(const long* ids, const void* embed, const void* img, c
   G4R_REQUIRE(n_patch == 0 || img, "splice_embed: image features missing");
   const int tpb = 4;
   hipLaunchKernelGGL(splice_embed_kernel, dim3(g4r_ceil_div(T, tpb), B), dim3(256), 2 * T * sizeof(int),
-                     (hipStream_t)stream, ids, (const bf16_t*)embed, (const bf16_t*)img, (const bf16_t*)spi,
-                     spi_offset, (bf16_t*)out, status, T, C, n_patch, patch_id, bbox_id, im_start_id, im_end_id,
+                     (hipStream_t)stream, ids, (const h16_t*)embed, (const h16_t*)img, (const h16_t*)spi,
+                     spi_offset, (h16_t*)out, status, T, C, n_patch, patch_id, bbox_id, im_start_id, im_end_id,
                      vocab, tpb);
   G4R_CHECK_LAUNCH("splice_embed");
   return G4R_OK;
 }
 
+#ifndef G4R_F16   // fp32 in, integers out: one instantiation serves both storage types
 int g4r_argmax_rows_f32(const float* logits, long ld, int rows, int N, long* out, void* stream) {
   G4R_REQUIRE(rows >= 0 && N > 0, "argmax_rows: bad shape");
   if (rows == 0) return G4R_OK;
@@ -815,12 +817,14 @@ int g4r_batch_advance(const long* nxt, int B, long* tok, int* tok32, long* out_i
   return G4R_OK;
 }
 
+#endif  // !G4R_F16
+
 int g4r_add_rows_bf16(const void* a, const void* b, void* y, long rows, int C, long brows, void* stream) {
   G4R_REQUIRE(rows >= 0 && C % 8 == 0 && brows > 0, "add_rows: bad shape");
   if (rows == 0) return G4R_OK;
   G4R_REQUIRE(a && b && y, "add_rows: null pointer");
   hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, rows, C, brows);
+                     (const h16_t*)a, (const h16_t*)b, (h16_t*)y, rows, C, brows);
   G4R_CHECK_LAUNCH("add_rows");
   return G4R_OK;
 }
@@ -829,11 +833,12 @@ int g4r_cast_f32_to_bf16(const float* x, void* y, long n, void* stream) {
   if (n <= 0) return G4R_OK;
   G4R_REQUIRE(x && y, "cast: null pointer");
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x,
-                     (bf16_t*)y, n);
+                     (h16_t*)y, n);
   G4R_CHECK_LAUNCH("cast_f32_bf16");
   return G4R_OK;
 }
 
+#ifndef G4R_F16   // u8 -> fp32: independent of the storage type
 int g4r_image_preprocess_u8_f32(const void* image, int height, int width, long row_bytes, int bgr, float* out,
                                 int out_h, int out_w, float mean_r, float mean_g, float mean_b, float std_r,
                                 float std_g, float std_b, void* stream) {
@@ -846,5 +851,6 @@ int g4r_image_preprocess_u8_f32(const void* image, int height, int width, long r
   G4R_CHECK_LAUNCH("image_preprocess");
   return G4R_OK;
 }
+#endif  // !G4R_F16
 
 }  // extern "C"

@@ -27,16 +27,15 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct GemmArgs {
-  const bf16_t* A;
-  const bf16_t* W;
+  const h16_t* A;
+  const h16_t* W;
   void* C;               // bf16 or f32 [M, ldc]
   float* ws;             // split-K partials [splits][M][N] (fp32), or null
   const float* bias;     // [N] fp32 or null
-  const bf16_t* residual;  // [M, ldr] bf16 or null
-  const bf16_t* zeros;   // >= 128 B of zeros (AMODE 1 padding source)
+  const h16_t* residual;  // [M, ldr] bf16 or null
+  const h16_t* zeros;   // >= 128 B of zeros (AMODE 1 padding source)
   long a_group_stride;   // AMODE 1: elements between groups
   int M, N, K;
   int lda, ldw, ldc, ldr;
@@ -56,9 +55,9 @@ struct GemmArgs {
   // act == 5 (fused q|k|v projection of a LLaMA layer, ring ping-pong tiles only): RoPE and the KV-cache append happen in
   // the epilogue -- what g4r_rope_qkv_bf16 did in a launch of its own.  Columns [0, HD) -> rotated q rows of rope_q,
   // [HD, 2 HD) -> rotated k into the cache rows pos0 + t, [2 HD, 3 HD) -> v into the cache.  Row m = b * rope_T + t.
-  bf16_t* rope_q;              // [M][HD]
-  bf16_t* rope_k;              // cache base of this layer: + b * rope_kbatch + (pos0 + t) * rope_krow
-  bf16_t* rope_v;
+  h16_t* rope_q;              // [M][HD]
+  h16_t* rope_k;              // cache base of this layer: + b * rope_kbatch + (pos0 + t) * rope_krow
+  h16_t* rope_v;
   const float* rope_cos;       // [maxT][D/2] fp32
   const float* rope_sin;
   long rope_krow, rope_kbatch;
@@ -188,10 +187,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float16v (&acc)
           const int n = nw + j * 32 + q * 8;
           if (n >= p.N) continue;
           const float g0 = c[q * 4], u0 = c[q * 4 + 1], g1 = c[q * 4 + 2], u1 = c[q * 4 + 3];
-          const float s0 = bf16lo(pack_bf16x2(g0 / (1.f + __expf(-g0)), 0.f));
-          const float s1 = bf16lo(pack_bf16x2(g1 / (1.f + __expf(-g1)), 0.f));
-          bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + (n >> 1);
-          *reinterpret_cast<uint32_t*>(dst) = pack_bf16x2(s0 * u0, s1 * u1);
+          const float s0 = h16lo(pack_h16x2(g0 / (1.f + __expf(-g0)), 0.f));
+          const float s1 = h16lo(pack_h16x2(g1 / (1.f + __expf(-g1)), 0.f));
+          h16_t* dst = reinterpret_cast<h16_t*>(p.C) + (size_t)m * p.ldc + (n >> 1);
+          *reinterpret_cast<uint32_t*>(dst) = pack_h16x2(s0 * u0, s1 * u1);
         }
       } else if (m < p.M) {
 #pragma unroll
@@ -200,15 +199,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float16v (&acc)
           if (n >= p.N) continue;
           float v0 = c[q * 4], v1 = c[q * 4 + 1], v2 = c[q * 4 + 2], v3 = c[q * 4 + 3];
           if (p.residual) {
-            const bf16_t* rp = p.residual + (size_t)m * p.ldr + n;
+            const h16_t* rp = p.residual + (size_t)m * p.ldr + n;
             if (res_vec) {
               const uint2v rr = *reinterpret_cast<const uint2v*>(rp);
-              v0 += bf16lo(rr.x); v1 += bf16hi(rr.x); v2 += bf16lo(rr.y); v3 += bf16hi(rr.y);
+              v0 += h16lo(rr.x); v1 += h16hi(rr.x); v2 += h16lo(rr.y); v3 += h16hi(rr.y);
             } else {
-              v0 += bf16_to_f32(rp[0]);
-              if (n + 1 < p.N) v1 += bf16_to_f32(rp[1]);
-              if (n + 2 < p.N) v2 += bf16_to_f32(rp[2]);
-              if (n + 3 < p.N) v3 += bf16_to_f32(rp[3]);
+              v0 += h16_to_f32(rp[0]);
+              if (n + 1 < p.N) v1 += h16_to_f32(rp[1]);
+              if (n + 2 < p.N) v2 += h16_to_f32(rp[2]);
+              if (n + 3 < p.N) v3 += h16_to_f32(rp[3]);
             }
           }
           if (p.out_f32) {
@@ -222,14 +221,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float16v (&acc)
               if (n + 3 < p.N) dst[3] = v3;
             }
           } else {
-            bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+            h16_t* dst = reinterpret_cast<h16_t*>(p.C) + (size_t)m * p.ldc + n;
             if (out_vec) {
-              *reinterpret_cast<uint2v*>(dst) = uint2v{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+              *reinterpret_cast<uint2v*>(dst) = uint2v{pack_h16x2(v0, v1), pack_h16x2(v2, v3)};
             } else {
-              dst[0] = f32_to_bf16(v0);
-              if (n + 1 < p.N) dst[1] = f32_to_bf16(v1);
-              if (n + 2 < p.N) dst[2] = f32_to_bf16(v2);
-              if (n + 3 < p.N) dst[3] = f32_to_bf16(v3);
+              dst[0] = f32_to_h16(v0);
+              if (n + 1 < p.N) dst[1] = f32_to_h16(v1);
+              if (n + 2 < p.N) dst[2] = f32_to_h16(v2);
+              if (n + 3 < p.N) dst[3] = f32_to_h16(v3);
             }
           }
         }
@@ -304,7 +303,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, float16v (&
           const int col = n_wave0 + rcol - part * p.rope_HD;   // column inside q / k / v
           // the unfused path stored the projection as bf16 before rotating it: keep that rounding point
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = bf16_to_f32(f32_to_bf16(v[k]));
+          for (int k = 0; k < 8; ++k) v[k] = h16_to_f32(f32_to_h16(v[k]));
           if (part < 2) {
             const float4v m0 = *reinterpret_cast<const float4v*>(mate_lds + r * E::RS + rcol * 4);
             const float4v m1 = *reinterpret_cast<const float4v*>(mate_lds + r * E::RS + rcol * 4 + 16);
@@ -317,15 +316,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, float16v (&
             const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              const float mate = bf16_to_f32(f32_to_bf16(u[k]));
+              const float mate = h16_to_f32(f32_to_h16(u[k]));
               // rotate_half: first half  a' = a cos - b sin ; second half  b' = b cos + a sin   (a = x[d], b = x[d + 64])
               v[k] = second ? __builtin_fmaf(v[k], cs[k], mate * sn[k]) : __builtin_fmaf(v[k], cs[k], -(mate * sn[k]));
             }
           }
-          bf16_t* dst = part == 0 ? p.rope_q + (size_t)m * p.rope_HD + col
+          h16_t* dst = part == 0 ? p.rope_q + (size_t)m * p.rope_HD + col
                                   : (part == 1 ? p.rope_k : p.rope_v) + (size_t)b * p.rope_kbatch + (size_t)pos * p.rope_krow + col;
-          *reinterpret_cast<uint4v*>(dst) = uint4v{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                                   pack_bf16x2(v[6], v[7])};
+          *reinterpret_cast<uint4v*>(dst) = uint4v{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]),
+                                                   pack_h16x2(v[6], v[7])};
         }
         __syncthreads();                                     // the neighbour is done with this wave's slice
       }
@@ -372,14 +371,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, float16v (&
       }
       if (swiglu) {
         // (gate, up) column pairs -> N/2 output columns (the launcher guarantees N % 4 == 0, bf16 out, no bias/residual)
-        bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + (n >> 1);
+        h16_t* dst = reinterpret_cast<h16_t*>(p.C) + (size_t)m * p.ldc + (n >> 1);
         uint32_t w2[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const float g0 = v[4 * k], u0 = v[4 * k + 1], g1 = v[4 * k + 2], u1 = v[4 * k + 3];
-          const float s0 = bf16lo(pack_bf16x2(g0 / (1.f + __expf(-g0)), 0.f));
-          const float s1 = bf16lo(pack_bf16x2(g1 / (1.f + __expf(-g1)), 0.f));
-          w2[k] = pack_bf16x2(s0 * u0, s1 * u1);
+          const float s0 = h16lo(pack_h16x2(g0 / (1.f + __expf(-g0)), 0.f));
+          const float s1 = h16lo(pack_h16x2(g1 / (1.f + __expf(-g1)), 0.f));
+          w2[k] = pack_h16x2(s0 * u0, s1 * u1);
         }
         if (nv == 8 && (p.ldc & 3) == 0) {
           *reinterpret_cast<uint2v*>(dst) = uint2v{w2[0], w2[1]};
@@ -390,13 +389,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, float16v (&
         continue;
       }
       if (p.residual) {
-        const bf16_t* rp = p.residual + (size_t)m * p.ldr + n;
+        const h16_t* rp = p.residual + (size_t)m * p.ldr + n;
         if (nv == 8 && vec_n && (p.ldr & 7) == 0) {
           const uint4v rr = *reinterpret_cast<const uint4v*>(rp);
-          v[0] += bf16lo(rr.x); v[1] += bf16hi(rr.x); v[2] += bf16lo(rr.y); v[3] += bf16hi(rr.y);
-          v[4] += bf16lo(rr.z); v[5] += bf16hi(rr.z); v[6] += bf16lo(rr.w); v[7] += bf16hi(rr.w);
+          v[0] += h16lo(rr.x); v[1] += h16hi(rr.x); v[2] += h16lo(rr.y); v[3] += h16hi(rr.y);
+          v[4] += h16lo(rr.z); v[5] += h16hi(rr.z); v[6] += h16lo(rr.w); v[7] += h16hi(rr.w);
         } else {
-          for (int k = 0; k < nv; ++k) v[k] += bf16_to_f32(rp[k]);
+          for (int k = 0; k < nv; ++k) v[k] += h16_to_f32(rp[k]);
         }
       }
       if (p.out_f32) {
@@ -408,12 +407,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, float16v (&
           for (int k = 0; k < nv; ++k) dst[k] = v[k];
         }
       } else {
-        bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+        h16_t* dst = reinterpret_cast<h16_t*>(p.C) + (size_t)m * p.ldc + n;
         if (nv == 8 && vec_n && (p.ldc & 7) == 0) {
-          *reinterpret_cast<uint4v*>(dst) = uint4v{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                                   pack_bf16x2(v[6], v[7])};
+          *reinterpret_cast<uint4v*>(dst) = uint4v{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]),
+                                                   pack_h16x2(v[6], v[7])};
         } else {
-          for (int k = 0; k < nv; ++k) dst[k] = f32_to_bf16(v[k]);
+          for (int k = 0; k < nv; ++k) dst[k] = f32_to_h16(v[k]);
         }
       }
     }
@@ -469,9 +468,9 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
   if (t_end > nt_total) t_end = nt_total;
 
   // ---- per-thread staging descriptors ----
-  const bf16_t* a_src[NA];
+  const h16_t* a_src[NA];
   int a_y[NA], a_x[NA];
-  const bf16_t* b_src[NB];
+  const h16_t* b_src[NB];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int pslot = (j * NW + wave) * 64 + lane;
@@ -530,7 +529,7 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       if (p.dbg == 3 && t != t_begin) break;  // ablation: A staged once, W keeps streaming
-      const bf16_t* src = a_src[j] + a_off;
+      const h16_t* src = a_src[j] + a_off;
       if (AMODE == 1) {
         const int yy = a_y[j] + dy, xx = a_x[j] + dx;
         if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.Wd) src = p.zeros + (lane & 7) * 8;
@@ -546,7 +545,7 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       if (p.dbg == 5 && t != t_begin) break;  // ablation: W staged once, A keeps streaming
-      const bf16_t* src = b_src[j] + k0;
+      const h16_t* src = b_src[j] + k0;
       char* dst_wave = sb + (j * NW + wave) * 1024;
       if (GLDS) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -583,18 +582,18 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
         const int slot = ((kk * 2 + fhi) ^ fsw) << 4;
-        bf16x8 af[TM], wf[TN];
+        h16x8 af[TM], wf[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          af[i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + slot);
+          af[i] = *reinterpret_cast<const h16x8*>(sa + a_row_off + i * 32 * ROWB + slot);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
+          wf[j] = *reinterpret_cast<const h16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = G4R_MFMA_32X32X16(wf[j], af[i], acc[i][j], 0, 0, 0);
       }
     } else if constexpr (STYLE == 3) {
       // every fragment read of the K tile goes out back to back and each k-step's MFMAs wait for THEIR reads only (counted
@@ -602,7 +601,7 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
       // MFMA -- an LDS round trip in front of every k-step (the interleaved style above: ~150 cycles x KK per K tile against
       // 32 x KK of MFMA on a 64 x 64 tile) -- and the burst style below makes the first MFMA wait for ALL the reads.  Each
       // wait is tied ("+v") to the fragments it releases so that their MFMAs cannot move above it.
-      bf16x8 af[KK][TM], wf[KK][TN];
+      h16x8 af[KK][TM], wf[KK][TN];
       const unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(sa + a_row_off);
       const unsigned lb = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(sb + b_row_off);
 #pragma unroll
@@ -626,21 +625,21 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = G4R_MFMA_32X32X16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       // one workgroup per CU: request every fragment of the K tile up front, then one MFMA burst
-      bf16x8 af[KK][TM], wf[KK][TN];
+      h16x8 af[KK][TM], wf[KK][TN];
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
         const int slot = ((kk * 2 + fhi) ^ fsw) << 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          af[kk][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + slot);
+          af[kk][i] = *reinterpret_cast<const h16x8*>(sa + a_row_off + i * 32 * ROWB + slot);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          wf[kk][j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
+          wf[kk][j] = *reinterpret_cast<const h16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the burst
 #pragma unroll
@@ -649,7 +648,7 @@ void gemm_bf16_nt_kernel(GemmArgs p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = G4R_MFMA_32X32X16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -720,10 +719,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
           if (s0 + u < p.splits) x += v[u];
       }
       if (p.act == 4) {
-        const float s0v = bf16lo(pack_bf16x2(x[0] / (1.f + __expf(-x[0])), 0.f));
-        const float s1v = bf16lo(pack_bf16x2(x[2] / (1.f + __expf(-x[2])), 0.f));
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + (c4 >> 1)) =
-            pack_bf16x2(s0v * x[1], s1v * x[3]);
+        const float s0v = h16lo(pack_h16x2(x[0] / (1.f + __expf(-x[0])), 0.f));
+        const float s1v = h16lo(pack_h16x2(x[2] / (1.f + __expf(-x[2])), 0.f));
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<h16_t*>(p.C) + (size_t)m * p.ldc + (c4 >> 1)) =
+            pack_h16x2(s0v * x[1], s1v * x[3]);
         continue;
       }
       if (p.bias) {
@@ -734,13 +733,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
       for (int e = 0; e < 4; ++e) x[e] = apply_act(x[e], p.act);
       if (p.residual) {
         const uint2v r = *reinterpret_cast<const uint2v*>(p.residual + (size_t)m * p.ldr + c4);
-        x[0] += bf16lo(r.x); x[1] += bf16hi(r.x); x[2] += bf16lo(r.y); x[3] += bf16hi(r.y);
+        x[0] += h16lo(r.x); x[1] += h16hi(r.x); x[2] += h16lo(r.y); x[3] += h16hi(r.y);
       }
       if (p.out_f32) {
         *reinterpret_cast<float4v*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + c4) = x;
       } else {
-        const uint2v w = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
-        *reinterpret_cast<uint2v*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + c4) = w;
+        const uint2v w = {pack_h16x2(x[0], x[1]), pack_h16x2(x[2], x[3])};
+        *reinterpret_cast<uint2v*>(reinterpret_cast<h16_t*>(p.C) + (size_t)m * p.ldc + c4) = w;
       }
     }
     return;
@@ -757,8 +756,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
         g += v.x;
         u += v.y;
       }
-      const float sg = bf16lo(pack_bf16x2(g / (1.f + __expf(-g)), 0.f));
-      reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + c] = f32_to_bf16(sg * u);
+      const float sg = h16lo(pack_h16x2(g / (1.f + __expf(-g)), 0.f));
+      reinterpret_cast<h16_t*>(p.C)[(size_t)m * p.ldc + c] = f32_to_h16(sg * u);
     }
     return;
   }
@@ -769,18 +768,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
     for (int s = 0; s < p.splits; ++s) x += p.ws[(size_t)s * total + i];
     if (p.bias) x += p.bias[n];
     x = apply_act(x, p.act);
-    if (p.residual) x += bf16_to_f32(p.residual[(size_t)m * p.ldr + n]);
+    if (p.residual) x += h16_to_f32(p.residual[(size_t)m * p.ldr + n]);
     if (p.out_f32)
       reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = x;
     else
-      reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(x);
+      reinterpret_cast<h16_t*>(p.C)[(size_t)m * p.ldc + n] = f32_to_h16(x);
   }
 }
 
 // Tiny/irregular contractions (K not a multiple of 64, e.g. the Linear(4,256) of pos_embedd,
 // gpt4roi/models/layers.py:260-267): one thread per output, fp32 accumulate.  Not a hot path.
-__global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restrict__ A,
-                                                           const bf16_t* __restrict__ W,
+__global__ __launch_bounds__(256) void small_linear_kernel(const h16_t* __restrict__ A,
+                                                           const h16_t* __restrict__ W,
                                                            const float* __restrict__ bias,
                                                            void* __restrict__ C, int M, int N, int K,
                                                            int lda, int ldw, int ldc, int act,
@@ -790,13 +789,13 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restr
     const int n = (int)(i % N);
     const long m = i / N;
     float x = 0.f;
-    for (int k = 0; k < K; ++k) x += bf16_to_f32(A[m * lda + k]) * bf16_to_f32(W[(size_t)n * ldw + k]);
+    for (int k = 0; k < K; ++k) x += h16_to_f32(A[m * lda + k]) * h16_to_f32(W[(size_t)n * ldw + k]);
     if (bias) x += bias[n];
     x = apply_act(x, act);
     if (out_f32)
       reinterpret_cast<float*>(C)[m * ldc + n] = x;
     else
-      reinterpret_cast<bf16_t*>(C)[m * ldc + n] = f32_to_bf16(x);
+      reinterpret_cast<h16_t*>(C)[m * ldc + n] = f32_to_h16(x);
   }
 }
 
@@ -807,10 +806,10 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restr
 // reduction.  Same epilogues as the GEMM (bias, residual, SwiGLU over interleaved row pairs, fp32 out).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dot8_bf16(const uint4v& a, const uint4v& b, float acc) {
-  acc += bf16lo(a.x) * bf16lo(b.x); acc += bf16hi(a.x) * bf16hi(b.x);
-  acc += bf16lo(a.y) * bf16lo(b.y); acc += bf16hi(a.y) * bf16hi(b.y);
-  acc += bf16lo(a.z) * bf16lo(b.z); acc += bf16hi(a.z) * bf16hi(b.z);
-  acc += bf16lo(a.w) * bf16lo(b.w); acc += bf16hi(a.w) * bf16hi(b.w);
+  acc += h16lo(a.x) * h16lo(b.x); acc += h16hi(a.x) * h16hi(b.x);
+  acc += h16lo(a.y) * h16lo(b.y); acc += h16hi(a.y) * h16hi(b.y);
+  acc += h16lo(a.z) * h16lo(b.z); acc += h16hi(a.z) * h16hi(b.z);
+  acc += h16lo(a.w) * h16lo(b.w); acc += h16hi(a.w) * h16hi(b.w);
   return acc;
 }
 
@@ -827,11 +826,11 @@ __device__ __forceinline__ float dot8_bf16(const uint4v& a, const uint4v& b, flo
 // x is staged in dynamic LDS (2 K bytes) next to a 16-byte static array: both must fit the default 64 KB limit
 #define G4R_GEMV_MAX_K 32736
 template <int R, int U, int XMODE, int NWV>
-__global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
-                                                        float eps, int mS, int mD, const bf16_t* __restrict__ W,
+__global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const h16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                        float eps, int mS, int mD, const h16_t* __restrict__ W,
                                                         void* __restrict__ C,
                                                         const float* __restrict__ bias,
-                                                        const bf16_t* __restrict__ residual, int N, int K, int ldw,
+                                                        const h16_t* __restrict__ residual, int N, int K, int ldw,
                                                         int act, int out_f32) {
   extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
   uint4v* xs = reinterpret_cast<uint4v*>(gemv_smem);
@@ -839,7 +838,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const bf16_t* __res
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nvec = K >> 3;
   const int n0 = (blockIdx.x * NWV + wave) * R;
-  const bf16_t* wrow[R];
+  const h16_t* wrow[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) wrow[r] = W + (size_t)(n0 + r < N ? n0 + r : N - 1) * ldw;
   uint4v wv[U][R];
@@ -866,8 +865,8 @@ __global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const bf16_t* __res
       const int v = tid + i * 256;
       if (stager && v < nvec) {
         const uint4v r = *reinterpret_cast<const uint4v*>(x + v * 8);
-        f[i][0] = bf16lo(r.x); f[i][1] = bf16hi(r.x); f[i][2] = bf16lo(r.y); f[i][3] = bf16hi(r.y);
-        f[i][4] = bf16lo(r.z); f[i][5] = bf16hi(r.z); f[i][6] = bf16lo(r.w); f[i][7] = bf16hi(r.w);
+        f[i][0] = h16lo(r.x); f[i][1] = h16hi(r.x); f[i][2] = h16lo(r.y); f[i][3] = h16hi(r.y);
+        f[i][4] = h16lo(r.z); f[i][5] = h16hi(r.z); f[i][6] = h16lo(r.w); f[i][7] = h16hi(r.w);
 #pragma unroll
         for (int k = 0; k < 8; ++k) s2 += f[i][k] * f[i][k];
       }
@@ -887,10 +886,10 @@ __global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const bf16_t* __res
         const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
         float o[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = bf16_to_f32(f32_to_bf16(f[i][k] * rstd)) * g[k];
+        for (int k = 0; k < 8; ++k) o[k] = h16_to_f32(f32_to_h16(f[i][k] * rstd)) * g[k];
         uint4v w;
-        w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
-        w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+        w.x = pack_h16x2(o[0], o[1]); w.y = pack_h16x2(o[2], o[3]);
+        w.z = pack_h16x2(o[4], o[5]); w.w = pack_h16x2(o[6], o[7]);
         xs[v] = w;
       }
     }
@@ -912,8 +911,8 @@ __global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const bf16_t* __res
         a2[4] += w * o1.x; a2[5] += w * o1.y; a2[6] += w * o1.z; a2[7] += w * o1.w;
       }
       uint4v w8;
-      w8.x = pack_bf16x2(a2[0] / Lt, a2[1] / Lt); w8.y = pack_bf16x2(a2[2] / Lt, a2[3] / Lt);
-      w8.z = pack_bf16x2(a2[4] / Lt, a2[5] / Lt); w8.w = pack_bf16x2(a2[6] / Lt, a2[7] / Lt);
+      w8.x = pack_h16x2(a2[0] / Lt, a2[1] / Lt); w8.y = pack_h16x2(a2[2] / Lt, a2[3] / Lt);
+      w8.z = pack_h16x2(a2[4] / Lt, a2[5] / Lt); w8.w = pack_h16x2(a2[6] / Lt, a2[7] / Lt);
       xs[v] = w8;
     }
   } else {
@@ -945,8 +944,8 @@ __global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const bf16_t* __res
     for (int r = 0; r < R; r += 2) {
       if (n0 + r + 1 < N) {
         const float g = acc[r], u = acc[r + 1];
-        const float sg = bf16lo(pack_bf16x2(g / (1.f + __expf(-g)), 0.f));
-        reinterpret_cast<bf16_t*>(C)[(n0 + r) >> 1] = f32_to_bf16(sg * u);
+        const float sg = h16lo(pack_h16x2(g / (1.f + __expf(-g)), 0.f));
+        reinterpret_cast<h16_t*>(C)[(n0 + r) >> 1] = f32_to_h16(sg * u);
       }
     }
     return;
@@ -958,17 +957,17 @@ __global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const bf16_t* __res
     float vv = acc[r];
     if (bias) vv += bias[n];
     vv = apply_act(vv, act);
-    if (residual) vv += bf16_to_f32(residual[n]);
+    if (residual) vv += h16_to_f32(residual[n]);
     if (out_f32)
       reinterpret_cast<float*>(C)[n] = vv;
     else
-      reinterpret_cast<bf16_t*>(C)[n] = f32_to_bf16(vv);
+      reinterpret_cast<h16_t*>(C)[n] = f32_to_h16(vv);
   }
 }
 
 template <int R, int U, int NWV>
-static void launch_gemv(int xmode, const bf16_t* x, const float* gamma, float eps, int mS, int mD, const bf16_t* W, void* C,
-                        const float* bias, const bf16_t* residual, int N, int K, int ldw, int act, int out_f32,
+static void launch_gemv(int xmode, const h16_t* x, const float* gamma, float eps, int mS, int mD, const h16_t* W, void* C,
+                        const float* bias, const h16_t* residual, int N, int K, int ldw, int act, int out_f32,
                         hipStream_t stream) {
   const int waves = g4r_ceil_div(N, R);
   const dim3 grid(g4r_ceil_div(waves, NWV)), block(NWV * 64);
@@ -985,8 +984,8 @@ static void launch_gemv(int xmode, const bf16_t* x, const float* gamma, float ep
 }
 
 // (R rows per wave, U K-steps in flight, waves per workgroup); variant >= 0: A/B probe (tools/gemm_bench.cpp v: cases)
-static void gemv_dispatch(int variant, int xmode, const bf16_t* x, const float* gamma, float eps, int mS, int mD,
-                          const bf16_t* W, void* C, const float* bias, const bf16_t* residual, int N, int K, int ldw,
+static void gemv_dispatch(int variant, int xmode, const h16_t* x, const float* gamma, float eps, int mS, int mD,
+                          const h16_t* W, void* C, const float* bias, const h16_t* residual, int N, int K, int ldw,
                           int act, int out_f32, hipStream_t st) {
   if (variant < 0) variant = 2;   // R = 2, U = 4, 8 waves: best or within noise of the best on all five LLaMA-7B projections (profiles/r02_gemv_variants.txt)
 #define G4R_GEMV_CASE(v, R_, U_, NW_) \
@@ -1048,9 +1047,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   const int nt_total = p.K / BKT;
   if (t_end > nt_total) t_end = nt_total;
 
-  const bf16_t* a_src[NA];
+  const h16_t* a_src[NA];
   int a_y[NA], a_x[NA];
-  const bf16_t* b_src[NB];
+  const h16_t* b_src[NB];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int pslot = (j * NW + wave) * 64 + lane;
@@ -1104,7 +1103,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   auto piece = [&](int j, const TileSrc& ts, int buf) {
     char* sa = smem + buf * STAGE_BYTES;
     if (j < NA) {
-      const bf16_t* src = a_src[j] + ts.a_off;
+      const h16_t* src = a_src[j] + ts.a_off;
       if (AMODE == 1) {
         const int yy = a_y[j] + ts.dy, xx = a_x[j] + ts.dx;
         if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.Wd) src = p.zeros + (lane & 7) * 8;
@@ -1127,7 +1126,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   const int frow = lane & 31, fsw = (frow >> 1) & 7, fhi = lane >> 5;
   const int a_row_off = (wm * 128 + frow) * ROWB;
   const int b_row_off = (wn * 64 + frow) * ROWB;
-  bf16x8 af[2][TM], wf[2][TN];  // the fragments of ONE k-half (2 of the 4 MFMA k-steps)
+  h16x8 af[2][TM], wf[2][TN];  // the fragments of ONE k-half (2 of the 4 MFMA k-steps)
   auto ldfrag = [&](int buf, int h) {
     const char* sa = smem + buf * STAGE_BYTES;
     const char* sb = sa + A_BYTES;
@@ -1135,9 +1134,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     for (int k2 = 0; k2 < 2; ++k2) {
       const int slot = (((h * 2 + k2) * 2 + fhi) ^ fsw) << 4;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[k2][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + slot);
+      for (int i = 0; i < TM; ++i) af[k2][i] = *reinterpret_cast<const h16x8*>(sa + a_row_off + i * 32 * ROWB + slot);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) wf[k2][j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
+      for (int j = 0; j < TN; ++j) wf[k2][j] = *reinterpret_cast<const h16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
     }
   };
   // 16 MFMAs with three issue slots (after the 3rd, 8th and 13th) for LDS-DMA pieces: among MFMAs a piece
@@ -1151,7 +1150,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = G4R_MFMA_32X32X16(wf[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
           ++n;
           if (n == 3 || n == 8 || n == 13) {
             __builtin_amdgcn_sched_barrier(0);
@@ -1330,12 +1329,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   const bool wg_probe = PROBE && blockIdx.y == 0 && wave == 0 && lane == 0;
   if (PROBE) { if (wg_probe) { wg_stamps[0] = __builtin_amdgcn_s_memtime(); wg_stamps[4] = __builtin_amdgcn_s_getreg(6164); wg_stamps[5] = wall_clock64(); } }
 
-  const bf16_t* a_src[NA];
+  const h16_t* a_src[NA];
   int a_y[NA], a_x[NA];
   int a_h[NA], a_w[NA];                    // AMODE 2: the row's own map size (rows of several pyramid levels in one GEMM)
   unsigned a_ok[NA];
   int a_pitch[NA];
-  const bf16_t* b_src[NB];
+  const h16_t* b_src[NB];
   int a_voff[NA], b_voff[NB];              // BUF: byte offsets of this lane's 16 bytes from the matrix base (k = 0)
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
@@ -1437,7 +1436,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
         g4r_buffer_piece(p.A, p.a_bytes, sa + (j * NW + wave) * 1024, voff, ts.soff);
         return;
       }
-      const bf16_t* src = a_src[j] + ts.a_off;
+      const h16_t* src = a_src[j] + ts.a_off;
       if (AMODE == 2) src += ts.dy * a_pitch[j] + ts.dx * p.lda;
       if (AMODE >= 1) {
         if (!((a_ok[j] >> ts.tap) & 1u)) src = p.zeros + (lane & 3) * 8;
@@ -1468,7 +1467,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   const int frow = lane & 31, fsw = (frow >> 2) & 3, fhi = lane >> 5;
   const int a_row_off = (wm * WTM + frow) * ROWB;
   const int b_row_off = (wn * WTN + frow) * ROWB;
-  bf16x8 af[2][TM], wf[2][TN];
+  h16x8 af[2][TM], wf[2][TN];
   // the 2 x (TM + TN) fragment reads of a K tile in three chunks
   auto ldchunk = [&](int buf, int c) {
     const char* sa = smem + buf * STAGE_BYTES;
@@ -1476,17 +1475,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
     const int s0 = ((0 * 2 + fhi) ^ fsw) << 4, s1 = ((1 * 2 + fhi) ^ fsw) << 4;
     if (c == 0) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + s0);
+      for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const h16x8*>(sa + a_row_off + i * 32 * ROWB + s0);
     } else if (c == 1) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) wf[0][j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + s0);
+      for (int j = 0; j < TN; ++j) wf[0][j] = *reinterpret_cast<const h16x8*>(sb + b_row_off + j * 32 * ROWB + s0);
 #pragma unroll
-      for (int i = 0; i < TM / 2; ++i) af[1][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + s1);
+      for (int i = 0; i < TM / 2; ++i) af[1][i] = *reinterpret_cast<const h16x8*>(sa + a_row_off + i * 32 * ROWB + s1);
     } else {
 #pragma unroll
-      for (int i = TM / 2; i < TM; ++i) af[1][i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + s1);
+      for (int i = TM / 2; i < TM; ++i) af[1][i] = *reinterpret_cast<const h16x8*>(sa + a_row_off + i * 32 * ROWB + s1);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) wf[1][j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + s1);
+      for (int j = 0; j < TN; ++j) wf[1][j] = *reinterpret_cast<const h16x8*>(sb + b_row_off + j * 32 * ROWB + s1);
     }
   };
   auto mma = [&]() {
@@ -1497,7 +1496,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = G4R_MFMA_32X32X16(wf[k2][j], af[k2][i], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -1637,9 +1636,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
   const int nt_total = p.K / BKT;
   if (t_end > nt_total) t_end = nt_total;
 
-  const bf16_t* a_src[NA];
+  const h16_t* a_src[NA];
   int a_yx[NA];
-  const bf16_t* b_src[NB];
+  const h16_t* b_src[NB];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int pslot = (j * NW + wave) * 64 + lane;
@@ -1693,7 +1692,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
   auto piece = [&](int j, const TileSrc& ts, int buf) {
     char* sa = smem + buf * STAGE_BYTES;
     if (j < NA) {
-      const bf16_t* src = a_src[j] + ts.a_off;
+      const h16_t* src = a_src[j] + ts.a_off;
       if (AMODE == 1) {
         const int yy = (a_yx[j] >> 16) + ts.dy, xx = (a_yx[j] & 0xffff) + ts.dx;
         if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.Wd) src = p.zeros + (lane & 3) * 8;
@@ -1716,20 +1715,20 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
   const int a_row_off = (wm * 128 + frow) * ROWB;
   const int b_row_off = (wn * 128 + frow) * ROWB;
   const int slot_k0 = ((0 * 2 + fhi) ^ fsw) << 4, slot_k1 = ((1 * 2 + fhi) ^ fsw) << 4;
-  bf16x8 af0[TM], wf0[TN], af1[TM], wf1[TN];
+  h16x8 af0[TM], wf0[TN], af1[TM], wf1[TN];
 
-  auto ldfrag = [&](bf16x8 (&AF)[TM], bf16x8 (&WF)[TN], int buf, int slot) {
+  auto ldfrag = [&](h16x8 (&AF)[TM], h16x8 (&WF)[TN], int buf, int slot) {
     const char* sa = smem + buf * STAGE_BYTES;
     const char* sb = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) AF[i] = *reinterpret_cast<const bf16x8*>(sa + a_row_off + i * 32 * ROWB + slot);
+    for (int i = 0; i < TM; ++i) AF[i] = *reinterpret_cast<const h16x8*>(sa + a_row_off + i * 32 * ROWB + slot);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) WF[j] = *reinterpret_cast<const bf16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
+    for (int j = 0; j < TN; ++j) WF[j] = *reinterpret_cast<const h16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
   };
-  auto mma_row = [&](bf16x8 (&AF)[TM], bf16x8 (&WF)[TN], auto irow) {
+  auto mma_row = [&](h16x8 (&AF)[TM], h16x8 (&WF)[TN], auto irow) {
     constexpr int i = decltype(irow)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[j], AF[i], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < TN; ++j) acc[i][j] = G4R_MFMA_32X32X16(WF[j], AF[i], acc[i][j], 0, 0, 0);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -2024,7 +2023,9 @@ extern "C" {
 //   1 / 2: skip the staging / the compute of the generic kernel's loop;  7: taps-outermost K order of the conv (A/B arm);
 //   8: pieces by global_load_lds instead of buffer loads;  9 / 10: force the M-fastest / N-fastest tile order;
 //   11: the round-2 workgroup -> tile map (tiles only, every XCD sees all K slices);  100 + v: GEMV variant v.
+#ifndef G4R_F16
 void g4r_gemm_debug_mode(int mode) { g_gemm_dbg = mode; }
+#endif
 
 // See include/g4r_kernels.h for the contract.
 // C = A W^T as `*splits_out` fp32 K-slice partials [slice][M][N] in `workspace` (>= splits * M * N floats), WITHOUT the reduce
@@ -2036,7 +2037,7 @@ int g4r_gemm_bf16_nt_partials(const void* A, const void* W, float* workspace, in
   G4R_REQUIRE(A && W && workspace && splits_out, "gemm_partials: null pointer");
   G4R_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && splits >= 2, "gemm_partials: 16-byte rows, splits >= 2");
   GemmArgs p = {};
-  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = workspace; p.ws = workspace;
+  p.A = (const h16_t*)A; p.W = (const h16_t*)W; p.C = workspace; p.ws = workspace;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = N; p.ldr = 0;
   p.act = 0; p.out_f32 = 1; p.dbg = g_gemm_dbg;
   p.n_fastest = (long)M * 1 > (long)N * 2;
@@ -2063,12 +2064,12 @@ int g4r_gemm_qkv_rope_bf16(const void* A, const void* W, int B, int T, int K, in
   if (tile_cfg == 0) tile_cfg = 28;
   G4R_REQUIRE(tile_cfg == 24 || tile_cfg == 28, "gemm_qkv_rope: ring ping-pong tiles only (24 / 28)");
   GemmArgs p = {};
-  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = q_out;
+  p.A = (const h16_t*)A; p.W = (const h16_t*)W; p.C = q_out;
   p.M = B * T; p.N = 3 * heads * head_dim; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = heads * head_dim;
   p.act = 5; p.dbg = g_gemm_dbg;
   p.n_fastest = 0;
   p.splits = 1;
-  p.rope_q = (bf16_t*)q_out; p.rope_k = (bf16_t*)k_cache; p.rope_v = (bf16_t*)v_cache;
+  p.rope_q = (h16_t*)q_out; p.rope_k = (h16_t*)k_cache; p.rope_v = (h16_t*)v_cache;
   p.rope_cos = cos_tab; p.rope_sin = sin_tab; p.rope_krow = cache_row; p.rope_kbatch = cache_batch;
   p.rope_T = T; p.rope_pos0 = pos0; p.rope_HD = heads * head_dim;
   return launch_gemm<0>(p, tile_cfg, (hipStream_t)stream);
@@ -2085,8 +2086,8 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
               "gemm: swiglu epilogue needs N % 4 == 0, bf16 output, no bias/residual");
   if (M == 1 && K % 8 == 0 && (ldw % 8) == 0 && splits == 1 && K >= 512 && K <= G4R_GEMV_MAX_K && (act != 4 || N % 4 == 0)) {
     // single-token decode: weight-streaming GEMV
-    gemv_dispatch(g_gemm_dbg >= 100 ? g_gemm_dbg - 100 : -1, 0, (const bf16_t*)A, nullptr, 0.f, 0, 0, (const bf16_t*)W, C,
-                  bias, (const bf16_t*)residual, N, K, ldw, act, out_f32, (hipStream_t)stream);
+    gemv_dispatch(g_gemm_dbg >= 100 ? g_gemm_dbg - 100 : -1, 0, (const h16_t*)A, nullptr, 0.f, 0, 0, (const h16_t*)W, C,
+                  bias, (const h16_t*)residual, N, K, ldw, act, out_f32, (hipStream_t)stream);
     G4R_CHECK_LAUNCH("gemv_bf16");
     return G4R_OK;
   }
@@ -2096,7 +2097,7 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(small_linear_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)A, (const bf16_t*)W, bias, C, M, N, K, lda, ldw, ldc, act, out_f32);
+                       (const h16_t*)A, (const h16_t*)W, bias, C, M, N, K, lda, ldw, ldc, act, out_f32);
     G4R_CHECK_LAUNCH("small_linear");
     return G4R_OK;
   }
@@ -2104,8 +2105,8 @@ int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, c
   G4R_REQUIRE(splits >= 1, "gemm: splits >= 1");
   G4R_REQUIRE(splits == 1 || workspace, "gemm: split-K needs a workspace of splits*M*N floats");
   GemmArgs p = {};
-  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.ws = workspace; p.bias = bias;
-  p.residual = (const bf16_t*)residual;
+  p.A = (const h16_t*)A; p.W = (const h16_t*)W; p.C = C; p.ws = workspace; p.bias = bias;
+  p.residual = (const h16_t*)residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.act = act; p.out_f32 = out_f32; p.dbg = g_gemm_dbg;
   p.n_fastest = (long)M * 1 > (long)N * 2;
@@ -2122,8 +2123,8 @@ int g4r_gemv_rmsnorm_bf16(const void* x, const float* gamma, float eps, const vo
   G4R_REQUIRE(act >= 0 && act <= 4, "gemv: act must be 0..4");
   G4R_REQUIRE(act != 4 || (N % 4 == 0 && !residual && !bias && !out_f32), "gemv: swiglu needs N % 4 == 0, bf16 output");
   G4R_REQUIRE(K <= (gamma ? 8192 : G4R_GEMV_MAX_K), "gemv: K <= 8192 with the fused norm, <= 32736 without (x is staged in 64 KB of LDS)");
-  gemv_dispatch(g_gemm_dbg >= 100 ? g_gemm_dbg - 100 : -1, gamma ? 1 : 0, (const bf16_t*)x, gamma, eps, 0, 0,
-                (const bf16_t*)W, C, bias, (const bf16_t*)residual, N, K, ldw, act, out_f32, (hipStream_t)stream);
+  gemv_dispatch(g_gemm_dbg >= 100 ? g_gemm_dbg - 100 : -1, gamma ? 1 : 0, (const h16_t*)x, gamma, eps, 0, 0,
+                (const h16_t*)W, C, bias, (const h16_t*)residual, N, K, ldw, act, out_f32, (hipStream_t)stream);
   G4R_CHECK_LAUNCH("gemv_rmsnorm_bf16");
   return G4R_OK;
 }
@@ -2136,7 +2137,7 @@ int g4r_gemv_attn_merge_bf16(const float* partials, int splits, int head_dim, co
   G4R_REQUIRE(partials && W && C, "gemv_attn_merge: null pointer");
   G4R_REQUIRE(splits >= 1 && splits <= 64 && (head_dim == 64 || head_dim == 128) && K % head_dim == 0,
               "gemv_attn_merge: splits in [1, 64], head_dim 64 or 128 dividing K");
-  gemv_dispatch(-1, 2, nullptr, partials, 0.f, splits, head_dim, (const bf16_t*)W, C, bias, (const bf16_t*)residual, N, K,
+  gemv_dispatch(-1, 2, nullptr, partials, 0.f, splits, head_dim, (const h16_t*)W, C, bias, (const h16_t*)residual, N, K,
                 ldw, 0, out_f32, (hipStream_t)stream);
   G4R_CHECK_LAUNCH("gemv_attn_merge_bf16");
   return G4R_OK;
@@ -2153,8 +2154,8 @@ int g4r_conv3x3_nhwc_bf16(const void* X, const void* W, void* Y, const float* bi
   G4R_REQUIRE(act >= 0 && act <= 3, "conv3x3: act must be 0..3");
   G4R_REQUIRE(splits >= 1 && (splits == 1 || workspace), "conv3x3: split-K needs a workspace");
   GemmArgs p = {};
-  p.A = (const bf16_t*)X; p.W = (const bf16_t*)W; p.C = Y; p.ws = workspace; p.bias = bias;
-  p.zeros = (const bf16_t*)zeros;
+  p.A = (const h16_t*)X; p.W = (const h16_t*)W; p.C = Y; p.ws = workspace; p.bias = bias;
+  p.zeros = (const h16_t*)zeros;
   p.M = batch * H * Wd; p.N = Cout; p.K = groups * 9 * Cin;
   p.lda = Cin; p.ldw = p.K; p.ldc = Cout; p.ldr = 0;
   p.act = act; p.out_f32 = out_f32;
@@ -2187,7 +2188,7 @@ int g4r_conv3x3_mlvl_nhwc_bf16(const void* X, const void* W, void* Y, const floa
   G4R_REQUIRE(rows < (1L << 31), "conv3x3_mlvl: too many rows");
   for (int l = n_levels; l <= 4; ++l) p.lvl_start[l] = (int)rows;
   p.n_lvl = n_levels;
-  p.A = (const bf16_t*)X; p.W = (const bf16_t*)W; p.C = Y; p.bias = bias; p.zeros = (const bf16_t*)zeros;
+  p.A = (const h16_t*)X; p.W = (const h16_t*)W; p.C = Y; p.bias = bias; p.zeros = (const h16_t*)zeros;
   p.M = (int)rows; p.N = Cout; p.K = 9 * Cin;
   p.lda = Cin; p.ldw = p.K; p.ldc = Cout;
   p.act = act; p.H = level_h[0]; p.Wd = level_w[0]; p.Cin = Cin; p.groups = 1;

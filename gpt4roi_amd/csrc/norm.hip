@@ -29,14 +29,14 @@ constexpr int NORM_MAXV = 4;  // 16-B vectors per thread: rows up to 256*4*8 = 8
 
 // One workgroup per row; the row lives in registers (single HBM read).  cols % 8 == 0.
 //   y = (x - mean) * rstd * gamma + beta   (biased variance, eps inside the sqrt)
-__global__ __launch_bounds__(256) void layernorm_bf16_kernel(const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256) void layernorm_bf16_kernel(const h16_t* __restrict__ x,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
-                                                             bf16_t* __restrict__ y, int rows, int cols,
+                                                             h16_t* __restrict__ y, int rows, int cols,
                                                              long ldx, long ldy, float eps, int relu_in) {
   __shared__ float red[4];
   const int row = blockIdx.x;
-  const bf16_t* xr = x + (size_t)row * ldx;
+  const h16_t* xr = x + (size_t)row * ldx;
   const int nvec = cols >> 3;
   float f[NORM_MAXV][8];
   float s = 0.f;
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const bf16_t* __res
     const int v = threadIdx.x + i * 256;
     if (v < nvec) {
       const uint4v r = *reinterpret_cast<const uint4v*>(xr + v * 8);
-      f[i][0] = bf16lo(r.x); f[i][1] = bf16hi(r.x); f[i][2] = bf16lo(r.y); f[i][3] = bf16hi(r.y);
-      f[i][4] = bf16lo(r.z); f[i][5] = bf16hi(r.z); f[i][6] = bf16lo(r.w); f[i][7] = bf16hi(r.w);
+      f[i][0] = h16lo(r.x); f[i][1] = h16hi(r.x); f[i][2] = h16lo(r.y); f[i][3] = h16hi(r.y);
+      f[i][4] = h16lo(r.z); f[i][5] = h16hi(r.z); f[i][6] = h16lo(r.w); f[i][7] = h16hi(r.w);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         if (relu_in) f[i][k] = fmaxf(f[i][k], 0.f);
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const bf16_t* __res
       }
     }
   const float rstd = rsqrtf(block_sum(s2, red) / (float)cols + eps);
-  bf16_t* yr = y + (size_t)row * ldy;
+  h16_t* yr = y + (size_t)row * ldy;
 #pragma unroll
   for (int i = 0; i < NORM_MAXV; ++i) {
     const int v = threadIdx.x + i * 256;
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const bf16_t* __res
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] = (f[i][k] - mean) * rstd * g[k] + b[k];
       uint4v w;
-      w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
-      w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+      w.x = pack_h16x2(o[0], o[1]); w.y = pack_h16x2(o[2], o[3]);
+      w.z = pack_h16x2(o[4], o[5]); w.w = pack_h16x2(o[6], o[7]);
       *reinterpret_cast<uint4v*>(yr + v * 8) = w;
     }
   }
@@ -90,13 +90,13 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const bf16_t* __res
 
 // One workgroup per row.  y = x * rsqrt(mean(x^2) + eps) * gamma   (HF LlamaRMSNorm: the
 // normalised value is rounded to the storage dtype BEFORE the gamma multiply).
-__global__ __launch_bounds__(256) void rmsnorm_bf16_kernel(const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256) void rmsnorm_bf16_kernel(const h16_t* __restrict__ x,
                                                            const float* __restrict__ gamma,
-                                                           bf16_t* __restrict__ y, int rows, int cols,
+                                                           h16_t* __restrict__ y, int rows, int cols,
                                                            long ldx, long ldy, float eps) {
   __shared__ float red[4];
   const int row = blockIdx.x;
-  const bf16_t* xr = x + (size_t)row * ldx;
+  const h16_t* xr = x + (size_t)row * ldx;
   const int nvec = cols >> 3;
   float f[NORM_MAXV][8];
   float s2 = 0.f;
@@ -105,14 +105,14 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_kernel(const bf16_t* __restr
     const int v = threadIdx.x + i * 256;
     if (v < nvec) {
       const uint4v r = *reinterpret_cast<const uint4v*>(xr + v * 8);
-      f[i][0] = bf16lo(r.x); f[i][1] = bf16hi(r.x); f[i][2] = bf16lo(r.y); f[i][3] = bf16hi(r.y);
-      f[i][4] = bf16lo(r.z); f[i][5] = bf16hi(r.z); f[i][6] = bf16lo(r.w); f[i][7] = bf16hi(r.w);
+      f[i][0] = h16lo(r.x); f[i][1] = h16hi(r.x); f[i][2] = h16lo(r.y); f[i][3] = h16hi(r.y);
+      f[i][4] = h16lo(r.z); f[i][5] = h16hi(r.z); f[i][6] = h16lo(r.w); f[i][7] = h16hi(r.w);
 #pragma unroll
       for (int k = 0; k < 8; ++k) s2 += f[i][k] * f[i][k];
     }
   }
   const float rstd = rsqrtf(block_sum(s2, red) / (float)cols + eps);
-  bf16_t* yr = y + (size_t)row * ldy;
+  h16_t* yr = y + (size_t)row * ldy;
 #pragma unroll
   for (int i = 0; i < NORM_MAXV; ++i) {
     const int v = threadIdx.x + i * 256;
@@ -122,10 +122,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_kernel(const bf16_t* __restr
       const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
       float o[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = bf16_to_f32(f32_to_bf16(f[i][k] * rstd)) * g[k];
+      for (int k = 0; k < 8; ++k) o[k] = h16_to_f32(f32_to_h16(f[i][k] * rstd)) * g[k];
       uint4v w;
-      w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
-      w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+      w.x = pack_h16x2(o[0], o[1]); w.y = pack_h16x2(o[2], o[3]);
+      w.z = pack_h16x2(o[4], o[5]); w.w = pack_h16x2(o[6], o[7]);
       *reinterpret_cast<uint4v*>(yr + v * 8) = w;
     }
   }
@@ -136,9 +136,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bf16_kernel(const bf16_t* __restr
 // row, same summation order (s = 0, 1, ...), same rounding points, same element -> thread map: bit-identical to the two
 // launches (one launch and one 6 MB round trip less per LLaMA layer).
 __global__ __launch_bounds__(256) void rmsnorm_splitk_bf16_kernel(const float* __restrict__ partials, int splits,
-                                                                  long slice_stride, const bf16_t* __restrict__ residual,
-                                                                  long ldr, bf16_t* __restrict__ xout, long ldxo,
-                                                                  const float* __restrict__ gamma, bf16_t* __restrict__ y,
+                                                                  long slice_stride, const h16_t* __restrict__ residual,
+                                                                  long ldr, h16_t* __restrict__ xout, long ldxo,
+                                                                  const float* __restrict__ gamma, h16_t* __restrict__ y,
                                                                   long ldy, int cols, float eps) {
   __shared__ float red[4];
   const int row = blockIdx.x;
@@ -161,21 +161,21 @@ __global__ __launch_bounds__(256) void rmsnorm_splitk_bf16_kernel(const float* _
       }
       if (residual) {
         const uint4v r = *reinterpret_cast<const uint4v*>(residual + (size_t)row * ldr + v * 8);
-        acc[0] += bf16lo(r.x); acc[1] += bf16hi(r.x); acc[2] += bf16lo(r.y); acc[3] += bf16hi(r.y);
-        acc[4] += bf16lo(r.z); acc[5] += bf16hi(r.z); acc[6] += bf16lo(r.w); acc[7] += bf16hi(r.w);
+        acc[0] += h16lo(r.x); acc[1] += h16hi(r.x); acc[2] += h16lo(r.y); acc[3] += h16hi(r.y);
+        acc[4] += h16lo(r.z); acc[5] += h16hi(r.z); acc[6] += h16lo(r.w); acc[7] += h16hi(r.w);
       }
       uint4v w;
-      w.x = pack_bf16x2(acc[0], acc[1]); w.y = pack_bf16x2(acc[2], acc[3]);
-      w.z = pack_bf16x2(acc[4], acc[5]); w.w = pack_bf16x2(acc[6], acc[7]);
+      w.x = pack_h16x2(acc[0], acc[1]); w.y = pack_h16x2(acc[2], acc[3]);
+      w.z = pack_h16x2(acc[4], acc[5]); w.w = pack_h16x2(acc[6], acc[7]);
       *reinterpret_cast<uint4v*>(xout + (size_t)row * ldxo + v * 8) = w;
-      f[i][0] = bf16lo(w.x); f[i][1] = bf16hi(w.x); f[i][2] = bf16lo(w.y); f[i][3] = bf16hi(w.y);
-      f[i][4] = bf16lo(w.z); f[i][5] = bf16hi(w.z); f[i][6] = bf16lo(w.w); f[i][7] = bf16hi(w.w);
+      f[i][0] = h16lo(w.x); f[i][1] = h16hi(w.x); f[i][2] = h16lo(w.y); f[i][3] = h16hi(w.y);
+      f[i][4] = h16lo(w.z); f[i][5] = h16hi(w.z); f[i][6] = h16lo(w.w); f[i][7] = h16hi(w.w);
 #pragma unroll
       for (int k = 0; k < 8; ++k) s2 += f[i][k] * f[i][k];
     }
   }
   const float rstd = rsqrtf(block_sum(s2, red) / (float)cols + eps);
-  bf16_t* yr = y + (size_t)row * ldy;
+  h16_t* yr = y + (size_t)row * ldy;
 #pragma unroll
   for (int i = 0; i < NORM_MAXV; ++i) {
     const int v = threadIdx.x + i * 256;
@@ -185,10 +185,10 @@ __global__ __launch_bounds__(256) void rmsnorm_splitk_bf16_kernel(const float* _
       const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
       float o[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = bf16_to_f32(f32_to_bf16(f[i][k] * rstd)) * g[k];
+      for (int k = 0; k < 8; ++k) o[k] = h16_to_f32(f32_to_h16(f[i][k] * rstd)) * g[k];
       uint4v w;
-      w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
-      w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+      w.x = pack_h16x2(o[0], o[1]); w.y = pack_h16x2(o[2], o[3]);
+      w.z = pack_h16x2(o[4], o[5]); w.w = pack_h16x2(o[6], o[7]);
       *reinterpret_cast<uint4v*>(yr + v * 8) = w;
     }
   }
@@ -199,10 +199,10 @@ __global__ __launch_bounds__(256) void rmsnorm_splitk_bf16_kernel(const float* _
 // same summation order and rounding points: bit-identical to the two launches (CLIP fc2 -> next block's layer_norm1).
 __global__ __launch_bounds__(256) void layernorm_splitk_bf16_kernel(const float* __restrict__ partials, int splits,
                                                                     long slice_stride, const float* __restrict__ bias,
-                                                                    const bf16_t* __restrict__ residual, long ldr,
-                                                                    bf16_t* __restrict__ xout, long ldxo,
+                                                                    const h16_t* __restrict__ residual, long ldr,
+                                                                    h16_t* __restrict__ xout, long ldxo,
                                                                     const float* __restrict__ gamma,
-                                                                    const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                                    const float* __restrict__ beta, h16_t* __restrict__ y,
                                                                     long ldy, int cols, float eps) {
   __shared__ float red[4];
   const int row = blockIdx.x;
@@ -230,15 +230,15 @@ __global__ __launch_bounds__(256) void layernorm_splitk_bf16_kernel(const float*
       }
       if (residual) {
         const uint4v r = *reinterpret_cast<const uint4v*>(residual + (size_t)row * ldr + v * 8);
-        acc[0] += bf16lo(r.x); acc[1] += bf16hi(r.x); acc[2] += bf16lo(r.y); acc[3] += bf16hi(r.y);
-        acc[4] += bf16lo(r.z); acc[5] += bf16hi(r.z); acc[6] += bf16lo(r.w); acc[7] += bf16hi(r.w);
+        acc[0] += h16lo(r.x); acc[1] += h16hi(r.x); acc[2] += h16lo(r.y); acc[3] += h16hi(r.y);
+        acc[4] += h16lo(r.z); acc[5] += h16hi(r.z); acc[6] += h16lo(r.w); acc[7] += h16hi(r.w);
       }
       uint4v w;
-      w.x = pack_bf16x2(acc[0], acc[1]); w.y = pack_bf16x2(acc[2], acc[3]);
-      w.z = pack_bf16x2(acc[4], acc[5]); w.w = pack_bf16x2(acc[6], acc[7]);
+      w.x = pack_h16x2(acc[0], acc[1]); w.y = pack_h16x2(acc[2], acc[3]);
+      w.z = pack_h16x2(acc[4], acc[5]); w.w = pack_h16x2(acc[6], acc[7]);
       *reinterpret_cast<uint4v*>(xout + (size_t)row * ldxo + v * 8) = w;
-      f[i][0] = bf16lo(w.x); f[i][1] = bf16hi(w.x); f[i][2] = bf16lo(w.y); f[i][3] = bf16hi(w.y);
-      f[i][4] = bf16lo(w.z); f[i][5] = bf16hi(w.z); f[i][6] = bf16lo(w.w); f[i][7] = bf16hi(w.w);
+      f[i][0] = h16lo(w.x); f[i][1] = h16hi(w.x); f[i][2] = h16lo(w.y); f[i][3] = h16hi(w.y);
+      f[i][4] = h16lo(w.z); f[i][5] = h16hi(w.z); f[i][6] = h16lo(w.w); f[i][7] = h16hi(w.w);
 #pragma unroll
       for (int k = 0; k < 8; ++k) s += f[i][k];
     }
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void layernorm_splitk_bf16_kernel(const float*
       }
     }
   const float rstd = rsqrtf(block_sum(s2, red) / (float)cols + eps);
-  bf16_t* yr = y + (size_t)row * ldy;
+  h16_t* yr = y + (size_t)row * ldy;
 #pragma unroll
   for (int i = 0; i < NORM_MAXV; ++i) {
     const int v = threadIdx.x + i * 256;
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void layernorm_splitk_bf16_kernel(const float*
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] = (f[i][k] - mean) * rstd * g[k] + b[k];
       uint4v w;
-      w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
-      w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+      w.x = pack_h16x2(o[0], o[1]); w.y = pack_h16x2(o[2], o[3]);
+      w.z = pack_h16x2(o[4], o[5]); w.w = pack_h16x2(o[6], o[7]);
       *reinterpret_cast<uint4v*>(yr + v * 8) = w;
     }
   }
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void layernorm_splitk_bf16_kernel(const float*
 //   (1) partial[b][chunk][g] = (sum, sumsq) over a chunk of pixels   grid = (chunks, B)
 //   (2) reduce the chunks in fp64 and emit the per-(b, channel) affine y = a*x + s
 // block = 256 threads; thread = one 8-channel vector, strided pixels.
-__global__ __launch_bounds__(256) void gn_stats_nhwc_kernel(const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256) void gn_stats_nhwc_kernel(const h16_t* __restrict__ x,
                                                             float* __restrict__ partial, int HW, int C,
                                                             int G, int pix_per_block) {
   __shared__ float red[2][256];
@@ -295,11 +295,11 @@ __global__ __launch_bounds__(256) void gn_stats_nhwc_kernel(const bf16_t* __rest
   int p1 = p0 + pix_per_block;
   if (p1 > HW) p1 = HW;
   float s = 0.f, s2 = 0.f;
-  const bf16_t* base = x + ((size_t)b * HW) * C + cv * 8;
+  const h16_t* base = x + ((size_t)b * HW) * C + cv * 8;
   for (int p = p0 + pl; p < p1; p += plc) {
     const uint4v r = *reinterpret_cast<const uint4v*>(base + (size_t)p * C);
-    const float f[8] = {bf16lo(r.x), bf16hi(r.x), bf16lo(r.y), bf16hi(r.y),
-                        bf16lo(r.z), bf16hi(r.z), bf16lo(r.w), bf16hi(r.w)};
+    const float f[8] = {h16lo(r.x), h16hi(r.x), h16lo(r.y), h16hi(r.y),
+                        h16lo(r.z), h16hi(r.z), h16lo(r.w), h16hi(r.w)};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       s += f[k];
@@ -371,7 +371,7 @@ struct GnLevels {
   int n;
 };
 // partial layout: [level][b][256 chunk slots][G][2] floats; statistics identical to gn_stats_nhwc_kernel per (level, b)
-__global__ __launch_bounds__(256) void gn_stats_mlvl_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
+__global__ __launch_bounds__(256) void gn_stats_mlvl_kernel(const h16_t* __restrict__ x, float* __restrict__ partial,
                                                             GnLevels a, int B, int C, int G) {
   __shared__ float red[2][256];
   int l = 0;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void gn_stats_mlvl_kernel(const bf16_t* __rest
   int p1 = p0 + ppb;
   if (p1 > HW) p1 = HW;
   float s = 0.f, s2 = 0.f;
-  const bf16_t* base = x + ((size_t)a.pix0[l] + (size_t)b * HW) * C + cv * 8;
+  const h16_t* base = x + ((size_t)a.pix0[l] + (size_t)b * HW) * C + cv * 8;
   // four 16-byte loads in flight per thread (the per-level kernel walks one pixel at a time: 2.6 TB/s); the accumulation
   // order per thread is unchanged, so the sums are the same bits
   for (int p = p0 + pl; p < p1; p += 4 * plc) {
@@ -403,8 +403,8 @@ __global__ __launch_bounds__(256) void gn_stats_mlvl_kernel(const bf16_t* __rest
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (p + u * plc < p1) {
-        const float f[8] = {bf16lo(r[u].x), bf16hi(r[u].x), bf16lo(r[u].y), bf16hi(r[u].y),
-                            bf16lo(r[u].z), bf16hi(r[u].z), bf16lo(r[u].w), bf16hi(r[u].w)};
+        const float f[8] = {h16lo(r[u].x), h16hi(r[u].x), h16lo(r[u].y), h16hi(r[u].y),
+                            h16lo(r[u].z), h16hi(r[u].z), h16lo(r[u].w), h16hi(r[u].w)};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           s += f[k];
@@ -502,7 +502,7 @@ int g4r_groupnorm_affine_mlvl_nhwc_bf16(const void* x, const float* gamma, const
     a.blk_end[l] = blocks;
   }
   a.n = n_levels;
-  hipLaunchKernelGGL(gn_stats_mlvl_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial, a,
+  hipLaunchKernelGGL(gn_stats_mlvl_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, partial, a,
                      B, C, G);
   G4R_CHECK_LAUNCH("gn_stats_mlvl");
   hipLaunchKernelGGL(gn_finalize_mlvl_kernel, dim3(g4r_ceil_div((long)n_levels * B * G, 4)), dim3(256), 0,
@@ -518,7 +518,7 @@ int g4r_layernorm_bf16(const void* x, const float* gamma, const float* beta, voi
   G4R_REQUIRE(x && gamma && beta && y && (ldx % 8) == 0 && (ldy % 8) == 0, "layernorm: bad pointer/stride");
   G4R_REQUIRE(cols <= 256 * NORM_MAXV * 8, "layernorm: cols <= 8192");
   hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, gamma, beta, (bf16_t*)y, rows, cols, ldx, ldy, eps, relu_in);
+                     (const h16_t*)x, gamma, beta, (h16_t*)y, rows, cols, ldx, ldy, eps, relu_in);
   G4R_CHECK_LAUNCH("layernorm");
   return G4R_OK;
 }
@@ -530,7 +530,7 @@ int g4r_rmsnorm_bf16(const void* x, const float* gamma, void* y, int rows, int c
   G4R_REQUIRE(x && gamma && y && (ldx % 8) == 0 && (ldy % 8) == 0, "rmsnorm: bad pointer/stride");
   G4R_REQUIRE(cols <= 256 * NORM_MAXV * 8, "rmsnorm: cols <= 8192");
   hipLaunchKernelGGL(rmsnorm_bf16_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, gamma, (bf16_t*)y, rows, cols, ldx, ldy, eps);
+                     (const h16_t*)x, gamma, (h16_t*)y, rows, cols, ldx, ldy, eps);
   G4R_CHECK_LAUNCH("rmsnorm");
   return G4R_OK;
 }
@@ -547,7 +547,7 @@ int g4r_layernorm_splitk_bf16(const float* partials, int splits, const float* bi
               "layernorm_splitk: bad pointer/stride");
   G4R_REQUIRE(cols <= 256 * NORM_MAXV * 8, "layernorm_splitk: cols <= 8192");
   hipLaunchKernelGGL(layernorm_splitk_bf16_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, partials, splits,
-                     (long)rows * cols, bias, (const bf16_t*)residual, ldr, (bf16_t*)x_out, ldxo, gamma, beta, (bf16_t*)y, ldy,
+                     (long)rows * cols, bias, (const h16_t*)residual, ldr, (h16_t*)x_out, ldxo, gamma, beta, (h16_t*)y, ldy,
                      cols, eps);
   G4R_CHECK_LAUNCH("layernorm_splitk");
   return G4R_OK;
@@ -564,7 +564,7 @@ int g4r_rmsnorm_splitk_bf16(const float* partials, int splits, const void* resid
               "rmsnorm_splitk: bad pointer/stride");
   G4R_REQUIRE(cols <= 256 * NORM_MAXV * 8, "rmsnorm_splitk: cols <= 8192");
   hipLaunchKernelGGL(rmsnorm_splitk_bf16_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, partials, splits,
-                     (long)rows * cols, (const bf16_t*)residual, ldr, (bf16_t*)x_out, ldxo, gamma, (bf16_t*)y, ldy, cols, eps);
+                     (long)rows * cols, (const h16_t*)residual, ldr, (h16_t*)x_out, ldxo, gamma, (h16_t*)y, ldy, cols, eps);
   G4R_CHECK_LAUNCH("rmsnorm_splitk");
   return G4R_OK;
 }
@@ -583,7 +583,7 @@ int g4r_groupnorm_affine_nhwc_bf16(const void* x, const float* gamma, const floa
   if (ppb < 32) ppb = 32;
   chunks = g4r_ceil_div(HW, ppb);
   hipLaunchKernelGGL(gn_stats_nhwc_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, partial, HW, C, G, ppb);
+                     (const h16_t*)x, partial, HW, C, G, ppb);
   G4R_CHECK_LAUNCH("gn_stats");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(g4r_ceil_div((long)B * G, 4)), dim3(256), 0,
                      (hipStream_t)stream, partial, gamma, beta, scale_shift, B, C, G, chunks,

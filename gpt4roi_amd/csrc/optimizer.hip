@@ -46,9 +46,9 @@ __global__ __launch_bounds__(256) void multi_sumsq_kernel(MultiArgs a, double* _
   const long n = a.numel[t];
   double s = 0.0;
   if (a.g_is_bf16[t]) {
-    const bf16_t* g = reinterpret_cast<const bf16_t*>(a.g[t]) + off;
+    const h16_t* g = reinterpret_cast<const h16_t*>(a.g[t]) + off;
     for (long i = threadIdx.x; i < CHUNK && off + i < n; i += 256) {
-      const float x = bf16_to_f32(g[i]);
+      const float x = h16_to_f32(g[i]);
       s += (double)x * x;
     }
   } else {
@@ -103,14 +103,14 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(MultiArgs a, const dou
   float* p = reinterpret_cast<float*>(a.p[t]) + off;
   float* m = reinterpret_cast<float*>(a.m[t]) + off;
   float* v = reinterpret_cast<float*>(a.v[t]) + off;
-  bf16_t* pb = a.pb[t] ? reinterpret_cast<bf16_t*>(a.pb[t]) + off : nullptr;
+  h16_t* pb = a.pb[t] ? reinterpret_cast<h16_t*>(a.pb[t]) + off : nullptr;
   const bool gb = a.g_is_bf16[t] != 0;
-  const bf16_t* g16 = reinterpret_cast<const bf16_t*>(a.g[t]) + off;
+  const h16_t* g16 = reinterpret_cast<const h16_t*>(a.g[t]) + off;
   const float* g32 = reinterpret_cast<const float*>(a.g[t]) + off;
   const long lim = (n - off < CHUNK ? n - off : CHUNK);
   const float decay = 1.f - lr * wd, ib1 = 1.f / bc1, ib2 = 1.f / bc2;
   for (long i = threadIdx.x; i < lim; i += 256) {
-    const float gi = (gb ? bf16_to_f32(g16[i]) : g32[i]) * gscale;
+    const float gi = (gb ? h16_to_f32(g16[i]) : g32[i]) * gscale;
     float pi = p[i] * decay;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(MultiArgs a, const dou
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
-    if (pb) pb[i] = f32_to_bf16(pi);
+    if (pb) pb[i] = f32_to_h16(pi);
   }
 }
 

@@ -271,11 +271,11 @@ struct MlvlArgs {
 struct Vec8 {
   float v[8];
 };
-__device__ __forceinline__ Vec8 load8(const bf16_t* p) {
+__device__ __forceinline__ Vec8 load8(const h16_t* p) {
   const uint4v r = *reinterpret_cast<const uint4v*>(p);
   Vec8 o;
-  o.v[0] = bf16lo(r.x); o.v[1] = bf16hi(r.x); o.v[2] = bf16lo(r.y); o.v[3] = bf16hi(r.y);
-  o.v[4] = bf16lo(r.z); o.v[5] = bf16hi(r.z); o.v[6] = bf16lo(r.w); o.v[7] = bf16hi(r.w);
+  o.v[0] = h16lo(r.x); o.v[1] = h16hi(r.x); o.v[2] = h16lo(r.y); o.v[3] = h16hi(r.y);
+  o.v[4] = h16lo(r.z); o.v[5] = h16hi(r.z); o.v[6] = h16lo(r.w); o.v[7] = h16hi(r.w);
   return o;
 }
 __device__ __forceinline__ Vec8 load8(const float* p) {
@@ -286,10 +286,10 @@ __device__ __forceinline__ Vec8 load8(const float* p) {
   o.v[4] = b.x; o.v[5] = b.y; o.v[6] = b.z; o.v[7] = b.w;
   return o;
 }
-__device__ __forceinline__ void store8(bf16_t* p, const Vec8& a) {
+__device__ __forceinline__ void store8(h16_t* p, const Vec8& a) {
   uint4v r;
-  r.x = pack_bf16x2(a.v[0], a.v[1]); r.y = pack_bf16x2(a.v[2], a.v[3]);
-  r.z = pack_bf16x2(a.v[4], a.v[5]); r.w = pack_bf16x2(a.v[6], a.v[7]);
+  r.x = pack_h16x2(a.v[0], a.v[1]); r.y = pack_h16x2(a.v[2], a.v[3]);
+  r.z = pack_h16x2(a.v[4], a.v[5]); r.w = pack_h16x2(a.v[6], a.v[7]);
   *reinterpret_cast<uint4v*>(p) = r;
 }
 __device__ __forceinline__ void store8(float* p, const Vec8& a) {
@@ -536,7 +536,7 @@ struct MlvlGradArgs {
 // LDS,  S[x][c] = sum_{pw,ix} (hx or lx) * d[pw][c] / count,  and then issues ONE atomic per (map row, column,
 // channel) instead of one per (bin, sample, corner): 4*ncols instead of 16*PW atomics per channel.
 __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_bwd_kernel(MlvlGradArgs a, const float* __restrict__ rois,
-                                                                      const bf16_t* __restrict__ dout, long lvl_stride,
+                                                                      const h16_t* __restrict__ dout, long lvl_stride,
                                                                       long pix_stride, int L, int B, int C, int N,
                                                                       int PH, int PW, int sr, int aligned) {
   __shared__ Tap1D<float> xtab[MLVL_MAX_XTAB];
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_bwd_kernel(MlvlGradAr
   const int nvec = C >> 3;
   const float inv_count = 1.f / (float)(sr * sr);
   float* gm = a.grad[l] + (size_t)g.batch * H * W * C;
-  const bf16_t* dbase = dout + (size_t)l * lvl_stride + ((size_t)n * PH + ph) * PW * pix_stride;
+  const h16_t* dbase = dout + (size_t)l * lvl_stride + ((size_t)n * PH + ph) * PW * pix_stride;
 
   const int x_first = xrange[0];
   const int ncols = xrange[1] - xrange[0] + 1;
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_bwd_kernel(MlvlGradAr
 #define MLVL_GATHER_CH 256
 
 __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_bwd_gather_kernel(
-    MlvlGradArgs a, const float* __restrict__ rois, const int* __restrict__ roi_offsets, const bf16_t* __restrict__ dout,
+    MlvlGradArgs a, const float* __restrict__ rois, const int* __restrict__ roi_offsets, const h16_t* __restrict__ dout,
     long lvl_stride, long pix_stride, int L, int B, int C, int N, int PH, int PW, int sr, int aligned) {
   __shared__ float S[MLVL_GATHER_TW * MLVL_GATHER_CH];
   __shared__ Tap1D<float> xtab[MLVL_MAX_XTAB];
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_bwd_gather_kernel(
       xtab[i] = make_tap1d<float>(sample_coord<float>(g.start_w, g.bin_w, i / sr, i % sr, sr), W);
     __syncthreads();
     if (!any_row || !ch_ok) continue;
-    const bf16_t* dn = dout + (size_t)l * lvl_stride + (size_t)n * PH * PW * pix_stride + c;
+    const h16_t* dn = dout + (size_t)l * lvl_stride + (size_t)n * PH * PW * pix_stride + c;
     for (int ph = 0; ph < PH; ++ph) {
       const float wy = wrow[ph];
       if (wy == 0.f) continue;
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) void roi_align_mlvl_nhwc_bwd_gather_kernel(
           const bool in_l = xl >= 0 && xl < tw, in_h = xh >= 0 && xh < tw;
           if (!in_l && !in_h) continue;
           if (!loaded) {
-            d = bf16_to_f32(dn[((size_t)ph * PW + pw) * pix_stride]) * wq;
+            d = h16_to_f32(dn[((size_t)ph * PW + pw) * pix_stride]) * wq;
             loaded = true;
           }
           const float lx = tx.frac, hx = 1.f - lx;
@@ -797,6 +797,7 @@ int launch_mlvl(const void* const* feats, const float* const* affines, const int
 
 extern "C" {
 
+#ifndef G4R_F16   // the drop-in NCHW op has its own dtype instantiations (f32 / f64 / f16)
 int g4r_roi_align_forward_f32(const float* input, const float* rois, float* output, float* argmax_y,
                               float* argmax_x, int batch, int channels, int height, int width,
                               int n_rois, int pooled_h, int pooled_w, float spatial_scale,
@@ -853,13 +854,16 @@ int g4r_roi_align_backward_f16(const void* grad_output, const void* rois, const 
                                         aligned, stream);
 }
 
+#endif  // !G4R_F16
+
 int g4r_roi_align_mlvl_nhwc_bf16(const void* const* feats, const float* const* affines, const int* heights, const int* widths,
                                  const float* scales, int levels, const float* rois, void* output,
                                  int batch, int channels, int n_rois, int pooled_h, int pooled_w,
                                  int sampling_ratio, int aligned, void* stream) {
-  return launch_mlvl<bf16_t>(feats, affines, heights, widths, scales, levels, rois, output, batch, channels,
+  return launch_mlvl<h16_t>(feats, affines, heights, widths, scales, levels, rois, output, batch, channels,
                              n_rois, pooled_h, pooled_w, sampling_ratio, aligned, stream);
 }
+#ifndef G4R_F16   // fp32 maps and the training-only backward: one instantiation
 int g4r_roi_align_mlvl_nhwc_f32(const void* const* feats, const float* const* affines, const int* heights, const int* widths,
                                 const float* scales, int levels, const float* rois, void* output,
                                 int batch, int channels, int n_rois, int pooled_h, int pooled_w,
@@ -893,7 +897,7 @@ int g4r_roi_align_mlvl_nhwc_bwd_bf16(const void* dout, long lvl_stride, long pix
   const long blocks = ((groups + 7) / 8) * 8 * pooled_h;
   G4R_REQUIRE(blocks < 2147483647L, "roi_align_mlvl_bwd: grid too large");
   hipLaunchKernelGGL(roi_align_mlvl_nhwc_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, rois,
-                     (const bf16_t*)dout, lvl_stride, pix_stride, levels, batch, channels, n_rois, pooled_h, pooled_w,
+                     (const h16_t*)dout, lvl_stride, pix_stride, levels, batch, channels, n_rois, pooled_h, pooled_w,
                      sampling_ratio, aligned);
   G4R_CHECK_LAUNCH("roi_align_mlvl_nhwc_bwd");
   return G4R_OK;
@@ -924,10 +928,12 @@ int g4r_roi_align_mlvl_nhwc_bwd_gather_bf16(const void* dout, long lvl_stride, l
   }
   G4R_REQUIRE(blocks < 2147483647L, "roi_align_mlvl_bwd_gather: grid too large");
   hipLaunchKernelGGL(roi_align_mlvl_nhwc_bwd_gather_kernel, dim3((unsigned)blocks, (channels + MLVL_GATHER_CH - 1) / MLVL_GATHER_CH),
-                     dim3(256), 0, (hipStream_t)stream, a, rois, roi_offsets, (const bf16_t*)dout, lvl_stride, pix_stride,
+                     dim3(256), 0, (hipStream_t)stream, a, rois, roi_offsets, (const h16_t*)dout, lvl_stride, pix_stride,
                      levels, batch, channels, n_rois, pooled_h, pooled_w, sampling_ratio, aligned);
   G4R_CHECK_LAUNCH("roi_align_mlvl_nhwc_bwd_gather");
   return G4R_OK;
 }
+
+#endif  // !G4R_F16
 
 }  // extern "C"

@@ -16,17 +16,17 @@ namespace {
 struct F8 {
   float v[8];
 };
-__device__ __forceinline__ F8 ld8(const bf16_t* p) {
+__device__ __forceinline__ F8 ld8(const h16_t* p) {
   const uint4v r = *reinterpret_cast<const uint4v*>(p);
   F8 a;
-  a.v[0] = bf16lo(r.x); a.v[1] = bf16hi(r.x); a.v[2] = bf16lo(r.y); a.v[3] = bf16hi(r.y);
-  a.v[4] = bf16lo(r.z); a.v[5] = bf16hi(r.z); a.v[6] = bf16lo(r.w); a.v[7] = bf16hi(r.w);
+  a.v[0] = h16lo(r.x); a.v[1] = h16hi(r.x); a.v[2] = h16lo(r.y); a.v[3] = h16hi(r.y);
+  a.v[4] = h16lo(r.z); a.v[5] = h16hi(r.z); a.v[6] = h16lo(r.w); a.v[7] = h16hi(r.w);
   return a;
 }
-__device__ __forceinline__ void st8(bf16_t* p, const F8& a) {
+__device__ __forceinline__ void st8(h16_t* p, const F8& a) {
   uint4v w;
-  w.x = pack_bf16x2(a.v[0], a.v[1]); w.y = pack_bf16x2(a.v[2], a.v[3]);
-  w.z = pack_bf16x2(a.v[4], a.v[5]); w.w = pack_bf16x2(a.v[6], a.v[7]);
+  w.x = pack_h16x2(a.v[0], a.v[1]); w.y = pack_h16x2(a.v[2], a.v[3]);
+  w.z = pack_h16x2(a.v[4], a.v[5]); w.w = pack_h16x2(a.v[6], a.v[7]);
   *reinterpret_cast<uint4v*>(p) = w;
 }
 __device__ __forceinline__ F8 ld8f(const float* p) {
@@ -46,7 +46,7 @@ inline int grid_for(long total) {
 }
 
 // ---- per-(image, group) statistics: chunk partials, then one wave per (b, g) ------------------------------
-__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
+__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const h16_t* __restrict__ x, float* __restrict__ partial,
                                                                int HW, int C, int G, int pix_per_block) {
   __shared__ float red[2][256];
   const int b = blockIdx.y;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const bf16_t* __r
   int p1 = p0 + pix_per_block;
   if (p1 > HW) p1 = HW;
   float s = 0.f, s2 = 0.f;
-  const bf16_t* base = x + ((size_t)b * HW) * C + cv * 8;
+  const h16_t* base = x + ((size_t)b * HW) * C + cv * 8;
   for (int p = p0 + pl; p < p1; p += plc) {
     const F8 f = ld8(base + (size_t)p * C);
 #pragma unroll
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void gn_stats_finalize_kernel(const float* __r
 //   dyh = d_y * (a*z + s > 0);  xhat = (z - mean) * rstd
 //   dgamma[c] += sum dyh * xhat;  dbeta[c] += sum dyh           (over images and pixels)
 //   gsum[b][g] += (sum gamma*dyh, sum gamma*dyh*xhat)           (over the group's pixels x channels)
-__global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const bf16_t* __restrict__ z, const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const h16_t* __restrict__ z, const float* __restrict__ dy,
                                                                  const float* __restrict__ aff, const float* __restrict__ gamma,
                                                                  const float* __restrict__ stats, float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta, float* __restrict__ gsum, int HW,
@@ -213,10 +213,10 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_reduce_kernel(const bf16_t* _
 }
 
 // ---- pass 2: dz = rstd * (gamma*dyh - m1 - xhat*m2),  m = gsum / (HW * C/G) -------------------------------
-__global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(const bf16_t* __restrict__ z, const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(const h16_t* __restrict__ z, const float* __restrict__ dy,
                                                                 const float* __restrict__ aff, const float* __restrict__ gamma,
                                                                 const float* __restrict__ stats, const float* __restrict__ gsum,
-                                                                bf16_t* __restrict__ dz, int B, int HW, int C, int G) {
+                                                                h16_t* __restrict__ dz, int B, int HW, int C, int G) {
   const int nvec = C >> 3;
   const int vpg = (C / G) >> 3;
   const float inv_n = 1.f / ((float)HW * (float)(C / G));
@@ -292,7 +292,7 @@ __device__ __forceinline__ void scatter_dst(const ShuffleDst& s, int b, int y, i
   add8(base + ((size_t)ly.i1 * s.W + lx.i1) * C, v, wy1 * wx1);
 }
 
-__global__ __launch_bounds__(256) void fuse_shuffle_bwd_kernel(const bf16_t* __restrict__ dinp, ShuffleDst own,
+__global__ __launch_bounds__(256) void fuse_shuffle_bwd_kernel(const h16_t* __restrict__ dinp, ShuffleDst own,
                                                                ShuffleDst top, ShuffleDst down, int B, int C) {
   const int H = own.H, W = own.W;
   const int nvec = C >> 3;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void fuse_shuffle_bwd_kernel(const bf16_t* __r
 // For a resampled target the candidate target rows/columns around src/scale are re-tested with the forward's own
 // lerp_ac(), so the weights are exactly the forward's.
 struct GatherTgt {
-  const bf16_t* g;  // bf16 [B, H, W, C] or null
+  const h16_t* g;  // bf16 [B, H, W, C] or null
   int H, W;
 };
 
@@ -347,7 +347,7 @@ __device__ __forceinline__ void gather_tgt(const GatherTgt& t, int b, int ys, in
   int ylo, yhi, xlo, xhi;
   cand_range(ys, Hs, t.H, ylo, yhi);
   cand_range(xs, Ws, t.W, xlo, xhi);
-  const bf16_t* base = t.g + (size_t)b * t.H * t.W * C + ch;
+  const h16_t* base = t.g + (size_t)b * t.H * t.W * C + ch;
   for (int i = ylo; i <= yhi; ++i) {
     const Lerp ly = lerp_ac(i, Hs, t.H);
     const float wy = (ly.i0 == ys ? 1.f - ly.w1 : 0.f) + (ly.i1 == ys ? ly.w1 : 0.f);
@@ -364,7 +364,7 @@ __device__ __forceinline__ void gather_tgt(const GatherTgt& t, int b, int ys, in
   }
 }
 
-__global__ __launch_bounds__(256) void fuse_shuffle_bwd_gather_kernel(float* __restrict__ dsrc, const bf16_t* __restrict__ own,
+__global__ __launch_bounds__(256) void fuse_shuffle_bwd_gather_kernel(float* __restrict__ dsrc, const h16_t* __restrict__ own,
                                                                       GatherTgt fine, GatherTgt coarse, int self_top,
                                                                       int self_down, int B, int H, int W, int C) {
   const int nvec = C >> 3;
@@ -405,10 +405,10 @@ __global__ __launch_bounds__(256) void fuse_shuffle_bwd_gather_kernel(float* __r
 // dst[s][c][base + b*seg + (y+1)*Wp + (x+1) - dx_s] = src[b][y][x][c],  dx_s = s - (n_shift >> 1)
 // (n_shift = 1: the plain copy; n_shift = 3: copies pre-shifted by -1, 0, +1 columns so that every tap's operand
 // starts 16-byte aligned).  The destination is zero-initialised once by the caller; pad positions are never written.
-__global__ __launch_bounds__(256) void nhwc_to_cm_padded_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+__global__ __launch_bounds__(256) void nhwc_to_cm_padded_kernel(const h16_t* __restrict__ src, h16_t* __restrict__ dst,
                                                                 int B, int H, int W, int C, int Wp, long seg, long base,
                                                                 long ltot, int n_shift) {
-  __shared__ bf16_t tile[64][66];
+  __shared__ h16_t tile[64][66];
   const int xt = (W + 63) / 64;
   const int bx = blockIdx.x % xt;
   const int y = (blockIdx.x / xt) % H;
@@ -418,14 +418,14 @@ __global__ __launch_bounds__(256) void nhwc_to_cm_padded_kernel(const bf16_t* __
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int j = ty; j < 64; j += 4) {  // j = pixel, tx = channel
     const int x = x0 + j, c = c0 + tx;
-    tile[j][tx] = (x < W && c < C) ? src[(((size_t)b * H + y) * W + x) * C + c] : (bf16_t)0;
+    tile[j][tx] = (x < W && c < C) ? src[(((size_t)b * H + y) * W + x) * C + c] : (h16_t)0;
   }
   __syncthreads();
   const long row = base + (long)b * seg + (long)(y + 1) * Wp + 1;
   for (int j = ty; j < 64; j += 4) {  // j = channel, tx = pixel
     const int c = c0 + j, x = x0 + tx;
     if (c < C && x < W) {
-      const bf16_t v = tile[tx][j];
+      const h16_t v = tile[tx][j];
       for (int s = 0; s < n_shift; ++s) {
         const int dx = s - (n_shift >> 1);
         dst[((size_t)s * C + c) * ltot + row + x - dx] = v;
@@ -448,7 +448,7 @@ int g4r_groupnorm_stats_nhwc_bf16(const void* x, float* partial, float* stats, i
   int ppb = g4r_ceil_div(HW, chunks);
   if (ppb < 32) ppb = 32;
   chunks = g4r_ceil_div(HW, ppb);
-  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x,
                      partial, HW, C, G, ppb);
   G4R_CHECK_LAUNCH("gn_stats_partial");
   hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(g4r_ceil_div((long)B * G, 4)), dim3(256), 0, (hipStream_t)stream,
@@ -472,11 +472,11 @@ int g4r_gn_relu_bwd_nhwc_bf16(const void* z, const float* dy, const float* affin
   chunks = g4r_ceil_div(HW, ppb);
   hipError_t e = hipMemsetAsync(gsum, 0, (size_t)B * G * 2 * sizeof(float), (hipStream_t)stream);
   if (e != hipSuccess) return g4r_note_hip_error(e, "gn_relu_bwd: memset");
-  hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z,
+  hipLaunchKernelGGL(gn_relu_bwd_reduce_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, (const h16_t*)z,
                      dy, affine, gamma, stats, dgamma, dbeta, gsum, HW, C, G, ppb);
   G4R_CHECK_LAUNCH("gn_relu_bwd_reduce");
   hipLaunchKernelGGL(gn_relu_bwd_apply_kernel, dim3(grid_for((long)B * HW * nvec)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)z, dy, affine, gamma, stats, gsum, (bf16_t*)dz, B, HW, C, G);
+                     (const h16_t*)z, dy, affine, gamma, stats, gsum, (h16_t*)dz, B, HW, C, G);
   G4R_CHECK_LAUNCH("gn_relu_bwd_apply");
   return G4R_OK;
 }
@@ -487,7 +487,7 @@ int g4r_fuse_shuffle_bwd_nhwc_bf16(const void* dinp, int H, int W, float* d_own,
   G4R_REQUIRE(dinp && d_own && d_top && d_down, "fuse_shuffle_bwd: null pointer");
   ShuffleDst own = {d_own, H, W}, top = {d_top, Ht, Wt}, down = {d_down, Hd, Wd};
   hipLaunchKernelGGL(fuse_shuffle_bwd_kernel, dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)dinp, own, top, down, B, C);
+                     (hipStream_t)stream, (const h16_t*)dinp, own, top, down, B, C);
   G4R_CHECK_LAUNCH("fuse_shuffle_bwd");
   return G4R_OK;
 }
@@ -497,9 +497,9 @@ int g4r_fuse_shuffle_bwd_gather_nhwc_bf16(float* d_src, const void* dinp_own, in
                                           int self_down, int B, int C, void* stream) {
   G4R_REQUIRE(B > 0 && H > 0 && W > 0 && C % 32 == 0, "fuse_shuffle_bwd_gather: bad shape");
   G4R_REQUIRE(d_src && dinp_own, "fuse_shuffle_bwd_gather: null pointer");
-  GatherTgt fine = {(const bf16_t*)dinp_fine, Hf, Wf}, coarse = {(const bf16_t*)dinp_coarse, Hc, Wc};
+  GatherTgt fine = {(const h16_t*)dinp_fine, Hf, Wf}, coarse = {(const h16_t*)dinp_coarse, Hc, Wc};
   hipLaunchKernelGGL(fuse_shuffle_bwd_gather_kernel, dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0,
-                     (hipStream_t)stream, d_src, (const bf16_t*)dinp_own, fine, coarse, self_top, self_down, B, H, W, C);
+                     (hipStream_t)stream, d_src, (const h16_t*)dinp_own, fine, coarse, self_top, self_down, B, H, W, C);
   G4R_CHECK_LAUNCH("fuse_shuffle_bwd_gather");
   return G4R_OK;
 }
@@ -512,7 +512,7 @@ int g4r_nhwc_to_cm_padded_bf16(const void* src, void* dst, int B, int H, int W, 
   const long blocks = (long)B * H * ((W + 63) / 64);
   G4R_REQUIRE(blocks < 2147483647L, "nhwc_to_cm: grid too large");
   hipLaunchKernelGGL(nhwc_to_cm_padded_kernel, dim3((unsigned)blocks, g4r_ceil_div(C, 64)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, B, H, W, C, Wp, seg, base, ltot, n_shift);
+                     (hipStream_t)stream, (const h16_t*)src, (h16_t*)dst, B, H, W, C, Wp, seg, base, ltot, n_shift);
   G4R_CHECK_LAUNCH("nhwc_to_cm_padded");
   return G4R_OK;
 }

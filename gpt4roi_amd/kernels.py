@@ -87,13 +87,14 @@ _bound = {}
 ACT = {None: 0, "none": 0, "relu": 1, "quick_gelu": 2, "silu": 3, "swiglu": 4}
 
 
-def _fn(name):
-    f = _bound.get(name)
+def _fn(name, sym=None):
+    sym = sym or name
+    f = _bound.get(sym)
     if f is None:
-        f = getattr(_lib.lib(), name)
-        f.argtypes = _SIGS[name]
+        f = getattr(_lib.lib(), sym)
+        f.argtypes = _SIGS[name]           # the fp16 instantiation has the signature of the bf16 entry point
         f.restype = c_int
-        _bound[name] = f
+        _bound[sym] = f
     return f
 
 
@@ -129,8 +130,16 @@ TILE_NAMES = {0: "128x128", 1: "256x128", 2: "128x128reg", 4: "64x128", 5: "128x
               15: "128x64s4", 22: "256x256pp", 24: "256x256pp32", 26: "256x256w4", 27: "128x384pp32", 28: "192x256pp32"}
 
 
-def _launch(name, args, tag=None, flops=0.0, nbytes=0.0):
-    f = _fn(name)
+def _sym(name, dt):
+    """Entry point of `name` for the 16-bit storage type dt: include/g4r_f16_names.h (bf16 -> f16 in the name, or an _f16
+    suffix where the name carries no dtype) for torch.float16, the name itself otherwise."""
+    if dt is torch.float16:
+        return name.replace("bf16", "f16") if "bf16" in name else name + "_f16"
+    return name
+
+
+def _launch(name, args, tag=None, flops=0.0, nbytes=0.0, dt=None):
+    f = _fn(name, _sym(name, dt))
     if PROFILER.enabled:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -156,6 +165,30 @@ def _bf16(*ts):
             _lib.require_gpu(t)
             if t.dtype != torch.bfloat16:
                 raise TypeError(f"expected bfloat16, got {t.dtype}")
+
+
+H16 = (torch.bfloat16, torch.float16)
+
+
+def _h16(*ts):
+    """The inference kernels exist for both 16-bit storage types (bf16 = the reference's training dtype, fp16 = its serving
+    dtype, app.py:74-98).  Checks that every tensor is on the GPU and that all share ONE of the two; returns it (None when
+    every argument is None).  A torch.dtype among the arguments (the `dt` of an earlier call) joins the check."""
+    dt = None
+    for t in ts:
+        if t is None:
+            continue
+        if isinstance(t, torch.dtype):
+            d = t
+        else:
+            _lib.require_gpu(t)
+            d = t.dtype
+        if d not in H16:
+            raise TypeError(f"expected bfloat16 or float16, got {d}")
+        if dt is not None and d != dt:
+            raise TypeError(f"mixed 16-bit storage types in one call: {dt} and {d}")
+        dt = d
+    return dt
 
 
 def _f32(*ts):
@@ -278,7 +311,7 @@ def partial_wave_plan(M, N, K):
 def gemm_partials(a, w, splits, tile_cfg):
     """a [M,K] @ w[N,K]^T as fp32 K-slice partials [n_slices, M, N] WITHOUT the reduce launch (the consumer combines them:
     rmsnorm_splitk).  Returns (partials, n_slices)."""
-    _bf16(a, w)
+    dt = _h16(a, w)
     M, K = a.shape
     N = w.size(0)
     assert a.stride(1) == 1 and w.stride(1) == 1 and splits >= 2
@@ -287,7 +320,7 @@ def gemm_partials(a, w, splits, tile_cfg):
     _launch("g4r_gemm_bf16_nt_partials", (_p(a), _p(w), _p(ws), M, N, K, a.stride(0), w.stride(0), int(splits), int(tile_cfg),
                                           ctypes.byref(n), _stream(a),),
             tag=f"gemm_bf16_nt<{TILE_NAMES.get(tile_cfg, tile_cfg)}>+splitk", flops=2.0 * M * N * K,
-            nbytes=2.0 * (M * K + N * K) + 4.0 * splits * M * N)
+            nbytes=2.0 * (M * K + N * K) + 4.0 * splits * M * N, dt=dt)
     return ws, n.value
 
 
@@ -295,13 +328,13 @@ def rmsnorm_splitk(partials, n_slices, residual, gamma, eps=1e-6):
     """x = bf16(sum of the first n_slices partials + residual); y = rmsnorm(x; gamma) -> (x, y): the split-K reduce of a
     residual GEMM and the RMSNorm that follows it in one pass (bit-identical to gemm(..., residual=) + rmsnorm())."""
     _f32(partials, gamma)
-    _bf16(residual)
+    dt = _h16(residual)
     _, M, N = partials.shape
-    x = torch.empty((M, N), dtype=torch.bfloat16, device=partials.device)
+    x = torch.empty((M, N), dtype=dt, device=partials.device)
     y = torch.empty_like(x)
     _launch("g4r_rmsnorm_splitk_bf16", (_p(partials), int(n_slices), _p(residual), residual.stride(0) if residual is not None else 0,
                                         _p(x), x.stride(0), _p(gamma), _p(y), y.stride(0), M, N, float(eps), _stream(x),),
-            tag="g4r_rmsnorm_bf16")
+            tag="g4r_rmsnorm_bf16", dt=dt)
     return x, y
 
 
@@ -317,14 +350,14 @@ def layernorm_splitk(partials, n_slices, bias, residual, gamma, beta, eps=1e-5):
     """x = bf16(sum of the first n_slices partials + bias + residual); y = layernorm(x) -> (x, y) in one pass (bit-identical
     to gemm(..., bias=, residual=) with K slices + layernorm())."""
     _f32(partials, bias, gamma, beta)
-    _bf16(residual)
+    dt = _h16(residual)
     _, M, N = partials.shape
-    x = torch.empty((M, N), dtype=torch.bfloat16, device=partials.device)
+    x = torch.empty((M, N), dtype=dt, device=partials.device)
     y = torch.empty_like(x)
     _launch("g4r_layernorm_splitk_bf16", (_p(partials), int(n_slices), _p(bias), _p(residual),
                                           residual.stride(0) if residual is not None else 0, _p(x), x.stride(0), _p(gamma),
                                           _p(beta), _p(y), y.stride(0), M, N, float(eps), _stream(x),),
-            tag="g4r_layernorm_bf16")
+            tag="g4r_layernorm_bf16", dt=dt)
     return x, y
 
 
@@ -333,7 +366,7 @@ def gemm_qkv_rope(h, wqkv, B, T, heads, head_dim, q_out, k_cache, v_cache, cos, 
     q_out [B, T, heads*D] (rotated), k_cache / v_cache [B, maxT, heads*D] rows pos0 .. pos0+T-1 (rotated keys, values).
     Same rounding points as gemm() + rope_qkv().  Returns None when the shape is not one the ring ping-pong tiles serve
     (the caller then runs the two launches)."""
-    _bf16(h, wqkv, q_out, k_cache, v_cache)
+    dt = _h16(h, wqkv, q_out, k_cache, v_cache)
     _f32(cos, sin)
     M, Kd = h.shape
     HD = heads * head_dim
@@ -347,14 +380,14 @@ def gemm_qkv_rope(h, wqkv, B, T, heads, head_dim, q_out, k_cache, v_cache, cos, 
                                        _p(k_cache), _p(v_cache), k_cache.stride(1), k_cache.stride(0), _p(cos), _p(sin), int(pos0),
                                        int(tile_cfg), _stream(h),),
             tag=f"gemm_bf16_nt<{TILE_NAMES.get(tile_cfg, tile_cfg)}>", flops=2.0 * M * 3 * HD * Kd,
-            nbytes=2.0 * (M * Kd + 3 * HD * Kd + 3 * M * HD))
+            nbytes=2.0 * (M * Kd + 3 * HD * Kd + 3 * M * HD), dt=dt)
     return q_out
 
 
-def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfloat16, splits=1,
+def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=None, splits=1,
          tile_cfg=None, workspace=None):
     """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) + residual.  a may be row-strided (last dim dense)."""
-    _bf16(a, w, residual)
+    dt = _h16(a, w, residual)
     _f32(bias)
     assert a.dim() == 2 and w.dim() == 2 and a.size(1) == w.size(1), (a.shape, w.shape)
     assert a.stride(1) == 1 and w.stride(1) == 1
@@ -362,7 +395,7 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
     N = w.size(0)
     n_out = N // 2 if act == "swiglu" else N          # swiglu: interleaved (gate, up) weight rows
     if out is None:
-        out = torch.empty((M, n_out), dtype=out_dtype, device=a.device)
+        out = torch.empty((M, n_out), dtype=out_dtype or dt, device=a.device)
     assert out.stride(1) == 1 and out.shape == (M, n_out)
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
@@ -406,35 +439,35 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfl
         1 if out.dtype == torch.float32 else 0, splits, tile_cfg, _stream(a),),
         tag="gemv_bf16" if (M == 1 and splits == 1 and K >= 512 and K % 8 == 0) else
         ((f"gemm_bf16_nt<{TILE_NAMES.get(tile_cfg, tile_cfg)}>" + ("+splitk" if splits > 1 else "")) if K % 64 == 0
-         else "small_linear"), flops=2.0 * M * N * K, nbytes=2.0 * (M * K + N * K) + out.element_size() * M * N)
+         else "small_linear"), flops=2.0 * M * N * K, nbytes=2.0 * (M * K + N * K) + out.element_size() * M * N, dt=dt)
     return out
 
 
-def gemv(x, w, norm_weight=None, eps=1e-6, bias=None, residual=None, act=None, out=None, out_dtype=torch.bfloat16):
+def gemv(x, w, norm_weight=None, eps=1e-6, bias=None, residual=None, act=None, out=None, out_dtype=None):
     """out[N] = act(w[N,K] . rmsnorm(x; norm_weight, eps) + bias) + residual for ONE row x [K] (any shape with K
     elements); norm_weight None = no norm.  The decode-step projections: weight streaming, x staged in LDS, the
     preceding RMSNorm fused in (bit-identical to rmsnorm() followed by gemm())."""
-    _bf16(x, w, residual)
+    dt = _h16(x, w, residual)
     _f32(bias, norm_weight)
     N, K = w.shape
     assert x.numel() == K and x.is_contiguous() and w.stride(1) == 1
     n_out = N // 2 if act == "swiglu" else N
     if out is None:
-        out = torch.empty((1, n_out), dtype=out_dtype, device=x.device)
+        out = torch.empty((1, n_out), dtype=out_dtype or dt, device=x.device)
     assert out.numel() == n_out and out.is_contiguous()
     if residual is not None:
         assert residual.numel() == N and residual.is_contiguous()
     _launch("g4r_gemv_rmsnorm_bf16", (_p(x), _p(norm_weight), float(eps), _p(w), _p(out), _p(bias), _p(residual), N, K,
                                       w.stride(0), ACT[act], 1 if out.dtype == torch.float32 else 0, _stream(x),),
-            tag="gemv_bf16", flops=2.0 * N * K, nbytes=2.0 * (K + N * K) + out.element_size() * n_out)
+            tag="gemv_bf16", flops=2.0 * N * K, nbytes=2.0 * (K + N * K) + out.element_size() * n_out, dt=dt)
     return out
 
 
-def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=torch.bfloat16, splits=1, tile_cfg=None,
+def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=None, splits=1, tile_cfg=None,
             workspace=None):
     """x [groups?, B, H, W, Cin] NHWC bf16 (groups dim present iff groups > 1);
     w [Cout, groups*9*Cin] prepared by prep_conv3x3_weight; returns [B, H, W, Cout]."""
-    _bf16(x, w)
+    dt = _h16(x, w)
     _f32(bias)
     x = x.contiguous()
     if groups > 1:
@@ -448,7 +481,7 @@ def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=torch.bfloa
     Cout = w.size(0)
     assert w.size(1) == groups * 9 * Cin and w.is_contiguous()
     if out is None:
-        out = torch.empty((B, H, W, Cout), dtype=out_dtype, device=x.device)
+        out = torch.empty((B, H, W, Cout), dtype=out_dtype or dt, device=x.device)
     if tile_cfg is None:
         tile_cfg, auto_splits = pick_conv_tile(B * H * W, Cout, groups * 9 * Cin)
         if splits == 1:
@@ -459,7 +492,7 @@ def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=torch.bfloa
         _p(x), _p(w), _p(out), _p(bias), _p(zeros_line(x.device)), _p(workspace), B, H, W, Cin, Cout, groups,
         gstride, ACT[act], 1 if out.dtype == torch.float32 else 0, splits, tile_cfg, _stream(x),),
         tag=f"conv3x3_igemm<{TILE_NAMES.get(tile_cfg, tile_cfg)}>", flops=2.0 * B * H * W * Cout * groups * 9 * Cin,
-        nbytes=2.0 * (groups * B * H * W * Cin + Cout * groups * 9 * Cin + B * H * W * Cout))
+        nbytes=2.0 * (groups * B * H * W * Cin + Cout * groups * 9 * Cin + B * H * W * Cout), dt=dt)
     return out
 
 
@@ -468,6 +501,7 @@ class MlvlMaps:
     conv3x3_mlvl reads and writes (one implicit GEMM over every level of a fuse round)."""
 
     def __init__(self, B, sizes, C, device, dtype=torch.bfloat16):
+        self.dtype = dtype
         self.B, self.sizes, self.C = B, [(int(h), int(w)) for h, w in sizes], C
         rows = [B * h * w for h, w in self.sizes]
         self.flat = torch.empty((sum(rows), C), dtype=dtype, device=device)
@@ -483,46 +517,46 @@ def conv3x3_mlvl(x, w, bias=None, act=None, out=None):
     """One 3x3 / pad 1 convolution with the SAME weights over every level of a pyramid (MlvlMaps in, MlvlMaps out): the
     fuse round of gpt4roi/models/layers.py:218-236 as a single implicit GEMM launch."""
     assert isinstance(x, MlvlMaps)
-    _bf16(x.flat, w)
+    dt = _h16(x.flat, w)
     _f32(bias)
     Cout = w.size(0)
     assert w.size(1) == 9 * x.C and w.is_contiguous() and len(x.sizes) <= 4
     if out is None:
-        out = MlvlMaps(x.B, x.sizes, Cout, x.flat.device)
+        out = MlvlMaps(x.B, x.sizes, Cout, x.flat.device, dtype=dt)
     assert out.sizes == x.sizes and out.B == x.B and out.C == Cout
     M = x.flat.size(0)
     _launch("g4r_conv3x3_mlvl_nhwc_bf16", (
         _p(x.flat), _p(w), _p(out.flat), _p(bias), _p(zeros_line(x.flat.device)), len(x.sizes), x._hw[0], x._hw[1], x.B,
         x.C, Cout, ACT[act], _stream(x.flat),),
         tag="conv3x3_igemm<256x256pp32>", flops=2.0 * M * Cout * 9 * x.C,
-        nbytes=2.0 * (M * x.C + Cout * 9 * x.C + M * Cout))
+        nbytes=2.0 * (M * x.C + Cout * 9 * x.C + M * Cout), dt=dt)
     return out
 
 
-def prep_conv3x3_weight(ws):
-    """list of torch conv weights [Cout, Cin, 3, 3] (one per group) -> [Cout, groups*9*Cin] bf16."""
+def prep_conv3x3_weight(ws, dtype=torch.bfloat16):
+    """list of torch conv weights [Cout, Cin, 3, 3] (one per group) -> [Cout, groups*9*Cin] in the 16-bit storage type."""
     if isinstance(ws, torch.Tensor):
         ws = [ws]
     parts = [w.permute(0, 2, 3, 1).reshape(w.size(0), 1, 9 * w.size(1)) for w in ws]
-    return torch.cat(parts, 1).reshape(ws[0].size(0), -1).to(torch.bfloat16).contiguous()
+    return torch.cat(parts, 1).reshape(ws[0].size(0), -1).to(dtype).contiguous()
 
 
 def flash_attn(q, k, v, heads, scale, causal=False, out=None, kv_len_dev=None, lse=None):
     """q [B, Tq, heads*D], k/v [B, Tk, heads*D] (row-strided views allowed) -> [B, Tq, heads*D].
     lse (optional fp32 [B, heads, Tq]) receives the log2-domain log-sum-exp for flash_attn_bwd."""
-    _bf16(q, k, v)
+    dt = _h16(q, k, v)
     B, Tq, HD = q.shape
     Tk = k.size(1)
     D = HD // heads
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
     if out is None:
-        out = torch.empty((B, Tq, HD), dtype=torch.bfloat16, device=q.device)
+        out = torch.empty((B, Tq, HD), dtype=dt, device=q.device)
     _launch("g4r_flash_attn_fwd_bf16", (
         _p(q), _p(k), _p(v), _p(out), B, heads, Tq, Tk, D, q.stride(1), k.stride(1), v.stride(1), out.stride(1),
         q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), int(bool(causal)), _p(kv_len_dev),
         _p(lse), _stream(q),),
         tag=f"flash_attn<{D}>", flops=4.0 * B * heads * Tq * Tk * D * (0.5 if causal and Tq == Tk else 1.0),
-        nbytes=2.0 * B * HD * (2 * Tq + 2 * Tk))
+        nbytes=2.0 * B * HD * (2 * Tq + 2 * Tk), dt=dt)
     return out
 
 
@@ -543,7 +577,7 @@ def attn_decode(q, k, v, heads, scale, work, kv_len_dev=None, kv_len=None, out=N
     qkv (instead of q): the raw q|k|v projection rows of the new tokens -- RoPE (cos/sin tables) and the cache append at row
     kv_len - 1 happen inside the launch (rope_qkv + attention in one).
     defer_merge (single sequence): returns None; the per-split partials stay in work.ws for gemv_attn_merge (the o_proj)."""
-    _bf16(q, k, v, qkv)
+    dt = _h16(q, k, v, qkv)
     batched = k.dim() == 3
     B = k.size(0) if batched else 1
     HD = k.size(-1)
@@ -558,70 +592,70 @@ def attn_decode(q, k, v, heads, scale, work, kv_len_dev=None, kv_len=None, out=N
     assert kv_len_dev is not None or kv_len is not None
     assert not (defer_merge and batched)
     if out is None and not defer_merge:
-        out = torch.empty((B, HD) if batched else HD, dtype=torch.bfloat16, device=k.device)
+        out = torch.empty((B, HD) if batched else HD, dtype=dt, device=k.device)
     if out is not None:
         assert out.numel() == B * HD and out.is_contiguous()
     _launch("g4r_attn_decode_bf16", (_p(q), _p(qkv), _p(cos), _p(sin), _p(k), _p(v), _p(out), _p(work.ws), _p(work.cnt),
                                      heads, D, int(kv_len or 0), k.stride(-2), v.stride(-2), float(scale), work.splits,
                                      _p(kv_len_dev), int(bool(defer_merge)), B, src.numel() // B,
                                      k.stride(0) if batched else 0, v.stride(0) if batched else 0, HD, _stream(k),),
-            tag=f"attn_decode<{D}>")
+            tag=f"attn_decode<{D}>", dt=dt)
     return out
 
 
-def gemv_attn_merge(work, heads, head_dim, w, bias=None, residual=None, out=None, out_dtype=torch.bfloat16):
+def gemv_attn_merge(work, heads, head_dim, w, bias=None, residual=None, out=None, out_dtype=None):
     """out[N] = w[N, heads*head_dim] . (attention output assembled from work.ws) + bias + residual: the o_proj of the decode
     step after attn_decode(..., defer_merge=True)."""
-    _bf16(w, residual)
+    dt = _h16(w, residual)
     _f32(bias)
     N, K = w.shape
     assert K == heads * head_dim and w.stride(1) == 1
     if out is None:
-        out = torch.empty((1, N), dtype=out_dtype, device=w.device)
+        out = torch.empty((1, N), dtype=out_dtype or dt, device=w.device)
     assert out.numel() == N and out.is_contiguous()
     if residual is not None:
         assert residual.numel() == N and residual.is_contiguous()
     _launch("g4r_gemv_attn_merge_bf16", (_p(work.ws), work.splits, head_dim, _p(w), _p(out), _p(bias), _p(residual), N, K,
                                          w.stride(0), 1 if out.dtype == torch.float32 else 0, _stream(w),),
-            tag="gemv_bf16", flops=2.0 * N * K, nbytes=2.0 * N * K)
+            tag="gemv_bf16", flops=2.0 * N * K, nbytes=2.0 * N * K, dt=dt)
     return out
 
 
 def layernorm(x, gamma, beta, eps=1e-5, relu_in=False, out=None):
-    _bf16(x)
+    dt = _h16(x)
     _f32(gamma, beta)
     x2 = x.reshape(-1, x.size(-1)) if x.is_contiguous() else x
     assert x2.dim() == 2 and x2.stride(1) == 1
     if out is None:
-        out = torch.empty((x2.size(0), x2.size(1)), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty((x2.size(0), x2.size(1)), dtype=dt, device=x.device)
     _launch("g4r_layernorm_bf16", (
         _p(x2), _p(gamma), _p(beta), _p(out), x2.size(0), x2.size(1), x2.stride(0),
-                                   out.stride(0), float(eps), int(relu_in), _stream(x),))
+                                   out.stride(0), float(eps), int(relu_in), _stream(x),), dt=dt)
     return out.view(x.shape) if x.is_contiguous() else out
 
 
 def rmsnorm(x, gamma, eps=1e-6, out=None):
-    _bf16(x)
+    dt = _h16(x)
     _f32(gamma)
     x2 = x.reshape(-1, x.size(-1))
     if out is None:
         out = torch.empty_like(x2)
     _launch("g4r_rmsnorm_bf16", (
         _p(x2), _p(gamma), _p(out), x2.size(0), x2.size(1), x2.stride(0), out.stride(0),
-                                 float(eps), _stream(x),))
+                                 float(eps), _stream(x),), dt=dt)
     return out.view(x.shape)
 
 
 def groupnorm_affine(x, gamma, beta, groups, eps=1e-5):
     """x [B, H, W, C] bf16 -> scale_shift [B, 2, C] fp32 (deferred GN: y = a*x + s)."""
-    _bf16(x)
+    dt = _h16(x)
     _f32(gamma, beta)
     B, H, W, C = x.shape
     acc = torch.empty((B, 256, groups, 2), dtype=torch.float32, device=x.device)
     ss = torch.empty((B, 2, C), dtype=torch.float32, device=x.device)
     _launch("g4r_groupnorm_affine_nhwc_bf16", (
         _p(x), _p(gamma), _p(beta), _p(acc), _p(ss), B, H * W, C, groups,
-                                               float(eps), _stream(x),))
+                                               float(eps), _stream(x),), dt=dt)
     return ss
 
 
@@ -629,7 +663,7 @@ def groupnorm_affine_mlvl(z, gamma, beta, groups, eps=1e-5):
     """z: MlvlMaps (bf16) -> list over levels of scale_shift [B, 2, C] fp32 (views of one [L, B, 2, C] tensor): the deferred
     GN of every level of a fuse round in two launches (bit-identical per level to groupnorm_affine)."""
     assert isinstance(z, MlvlMaps)
-    _bf16(z.flat)
+    dt = _h16(z.flat)
     _f32(gamma, beta)
     L, B, C = len(z.sizes), z.B, z.C
     acc = torch.empty((L, B, 256, groups, 2), dtype=torch.float32, device=z.flat.device)
@@ -637,7 +671,7 @@ def groupnorm_affine_mlvl(z, gamma, beta, groups, eps=1e-5):
     hw = (c_int * L)(*[h * w for h, w in z.sizes])
     _launch("g4r_groupnorm_affine_mlvl_nhwc_bf16", (_p(z.flat), _p(gamma), _p(beta), _p(acc), _p(ss), L, ctypes.cast(hw, P), B, C,
                                                     groups, float(eps), _stream(z.flat),),
-            tag="g4r_groupnorm_affine_nhwc_bf16")
+            tag="g4r_groupnorm_affine_nhwc_bf16", dt=dt)
     return [ss[l] for l in range(L)]
 
 
@@ -645,7 +679,7 @@ def fuse_shuffle_mlvl(maps, affs, lvl_list, out):
     """Every target level of a fuse round in one launch.  maps: list over levels of NHWC bf16 maps; affs: list of [B,2,C] fp32
     or None per level; lvl_list: [(target, top, down)] covering every level once (layers.py:108-112); out: MlvlMaps."""
     assert isinstance(out, MlvlMaps)
-    _bf16(*maps)
+    dt = _h16(*maps)
     L = len(maps)
     B, _, _, C = maps[0].shape
     top, down = [0] * L, [0] * L
@@ -667,24 +701,24 @@ def fuse_shuffle_mlvl(maps, affs, lvl_list, out):
     _launch("g4r_fuse_shuffle_mlvl_nhwc_bf16", (ctypes.cast(ma, P), ctypes.cast(aa, P) if aa is not None else None,
                                                 ctypes.cast(ha, P), ctypes.cast(wa, P), ctypes.cast(ta, P), ctypes.cast(da, P),
                                                 ctypes.cast(oa, P), L, B, C, _stream(maps[0]),),
-            tag="g4r_fuse_shuffle_nhwc_bf16")
+            tag="g4r_fuse_shuffle_nhwc_bf16", dt=dt)
     return out
 
 
 def upsample_coord(tokens, hin, win, H, W, cpad):
     """tokens [B, hin*win, C] bf16 (row/batch strided ok) -> [B, H, W, cpad] with coord channels."""
-    _bf16(tokens)
+    dt = _h16(tokens)
     B, n, C = tokens.shape
     assert n == hin * win and tokens.stride(2) == 1
-    out = torch.empty((B, H, W, cpad), dtype=torch.bfloat16, device=tokens.device)
+    out = torch.empty((B, H, W, cpad), dtype=dt, device=tokens.device)
     _launch("g4r_upsample_coord_nhwc_bf16", (
         _p(tokens), _p(out), B, hin, win, tokens.stride(0), tokens.stride(1),
-                                             H, W, C, cpad, _stream(tokens),))
+                                             H, W, C, cpad, _stream(tokens),), dt=dt)
     return out
 
 
 def fuse_shuffle(own, top, down, own_aff=None, top_aff=None, down_aff=None, out=None):
-    _bf16(own, top, down)
+    dt = _h16(own, top, down)
     _f32(own_aff, top_aff, down_aff)
     B, H, W, C = own.shape
     if out is None:
@@ -692,38 +726,40 @@ def fuse_shuffle(own, top, down, own_aff=None, top_aff=None, down_aff=None, out=
     _launch("g4r_fuse_shuffle_nhwc_bf16", (
         _p(own), _p(own_aff), H, W, _p(top), _p(top_aff), top.size(1),
                                            top.size(2), _p(down), _p(down_aff), down.size(1), down.size(2),
-                                           _p(out), B, C, _stream(own),))
+                                           _p(out), B, C, _stream(own),), dt=dt)
     return out
 
 
-def im2col_patch14(img, kpad=640):
+def im2col_patch14(img, kpad=640, dtype=torch.bfloat16):
+    """fp32 image [B,3,S,S] -> the [B*P*P, kpad] patch rows in the 16-bit storage type `dtype`."""
     _f32(img)
+    dt = _h16(dtype)
     img = img.contiguous()
     B, _, S, _ = img.shape
     Pn = S // 14
-    out = torch.empty((B * Pn * Pn, kpad), dtype=torch.bfloat16, device=img.device)
+    out = torch.empty((B * Pn * Pn, kpad), dtype=dt, device=img.device)
     _launch("g4r_im2col_patch14_f32", (
-        _p(img), _p(out), B, S, kpad, _stream(img),))
+        _p(img), _p(out), B, S, kpad, _stream(img),), dt=dt)
     return out
 
 
 def vit_assemble(patch, cls, pos, B):
-    _bf16(patch, cls, pos)
+    dt = _h16(patch, cls, pos)
     n = patch.size(0) // B
     C = patch.size(1)
-    tok = torch.empty((B, n + 1, C), dtype=torch.bfloat16, device=patch.device)
+    tok = torch.empty((B, n + 1, C), dtype=dt, device=patch.device)
     _launch("g4r_vit_assemble_bf16", (
-        _p(patch), _p(cls), _p(pos), _p(tok), B, n, C, _stream(patch),))
+        _p(patch), _p(cls), _p(pos), _p(tok), B, n, C, _stream(patch),), dt=dt)
     return tok
 
 
 def rope_qkv(qkv, cos, sin, q_out, k_cache, v_cache, heads, head_dim, pos0, pos_dev=None):
-    _bf16(qkv, q_out, k_cache, v_cache)
+    dt = _h16(qkv, q_out, k_cache, v_cache)
     _f32(cos, sin)
     T = qkv.size(0)
     _launch("g4r_rope_qkv_bf16", (
         _p(qkv), _p(cos), _p(sin), _p(q_out), _p(k_cache), _p(v_cache), T, heads,
-                                  head_dim, pos0, _p(pos_dev), _stream(qkv),))
+                                  head_dim, pos0, _p(pos_dev), _stream(qkv),), dt=dt)
 
 
 def interleave_gate_up(gate_w, up_w):
@@ -732,29 +768,29 @@ def interleave_gate_up(gate_w, up_w):
 
 
 def swiglu(gate_up, out=None):
-    _bf16(gate_up)
+    dt = _h16(gate_up)
     T, F2 = gate_up.shape
     if out is None:
-        out = torch.empty((T, F2 // 2), dtype=torch.bfloat16, device=gate_up.device)
+        out = torch.empty((T, F2 // 2), dtype=dt, device=gate_up.device)
     _launch("g4r_swiglu_bf16", (
-        _p(gate_up), _p(out), T, F2 // 2, _stream(gate_up),))
+        _p(gate_up), _p(out), T, F2 // 2, _stream(gate_up),), dt=dt)
     return out
 
 
 def splice_embed(ids, embed, img, spi, spi_offset, n_patch, patch_id, bbox_id, im_start_id, im_end_id):
     """ids [B,T] int64; embed [V,C]; img [B,n_patch,C] or None; spi [N,C] or None;
     spi_offset int32 [B+1] or None -> (inputs_embeds [B,T,C], status int32 [B])."""
-    _bf16(embed, img, spi)
+    dt = _h16(embed, img, spi)
     _lib.require_gpu(ids)
     assert ids.dtype == torch.int64 and ids.is_contiguous()
     B, T = ids.shape
     C = embed.size(1)
-    out = torch.empty((B, T, C), dtype=torch.bfloat16, device=ids.device)
+    out = torch.empty((B, T, C), dtype=dt, device=ids.device)
     status = torch.empty((B,), dtype=torch.int32, device=ids.device)
     _launch("g4r_splice_embed_bf16", (
         _p(ids), _p(embed), _p(img), _p(spi), _p(spi_offset), _p(out), _p(status),
                                       B, T, C, n_patch if img is not None else 0, patch_id, bbox_id,
-                                      im_start_id, im_end_id, embed.size(0), _stream(ids),))
+                                      im_start_id, im_end_id, embed.size(0), _stream(ids),), dt=dt)
     return out, status
 
 
@@ -798,22 +834,24 @@ def argmax_rows(logits):
 
 
 def add_rows(a, b, out=None):
-    _bf16(a, b)
+    dt = _h16(a, b)
     a2 = a.reshape(-1, a.size(-1))
     b2 = b.reshape(-1, b.size(-1))
     if out is None:
         out = torch.empty_like(a2)
     _launch("g4r_add_rows_bf16", (
-        _p(a2), _p(b2), _p(out), a2.size(0), a2.size(1), b2.size(0), _stream(a),))
+        _p(a2), _p(b2), _p(out), a2.size(0), a2.size(1), b2.size(0), _stream(a),), dt=dt)
     return out.view(a.shape)
 
 
-def cast_bf16(x):
+def cast_bf16(x, dtype=torch.bfloat16):
+    """fp32 -> the 16-bit storage type (round to nearest even)."""
     _f32(x)
+    dt = _h16(dtype)
     x = x.contiguous()
-    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(x.shape, dtype=dt, device=x.device)
     _launch("g4r_cast_f32_to_bf16", (
-        _p(x), _p(y), x.numel(), _stream(x),))
+        _p(x), _p(y), x.numel(), _stream(x),), dt=dt)
     return y
 
 
@@ -841,7 +879,8 @@ def roi_align_mlvl(feats, rois, output_size, scales, sampling_ratio=2, aligned=T
     -> [L, N, ph, pw, C] in the dtype of feats."""
     L = len(feats)
     dt = feats[0].dtype
-    name = {torch.bfloat16: "g4r_roi_align_mlvl_nhwc_bf16", torch.float32: "g4r_roi_align_mlvl_nhwc_f32"}[dt]
+    name = {torch.bfloat16: "g4r_roi_align_mlvl_nhwc_bf16", torch.float16: "g4r_roi_align_mlvl_nhwc_bf16",
+            torch.float32: "g4r_roi_align_mlvl_nhwc_f32"}[dt]
     for f in feats:
         _lib.require_gpu(f)
         assert f.dtype == dt and f.is_contiguous() and f.dim() == 4
@@ -866,7 +905,7 @@ def roi_align_mlvl(feats, rois, output_size, scales, sampling_ratio=2, aligned=T
     _launch(name, (ctypes.cast(fa, P), ctypes.cast(aa, P) if aa is not None else None, ctypes.cast(ha, P),
                    ctypes.cast(wa, P), ctypes.cast(sa, P), L, _p(rois), _p(out), B, C, N, ph, pw,
                    int(sampling_ratio), int(bool(aligned)), _stream(rois)),
-            tag="roi_align_mlvl_nhwc", flops=0.0, nbytes=float(alg))
+            tag="roi_align_mlvl_nhwc", flops=0.0, nbytes=float(alg), dt=dt)
     return out
 
 

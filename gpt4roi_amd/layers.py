@@ -90,7 +90,7 @@ class MLVLFuseModule(nn.Module):
         dev = self.input_conv[0].weight.device
         cin = self.input_dims + 2
         self.cpad = -(-cin // 64) * 64
-        bf = torch.bfloat16
+        bf = getattr(self, "compute_dtype", torch.bfloat16)      # set by MLVLROIQueryModule.set_compute_dtype
         w_in, b_in = [], []
         with torch.no_grad():
             for conv in self.input_conv:
@@ -98,7 +98,7 @@ class MLVLFuseModule(nn.Module):
                 w[:, :cin] = conv.weight.reshape(self.embed_dims, cin).to(bf)
                 w_in.append(w)
                 b_in.append(conv.bias.to(bf).float().contiguous())
-            w_f = [K.prep_conv3x3_weight(m.conv.weight.detach()) for m in self.fuse_convs]
+            w_f = [K.prep_conv3x3_weight(m.conv.weight.detach(), bf) for m in self.fuse_convs]
             gn = [(m.gn.weight.detach().float().contiguous(), m.gn.bias.detach().float().contiguous(),
                    m.gn.num_groups, m.gn.eps) for m in self.fuse_convs]
         self._ready = dict(w_in=w_in, b_in=b_in, w_f=w_f, gn=gn)
@@ -123,7 +123,7 @@ class MLVLFuseModule(nn.Module):
         dev = maps[0].device
         for rnd in range(self.num_fuse):
             g, bt, groups, eps = r['gn'][rnd]
-            inp = K.MlvlMaps(B, hw, self.embed_dims, dev)
+            inp = K.MlvlMaps(B, hw, self.embed_dims, dev, dtype=maps[0].dtype)
             K.fuse_shuffle_mlvl(maps, affs, self.fuse_lvl_list, inp)       # every level's conv input: one launch
             z = K.conv3x3_mlvl(inp, r['w_f'][rnd])
             maps = z.levels
@@ -214,7 +214,12 @@ class PreparedBoxes:
     the [img_id, box * image_size] RoI table of layers.py:295-302, the raw normalised boxes for
     pos_embedd (layers.py:284-285), the per-image counts and their prefix sums (for the splice)."""
 
-    def __init__(self, bboxes, image_size, device):
+    def __init__(self, bboxes, image_size, device, dtype=torch.bfloat16):
+        """dtype: the 16-bit storage type of the request.  torch.float16 reproduces the serving path of the reference, where
+        the boxes arrive as `.half()` (app.py:271): `single_img_roi * 224` (layers.py:297) is then a HALF product, rounded
+        to fp16 before RoIAlign's `.to(float32)` (layers.py:311).  With bf16 (the training dtype, where the dataset hands
+        fp32 boxes) the product stays fp32."""
+        self.dtype = dtype
         self.counts = [int(b.size(0)) for b in bboxes]
         self.num_imgs = len(bboxes)
         n = sum(self.counts)
@@ -222,8 +227,10 @@ class PreparedBoxes:
         boxes = torch.cat([b.detach().float() for b in bboxes], 0) if n else torch.zeros(0, 4, device=src)
         img_id = torch.cat([torch.full((c,), float(i), device=src) for i, c in enumerate(self.counts)]) \
             if self.num_imgs else torch.zeros(0, device=src)
-        self.rois5 = torch.cat([img_id[:, None], boxes * float(image_size)], 1).contiguous().to(device)
-        self.boxes_bf16 = boxes.to(torch.bfloat16).to(device)
+        scaled = (boxes.to(torch.float16) * float(image_size)).float() if dtype is torch.float16 else boxes * float(image_size)
+        self.rois5 = torch.cat([img_id[:, None], scaled], 1).contiguous().to(device)
+        self.boxes_h16 = boxes.to(dtype).to(device)              # pos_embedd input (layers.py:284-285) in the storage type
+        self.boxes_bf16 = self.boxes_h16                         # (older name)
         off = [0]
         for c in self.counts:
             off.append(off[-1] + c)
@@ -275,11 +282,11 @@ class MlvlRoIExtractor(BaseRoIExtractor):
                 normal_init(m, 0, 0.01)
 
     def prepare(self):
-        bf = torch.bfloat16
+        bf = getattr(self, "compute_dtype", torch.bfloat16)
         C = self.embed_dims
         oh, ow = self.roi_layers[0].output_size
         with torch.no_grad():
-            w_p = K.prep_conv3x3_weight([c.weight.detach() for c in self.pconvs])
+            w_p = K.prep_conv3x3_weight([c.weight.detach() for c in self.pconvs], bf)
             b_p = sum(c.bias.detach().to(bf).float() for c in self.pconvs).contiguous()
             # flatten is c-major in the reference (layers.py:326): column c*oh*ow + pos.  Our RoI
             # features are NHWC, so permute the weight once: column pos*C + c.
@@ -303,13 +310,14 @@ class MlvlRoIExtractor(BaseRoIExtractor):
             self.prepare()
         r = self._ready
         dev = feats[0].device
-        prep = rois if isinstance(rois, PreparedBoxes) else PreparedBoxes(rois, image_size, dev)
+        prep = rois if isinstance(rois, PreparedBoxes) else PreparedBoxes(rois, image_size, dev, dtype=feats[0].dtype)
+        assert prep.dtype == feats[0].dtype, "PreparedBoxes were built for another storage type"
         num_imgs, counts, N = prep.num_imgs, prep.counts, prep.n
         out_dims = self.updims.out_features
         if N == 0:
             return [feats[0].new_zeros((0, out_dims)) for _ in range(num_imgs)]
         # pos_embedd(cat(bboxes)) on the raw normalised boxes (layers.py:284-285)
-        pe = K.gemm(prep.boxes_bf16, r['pe0'][0], bias=r['pe0'][1], act='relu')
+        pe = K.gemm(prep.boxes_h16, r['pe0'][0], bias=r['pe0'][1], act='relu')
         pe = K.layernorm(pe, r['ln2'][0], r['ln2'][1], r['ln2'][2])
         pe = K.gemm(pe, r['pe3'][0], bias=r['pe3'][1], act='relu')
         pe = K.layernorm(pe, r['ln5'][0], r['ln5'][1], r['ln5'][2])
@@ -335,7 +343,7 @@ class MlvlRoIExtractor(BaseRoIExtractor):
         dev = feats[0].device
         prep = rois if isinstance(rois, PreparedBoxes) else PreparedBoxes(rois, image_size, dev)
         assert prep.n > 0, "training needs at least one box"
-        h1 = K.gemm(prep.boxes_bf16, r['pe0'][0], bias=r['pe0'][1], act='relu')
+        h1 = K.gemm(prep.boxes_h16, r['pe0'][0], bias=r['pe0'][1], act='relu')
         l2 = K.layernorm(h1, r['ln2'][0], r['ln2'][1], r['ln2'][2])
         h3 = K.gemm(l2, r['pe3'][0], bias=r['pe3'][1], act='relu')
         pe = K.layernorm(h3, r['ln5'][0], r['ln5'][1], r['ln5'][2])
@@ -376,7 +384,7 @@ class MlvlRoIExtractor(BaseRoIExtractor):
         g['pos_embedd.2.weight'], g['pos_embedd.2.bias'] = z(256), z(256)
         d_h1 = K.layernorm_bwd(ctx['h1'], r['ln2'][0], d_l2, g['pos_embedd.2.weight'], g['pos_embedd.2.bias'], r['ln2'][2])
         d_p1 = K.relu_bwd(ctx['h1'], d_h1)
-        g['pos_embedd.0.weight'] = K.linear_wgrad(d_p1, prep.boxes_bf16)
+        g['pos_embedd.0.weight'] = K.linear_wgrad(d_p1, prep.boxes_h16)
         g['pos_embedd.0.bias'] = K.colsum(d_p1)
         # flatten_linear (kernel layout: column pos*C + c; reference: column c*oh*ow + pos)
         flat = ctx['fused'].view(N, -1)
@@ -415,7 +423,19 @@ class MLVLROIQueryModule(nn.Module):
                                   featmap_strides=strids, out_dims=out_dims)
         self.roi_align = MlvlRoIExtractor(**bbox_roi_extractor)
 
+    compute_dtype = torch.bfloat16
+
+    def set_compute_dtype(self, dtype):
+        """16-bit storage type of the kernel-ready weights and every activation of the module: torch.bfloat16 (default, the
+        training dtype) or torch.float16 (the reference's serving dtype, app.py:74-98).  Inference only for fp16."""
+        assert dtype in K.H16
+        if dtype != self.compute_dtype:
+            self.compute_dtype = dtype
+            self.mlvl_fuse._ready = self.roi_align._ready = None
+        return self
+
     def prepare(self):
+        self.mlvl_fuse.compute_dtype = self.roi_align.compute_dtype = self.compute_dtype
         self.mlvl_fuse.prepare()
         self.roi_align.prepare()
         self._stamp = self._param_stamp()
@@ -426,8 +446,8 @@ class MLVLROIQueryModule(nn.Module):
             if f.dim() == 4:                                   # NCHW -> token form
                 b, c, h, w = f.shape
                 f = f.permute(0, 2, 3, 1).reshape(b, h * w, c)
-            if f.dtype != torch.bfloat16:
-                f = f.to(torch.bfloat16)
+            if f.dtype != self.compute_dtype:
+                f = f.to(self.compute_dtype)
             toks.append(f)
         P = int(math.isqrt(toks[0].shape[1]))
         assert P * P == toks[0].shape[1], "level features must be square token grids"

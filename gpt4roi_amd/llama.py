@@ -18,9 +18,13 @@ from . import kernels as K
 
 class LlamaDecoder:
     def __init__(self, state_dict, heads, eps=1e-6, theta=10000.0, max_positions=2048, device="cuda",
-                 num_layers=None, max_batch=1):
+                 num_layers=None, max_batch=1, dtype=torch.bfloat16):
+        """dtype: the 16-bit storage type of weights, activations and the KV cache -- torch.bfloat16 (training dtype,
+        train_stage1.sh:19) or torch.float16 (the reference's serving dtype, app.py:74-98); fp32 accumulation either way.
+        Training (forward_train / backward) is bf16 only."""
         sd = state_dict
-        bf = torch.bfloat16
+        assert dtype in K.H16
+        self.dtype = bf = dtype
 
         def g(name, dtype=bf):
             return sd[name].detach().to(device=device, dtype=dtype).contiguous()
@@ -55,7 +59,7 @@ class LlamaDecoder:
 
     def _alloc_cache(self, batch):
         L = len(self.layers)
-        self.kc = torch.zeros((L, batch, self.max_positions, self.hidden), dtype=torch.bfloat16, device=self.device)
+        self.kc = torch.zeros((L, batch, self.max_positions, self.hidden), dtype=self.dtype, device=self.device)
         self.vc = torch.zeros_like(self.kc)
         self.pos = 0
         self._dstate = None            # a captured decode graph points into the old cache
@@ -74,11 +78,11 @@ class LlamaDecoder:
         assert self.pos + T <= self.max_positions and B <= self.kc.size(1)
         H, D, pos0 = self.heads, self.head_dim, self.pos
         x = inputs_embeds.reshape(B * T, C)
-        if x.dtype != torch.bfloat16:
-            x = x.to(torch.bfloat16)
+        if x.dtype != self.dtype:
+            x = x.to(self.dtype)
         x = x.contiguous()
         scale = 1.0 / math.sqrt(D)
-        q = torch.empty((B, T, C), dtype=torch.bfloat16, device=x.device)
+        q = torch.empty((B, T, C), dtype=self.dtype, device=x.device)
         h = None                                             # the next RMSNorm output when the down_proj reduce produced it
         for li, L in enumerate(self.layers):
             if h is None:
@@ -123,6 +127,7 @@ class LlamaDecoder:
         """Materialise W^T for every projection (the input-gradient GEMMs are NT GEMMs against W^T;
         13 GB for the 7B model, a one-off for frozen weights, refreshed by `refresh_transposes` after an
         optimizer step when the decoder itself is trained)."""
+        assert self.dtype is torch.bfloat16, "training runs in bf16 (train_stage1.sh:19); the fp16 instantiation is inference only"
         self.train_weights = train_weights
         self.v_pad = -(-self.vocab // 64) * 64
         self.refresh_transposes()

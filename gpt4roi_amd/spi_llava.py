@@ -122,7 +122,12 @@ class SPILlavaLlamaModel(nn.Module):
         self.vision_tower = [vision_tower]          # a list, as in the reference (llava.py:48): not in the state_dict
         self.llama = llama
         self.config = token_ids                     # im_patch_token, im_start_token, im_end_token, bbox_token
+        # the 16-bit storage type of the whole path follows the decoder's: bf16 (training dtype) or fp16 (the reference's
+        # serving dtype, app.py:74-98: model, boxes :271 and image :296 are all .half())
+        self.dtype = getattr(llama, "dtype", torch.bfloat16)
+        assert vision_tower is None or vision_tower.dtype == self.dtype, "vision tower and decoder must share the storage type"
         self.spi_module = MLVLROIQueryModule(embed_dims=embed_dims, out_dims=llama.hidden, num_levels=4)
+        self.spi_module.set_compute_dtype(self.dtype)
         self.mm_projector = mm_projector if mm_projector is not None else nn.Linear(embed_dims, llama.hidden)
         self._proj = None
         self._stamp = None
@@ -135,7 +140,7 @@ class SPILlavaLlamaModel(nn.Module):
                                                                          self.mm_projector.parameters()))
 
     def prepare(self):
-        bf = torch.bfloat16
+        bf = self.dtype
         dev = self.llama.device
         self.spi_module.to(dev)
         self.mm_projector.to(dev)
@@ -193,13 +198,13 @@ class SPILlavaLlamaModel(nn.Module):
             image_features, mlvl = tower.select(keep)
             if bboxes is not None and (isinstance(bboxes, PreparedBoxes) or len(bboxes) > 0):
                 if not isinstance(bboxes, PreparedBoxes):      # reference contract: list[B] of [n_i, 4]
-                    bboxes = PreparedBoxes(bboxes, images.size(-1), images.device)
+                    bboxes = PreparedBoxes(bboxes, images.size(-1), images.device, dtype=self.dtype)
                 feats = self.spi_module(mlvl, bboxes)
                 spi = torch.cat(feats, 0).contiguous() if len(feats) > 1 else feats[0]
                 off = bboxes.offsets
             n_patch = image_features.size(1)
             # mm_projector over the patch tokens (strided view of the hidden state, CLS skipped)
-            img_tok = torch.empty((B, n_patch, self.llama.hidden), dtype=torch.bfloat16, device=images.device)
+            img_tok = torch.empty((B, n_patch, self.llama.hidden), dtype=self.dtype, device=images.device)
             for b in range(B):
                 K.gemm(image_features[b], self._proj[0], bias=self._proj[1], out=img_tok[b])
         embeds, status = K.splice_embed(input_ids.contiguous(), self.llama.embed, img_tok, spi, off, n_patch,
@@ -210,7 +215,7 @@ class SPILlavaLlamaModel(nn.Module):
     def prepare_boxes(self, bboxes, image_size):
         """Do the host-side part of a request once (see layers.PreparedBoxes); the returned object can be
         passed as `bboxes=` and makes forward() free of host<->device traffic (hipGraph-capturable)."""
-        return PreparedBoxes(bboxes, image_size, self.llama.device)
+        return PreparedBoxes(bboxes, image_size, self.llama.device, dtype=self.dtype)
 
     def clone_context(self):
         """A second request context: shares every weight / prepared buffer with `self`, owns its KV

@@ -16,10 +16,13 @@ from . import kernels as K
 
 class ClipVisionTower:
     def __init__(self, state_dict, heads=16, eps=1e-5, device="cuda", select_layer=-2, num_levels=4,
-                 num_layers=None):
+                 num_layers=None, dtype=torch.bfloat16):
+        """dtype: 16-bit storage type (bf16, or fp16 as the reference serves it: app.py:96 `vision_tower.to(dtype=float16)`)."""
         sd = state_dict
+        assert dtype in K.H16
+        self.dtype = dtype
         pre = "vision_model." if "vision_model.pre_layrnorm.weight" in sd else ""
-        bf = torch.bfloat16
+        bf = dtype
 
         def g(name, dtype=bf):
             return sd[pre + name].detach().to(device=device, dtype=dtype).contiguous()
@@ -65,7 +68,7 @@ class ClipVisionTower:
         B, _, S, _ = images.shape
         C, H = self.hidden, self.heads
         D = C // H
-        cols = K.im2col_patch14(images.float(), self.kpad)
+        cols = K.im2col_patch14(images.float(), self.kpad, dtype=self.dtype)
         patch = K.gemm(cols, self.w_patch)
         n = patch.size(0) // B
         assert n + 1 <= self.pos.size(0), "image larger than the position table"

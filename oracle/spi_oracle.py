@@ -36,7 +36,11 @@ from . import roi_align as roi_oracle
 
 
 def _r(x, emulate):
-    return x.to(torch.bfloat16).to(torch.float32) if emulate else x
+    """emulate: False = exact fp32; True = round to bfloat16 (the training dtype); a torch dtype (torch.float16: the
+    reference's serving dtype, app.py:74-98) = round to that type."""
+    if not emulate:
+        return x
+    return x.to(torch.bfloat16 if emulate is True else emulate).to(torch.float32)
 
 
 class ConvModuleOracle(nn.Module):
@@ -179,7 +183,12 @@ class MlvlRoIExtractorOracle(BaseRoIExtractorOracle):
         pe = _r(pe, emulate)
         new_rois = []
         for img_id, r in enumerate(rois):
-            r = r.float() * self.image_size                      # layers.py:297 (224 at P = 16)
+            if emulate is torch.float16:
+                # serving: the boxes arrive as .half() (app.py:271), so `single_img_roi * 224` (layers.py:297) is a half
+                # product, rounded to fp16 before RoIAlign's .to(float32) (layers.py:311)
+                r = (r.to(torch.float16) * self.image_size).float()
+            else:
+                r = r.float() * self.image_size                  # layers.py:297 (224 at P = 16)
             new_rois.append(torch.cat([r.new_ones(len(r), 1) * img_id, r], 1))
         rois5 = torch.cat(new_rois)
         roi_feats = [self.roi_layers[i](feats[i].float(), rois5) for i in range(len(feats))]

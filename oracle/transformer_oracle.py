@@ -25,7 +25,11 @@ import torch.nn.functional as F
 
 
 def _r(x, emulate):
-    return x.to(torch.bfloat16).to(torch.float32) if emulate else x
+    """emulate: False = exact fp32; True = round to bfloat16 (the training dtype); a torch dtype (torch.float16: the
+    reference's serving dtype, app.py:74-98) = round to that type."""
+    if not emulate:
+        return x
+    return x.to(torch.bfloat16 if emulate is True else emulate).to(torch.float32)
 
 
 def _lin(x, w, b, emulate):

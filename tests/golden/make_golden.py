@@ -101,8 +101,33 @@ def seeded():
     np.savez_compressed(os.path.join(HERE, "roi_align_seeded.npz"), **d)
 
 
+def edges_mlvl():
+    """Edge boxes for the PRODUCTION kernel (g4r_roi_align_mlvl_nhwc_*: four levels, NHWC, one launch -- VERDICT r03
+    weak-2: its edge handling was only ever compared with itself).  The reference's compiled CPU op (oracle/_ref) runs each
+    of the four levels of a P = 4 pyramid (maps 32/16/8/4, strides 14/8 .. 14 as layers.py:206-214) on boxes that hang
+    off every border, lie fully outside, have zero area, cover the whole image, are sub-pixel thin, and sit on the last
+    row / column.  Map values are multiples of 1/16 below 8: exact in fp32, bf16 and fp16, so the 16-bit instantiations
+    are checked against the same file with only their OUTPUT rounding as tolerance."""
+    rng = np.random.default_rng(77)
+    P, C, B = 4, 16, 2
+    img = 14.0 * P
+    sizes = [8 * P, 4 * P, 2 * P, P]
+    strides = [14 / 8, 14 / 4, 14 / 2, 14.0]
+    r = np.array([[0, -20., -20., 30., 40.], [1, 0., 0., img, img], [0, 25., 25., 25., 25.], [1, 70., 70., 90., 95.],
+                  [0, img - 3, img - 3, img + 30, img + 30], [1, -40., -40., -10., -5.], [0, 10.3, 20.7, 17.1, 25.2],
+                  [1, 5., 30., 50., 30.4], [0, img - 1, 0., img, img], [1, 0., img - 0.5, img, img],
+                  [0, -0.4, -0.4, 0.4, 0.4], [1, 12.25, 3.5, 40.75, 52.0]], np.float32)
+    d = {"rois": r, "strides": np.array(strides, np.float64), "cfg": np.array([14, 14, 2, 1, 1], np.int64)}
+    for l, (sz, st) in enumerate(zip(sizes, strides)):
+        x = np.clip(np.round(rng.standard_normal((B, C, sz, sz)) * 16) / 16, -7.9375, 7.9375).astype(np.float32)
+        o, _, _ = O.ref_forward(x, r, 14, np.float32(1.0 / st), 2, "avg", True)
+        d[f"x{l}"], d[f"out{l}"] = x, o
+    np.savez_compressed(os.path.join(HERE, "roi_align_edges_mlvl.npz"), **d)
+
+
 if __name__ == "__main__":
     known()
     seeded()
-    for f in ("roi_align_known.npz", "roi_align_seeded.npz"):
+    edges_mlvl()
+    for f in ("roi_align_known.npz", "roi_align_seeded.npz", "roi_align_edges_mlvl.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

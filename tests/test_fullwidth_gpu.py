@@ -280,25 +280,120 @@ def test_config5_shape_224_crops_64_regions_full_width():
 
 
 # ------------------------------------------------------------------------------------------ the BENCHMARKED model, full depth
-def test_bench_model_full_depth_32_layers_vs_hf_fp32_on_the_gpu():
+def _hf_llama_fp32(lsd, ids, n_layers):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    l = syn.LLAMA_7B
+    lcfg = LlamaConfig(vocab_size=ids.vocab, hidden_size=l["hidden"], intermediate_size=l["inter"],
+                       num_hidden_layers=n_layers, num_attention_heads=l["heads"], num_key_value_heads=l["heads"],
+                       rms_norm_eps=1e-6, max_position_embeddings=2048, attention_bias=False, tie_word_embeddings=False,
+                       rope_theta=10000.0, attn_implementation="eager")
+    with torch.device(DEV):
+        hf_l = LlamaForCausalLM(lcfg).float().eval()
+    r = hf_l.load_state_dict({k: v.float() for k, v in lsd.items()}, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    return hf_l
+
+
+def _greedy_parity(dec, hf_l, spliced, lsd, n_new, emulate, what):
+    """generate(do_sample=False) (app.py:293-300 with sampling off) of the HIP decoder against HF LlamaForCausalLM fp32 from
+    the SAME prompt embeddings, with the rounding-emulating oracle (oracle/transformer_oracle.py, `emulate` = the HIP
+    path's storage type) run beside both as the yardstick of what that storage type costs.
+
+    STRICT criterion: the comparison is teacher-forced with HF fp32's own greedy ids -- a pipeline
+    that disagrees once cannot hide behind the divergence that follows -- and at every one of the n_new steps the HIP
+    choice must EQUAL HF's, unless HF's fp32 logit gap between the two choices is smaller than the emulating oracle's OWN
+    max |logit error| against fp32 at that step (a tie no pipeline in that storage type can be expected to resolve; on
+    flat random-init logits these exist: seed 282, step 11: top-2 margin 4e-4 of a 10.7 range).  Also asserted: the HIP
+    path's rms logit error against fp32 is not larger than 1.25x the oracle's own at every step (it rounds at FEWER points
+    than the oracle -- SwiGLU, RoPE and the norms round once from fp32 -- so it should not be worse), and the free-running
+    device loop reproduces the teacher-forced choices up to the first tolerated tie."""
+    l = syn.LLAMA_7B
+    dt = dec.dtype
+    w = dict(hf_l.state_dict())
+    embed = hf_l.get_input_embeddings()
+    with torch.no_grad():
+        # HF fp32, greedy, KV cache
+        o = hf_l(inputs_embeds=spliced.to(DEV).float(), use_cache=True)
+        past, last = o.past_key_values, o.logits[0, -1]
+        want_ids, want_trace = [], []
+        for _ in range(n_new):
+            want_trace.append(last.float())
+            nxt = int(last.argmax())
+            want_ids.append(nxt)
+            o = hf_l(inputs_embeds=embed(torch.tensor([[nxt]], device=DEV)), past_key_values=past, use_cache=True)
+            past, last = o.past_key_values, o.logits[0, -1]
+        # the emulating oracle, teacher-forced with HF's ids (torch's GPU kernels, fp32 arithmetic, rounding at the
+        # storage points of an HF model run in that dtype)
+        h, cache = T.llama_forward(w, spliced.to(DEV).float(), l["heads"], emulate=emulate)
+        em_trace, pos = [], spliced.shape[1]
+        for sidx in range(n_new):
+            em_trace.append(T.lm_logits(w, h[:, -1:], emulate)[0, 0].float())
+            h, cache = T.llama_forward(w, embed(torch.tensor([[want_ids[sidx]]], device=DEV)), l["heads"], kv_cache=cache,
+                                       pos0=pos, emulate=emulate)
+            pos += 1
+        # the HIP decoder, teacher-forced with HF's ids
+        dec.reset(1)
+        lg = dec.forward(spliced.to(DEV).to(dt), all_logits=False)
+        hip_trace, forced = [], []
+        for sidx in range(n_new):
+            hip_trace.append(lg.view(-1).float())
+            forced.append(int(lg.view(-1).argmax()))
+            lg = dec.forward(lsd["model.embed_tokens.weight"][want_ids[sidx]].view(1, 1, -1).to(dt), all_logits=False)
+        got_free = dec.greedy(spliced.to(DEV).to(dt), n_new)
+    flips, worst_ratio, worst_max_ratio = [], 0.0, 0.0
+    for sidx in range(n_new):
+        e_hip = (hip_trace[sidx] - want_trace[sidx]).abs().max().item()
+        e_em = (em_trace[sidx] - want_trace[sidx]).abs().max().item()
+        r_hip = (hip_trace[sidx] - want_trace[sidx]).pow(2).mean().sqrt().item()
+        r_em = (em_trace[sidx] - want_trace[sidx]).pow(2).mean().sqrt().item()
+        worst_ratio = max(worst_ratio, r_hip / r_em)
+        worst_max_ratio = max(worst_max_ratio, e_hip / e_em)
+        if forced[sidx] != want_ids[sidx]:
+            gap = float(want_trace[sidx][want_ids[sidx]] - want_trace[sidx][forced[sidx]])
+            flips.append((sidx, gap, e_em, e_hip))
+    span = float(want_trace[0].max() - want_trace[0].min())
+    e_hip0 = (hip_trace[0] - want_trace[0]).abs().max().item()
+    e_em0 = (em_trace[0] - want_trace[0]).abs().max().item()
+    print(f"{what}: logit range {span:.2f}; max |logit err| vs HF fp32 at the first step: HIP {e_hip0:.4f}, emulating oracle "
+          f"{e_em0:.4f}; worst HIP/oracle error ratio over {n_new} steps: rms {worst_ratio:.2f}, max {worst_max_ratio:.2f}")
+    print(f"  HF fp32 greedy          : {want_ids}\n  HIP, teacher-forced     : {forced}\n  HIP, free-running       : {got_free}")
+    for (sidx, gap, e_em, e_hip) in flips:
+        print(f"  step {sidx}: different choice; HF fp32 gap between the two choices {gap:.3e}; the emulating oracle's own max "
+              f"|logit err| at this step {e_em:.3e} (HIP {e_hip:.3e})")
+        assert 0 <= gap < e_em, f"{what}: step {sidx}: ids differ from HF fp32 by MORE than the storage type's own error"
+    assert worst_ratio < 1.25 and worst_max_ratio < 2.0, \
+        f"{what}: HIP logit error exceeds the emulating oracle's own (rms {worst_ratio:.2f}x, max {worst_max_ratio:.2f}x)"
+    first = flips[0][0] if flips else n_new
+    assert got_free[:first] == want_ids[:first], f"{what}: the free-running device loop left the teacher-forced path early"
+    print(f"  {n_new - len(flips)} of {n_new} choices identical to HF LlamaForCausalLM fp32"
+          + ("" if not flips else f"; {len(flips)} tie(s) below the storage type's own error, listed above"))
+    return len(flips), want_ids, want_trace, [(e - w_).abs().max().item() for e, w_ in zip(em_trace, want_trace)]
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "fp16"])
+def test_bench_model_full_depth_32_layers_vs_hf_fp32_on_the_gpu(dtype_name):
     """What bench.py times -- ViT-L/14@336 (23 blocks) + region module (C = 1024, P = 24, 32 RoIs) + projector + splice +
     LLaMA-7B at its FULL depth (32 layers x 4096, T = 767) -- against the arithmetic the reference actually calls:
     HF `CLIPVisionModel` and `LlamaForCausalLM` (spi_llava.py:66-67, 198-205; llava.py:235-249), built from the SAME
     state dicts and run in fp32 with eager attention ON THE GPU (PyTorch-ROCm's own kernels: arithmetic independent of
-    everything under gpt4roi_amd/), with the region module from oracle/spi_oracle.py (bf16 rounding points, CPU, its
-    RoIAlign node = the C oracle pinned to the reference's compiled CPU op) in between.  Asserts the logits of all 767
-    positions and 16 greedy ids (generate(do_sample=False), app.py:293-300 with sampling off).
-    Tolerance: logits within 4e-2 of the logit range (a bf16 pipeline, 32 layers deep, against fp32); ids identical, unless
-    the fp32 top-2 margin at the first differing step is a near tie (< 1 % of that step's logit range) -- printed."""
-    from transformers import CLIPVisionConfig, CLIPVisionModel, LlamaConfig, LlamaForCausalLM
+    everything under gpt4roi_amd/), with the region module from oracle/spi_oracle.py (rounding points of the storage type,
+    CPU, its RoIAlign node = the C oracle pinned to the reference's compiled CPU op) in between.
+    Both storage types: bf16 (the reference's training dtype) and fp16 (its SERVING dtype -- app.py:74-98 loads the model,
+    :271 the boxes and :296 the image as .half() -- i.e. BASELINE configs[1] as the reference runs it).
+    Asserts the logits of all 767 positions (4e-2 of the logit range in bf16, 6e-3 in fp16) and the greedy ids by the
+    strict criterion of _greedy_parity."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    dt = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    emulate = True if dtype_name == "bf16" else torch.float16
     Hv, P, image, heads_v, n_new = 1024, 24, 336, 16, 16
     ids = syn.token_ids(32000)
     l = syn.LLAMA_7B
-    # bf16-representable weights, generated on the device like bench.build_model does (same generator stream)
-    vsd = syn.vit_state(Hv, 4 * Hv, 24, image, seed=81, device=DEV, dtype=torch.bfloat16)
-    lsd = syn.llama_state(l["hidden"], l["inter"], l["layers"], ids.vocab, seed=82, device=DEV, dtype=torch.bfloat16)
-    tower = ClipVisionTower(vsd, heads=heads_v, device=DEV)
-    dec = LlamaDecoder(lsd, heads=l["heads"], max_positions=1024, device=DEV)
+    # bf16-representable weights (exact in fp16 too at these magnitudes? no: fp16 re-rounds them -- both sides of the
+    # comparison are built from the tensors the HIP model actually holds, see below), generated on the device
+    vsd = syn.vit_state(Hv, 4 * Hv, 24, image, seed=81, device=DEV, dtype=dt)
+    lsd = syn.llama_state(l["hidden"], l["inter"], l["layers"], ids.vocab, seed=82, device=DEV, dtype=dt)
+    tower = ClipVisionTower(vsd, heads=heads_v, device=DEV, dtype=dt)
+    dec = LlamaDecoder(lsd, heads=l["heads"], max_positions=1024, device=DEV, dtype=dt)
     model = SPILlavaLlamaModel(tower, dec, ids, embed_dims=Hv)
     orc = S.MLVLROIQueryOracle(embed_dims=Hv, P=P)
     spi_sd = S.synthetic_state(orc, 83)
@@ -317,8 +412,6 @@ def test_bench_model_full_depth_32_layers_vs_hf_fp32_on_the_gpu():
     dboxes = [b.to(DEV) for b in boxes]
     with torch.no_grad():
         out = lm(input_ids=prompt.to(DEV), images=img.to(DEV), bboxes=dboxes)
-        got_ids = lm.generate(input_ids=prompt.to(DEV), images=img.to(DEV), bboxes=dboxes, do_sample=False,
-                              max_new_tokens=n_new, return_new_tokens=True)
     model.check_status()
     logits = out.logits.float()
 
@@ -333,80 +426,64 @@ def test_bench_model_full_depth_32_layers_vs_hf_fp32_on_the_gpu():
     # post_layernorm acts on the pooled output only, which the path never reads (hidden_states are taken before it)
     assert not [k for k in missing.missing_keys if "position_ids" not in k and "post_layernorm" not in k] \
         and not missing.unexpected_keys, missing
-    lcfg = LlamaConfig(vocab_size=ids.vocab, hidden_size=l["hidden"], intermediate_size=l["inter"],
-                       num_hidden_layers=l["layers"], num_attention_heads=l["heads"], num_key_value_heads=l["heads"],
-                       rms_norm_eps=1e-6, max_position_embeddings=2048, attention_bias=False, tie_word_embeddings=False,
-                       rope_theta=10000.0, attn_implementation="eager")
-    with torch.device(DEV):
-        hf_l = LlamaForCausalLM(lcfg).float().eval()
-    r = hf_l.load_state_dict({k: v.float() for k, v in lsd.items()}, strict=True)
-    assert not r.missing_keys and not r.unexpected_keys
+    hf_l = _hf_llama_fp32(lsd, ids, l["layers"])
     with torch.no_grad():
         hs = hf_v(img.to(DEV), output_hidden_states=True).hidden_states
         assert len(hs) == 25
         img_feat, lv = T.select_spi_levels([h.cpu() for h in hs], -2, 4)       # spi_llava.py:58-82
-        spi = orc(lv, boxes, emulate=True)
+        spi = orc(lv, boxes, emulate=emulate)
         proj = img_feat @ pw.t() + pb
         emb = lsd["model.embed_tokens.weight"].float().cpu()[prompt]
         spliced = S.splice(prompt, emb, proj, spi, ids.im_start_token, ids.im_end_token, ids.bbox_token)
-        o = hf_l(inputs_embeds=spliced.to(DEV), use_cache=True)
-        want = o.logits.float()
-        # greedy loop on the HF side (generate(do_sample=False) with a KV cache)
-        want_ids, trace, past, last = [], [], o.past_key_values, o.logits[0, -1]
-        embed = hf_l.get_input_embeddings()
-        for _ in range(n_new):
-            trace.append(last.float().cpu())
-            nxt = int(last.argmax())
-            want_ids.append(nxt)
-            o = hf_l(inputs_embeds=embed(torch.tensor([[nxt]], device=DEV)), past_key_values=past, use_cache=True)
-            past, last = o.past_key_values, o.logits[0, -1]
+        want = hf_l(inputs_embeds=spliced.to(DEV)).logits.float()
     span = (want.max() - want.min()).item()
     e_abs = (logits - want).abs().max().item()
-    e_rel = relerr(logits, want)
     agree = (logits[0].argmax(-1) == want[0].argmax(-1)).float().mean().item()
-    print(f"bench model, 32 layers x 4096, T={T_PROMPT}: logits vs HF fp32 max |err| {e_abs:.4f} = {e_abs / span:.4f} of the "
-          f"logit range {span:.2f} ({e_rel:.4f} of max |logit|); per-position argmax agreement {agree:.4f}")
-    print(f"greedy ids  HIP: {got_ids}\n            HF : {want_ids}")
+    print(f"bench model [{dtype_name}], 32 layers x 4096, T={T_PROMPT}: logits vs HF fp32 max |err| {e_abs:.4f} = "
+          f"{e_abs / span:.4f} of the logit range {span:.2f}; per-position argmax agreement {agree:.4f}")
     assert logits.shape == want.shape == (1, T_PROMPT, ids.vocab)
-    assert e_abs < 4e-2 * span
+    assert e_abs < (4e-2 if dtype_name == "bf16" else 6e-3) * span
+    # greedy ids: the whole path's own prompt embeddings on the HIP side are what `generate` decodes from; the strict
+    # comparison runs the decoder on both sides from the SAME (reference-side) spliced embeddings
+    with torch.no_grad():
+        got_ids = lm.generate(input_ids=prompt.to(DEV), images=img.to(DEV), bboxes=dboxes, do_sample=False,
+                              max_new_tokens=n_new, return_new_tokens=True)
+    print(f"  generate() on the whole path : {got_ids}")
+    _, want_ids, want_trace, em_err = _greedy_parity(dec, hf_l, spliced, lsd, n_new, emulate, f"bench model [{dtype_name}]")
+    # and generate() of the WHOLE path (its own ViT / region-module / projector outputs as the prompt embeddings, which differ
+    # from the reference side's by those stages' rounding): identical to HF fp32's ids up to the first step whose fp32 gap
+    # between the two choices is below the storage type's own logit error at that step
     if got_ids != want_ids:
         k = next(i for i, (a, b) in enumerate(zip(got_ids, want_ids)) if a != b)
-        top2 = trace[k].topk(2).values
-        margin, sp = float(top2[0] - top2[1]), float(trace[k].max() - trace[k].min())
-        print(f"ids differ from HF fp32 at step {k}: HF top-2 margin {margin:.3e} of a logit range {sp:.2f}")
-        assert margin < 1e-2 * sp, f"greedy ids differ from HF fp32 at step {k} with a CLEAR margin {margin:.3e}"
+        gap = float(want_trace[k][want_ids[k]] - want_trace[k][got_ids[k]])
+        print(f"  whole-path generate() leaves HF fp32 at step {k}: fp32 gap between the two choices {gap:.3e}, the emulating "
+              f"oracle's own max |logit err| there {em_err[k]:.3e}")
+        assert 0 <= gap < em_err[k], "whole-path greedy ids differ from HF fp32 by more than the storage type's own error"
     else:
-        print(f"{n_new} greedy ids identical to HF LlamaForCausalLM fp32")
-    # and the exact-id claim of north_star against the oracle that rounds to bf16 at the pipeline's storage points
-    # (oracle/transformer_oracle.py, pinned to HF by tests/test_oracle_transformers.py), run here through torch's GPU
-    # kernels at the full depth, from the SAME spliced embeddings on both sides.  The comparison is teacher-forced: the
-    # oracle decodes greedily; this pipeline is fed the oracle's token at every step and must make the same choice at
-    # every step -- one early near tie cannot hide (or fake) the agreement of the later steps.  A random-init model has
-    # near-flat logits, so a step whose oracle top-2 margin is below 1 % of its logit range (the pipeline's own logit
-    # error against fp32 is ~1 %, printed above) may go either way; any other disagreement fails.
-    w = {k: v for k, v in hf_l.state_dict().items()}
+        print(f"  whole-path generate(): all {n_new} ids identical to HF fp32")
+
+
+@pytest.mark.parametrize("seed", [82, 182, 282])
+def test_fp16_decoder_full_depth_greedy_ids_three_seeds(seed):
+    """The serving dtype of the reference (fp16, app.py:74-98) at the benchmarked depth and length on three independent
+    weight / prompt draws: LLaMA-7B 32 x 4096, T = 767, ids by the strict criterion of _greedy_parity against HF
+    LlamaForCausalLM fp32: all 16 ids identical on every draw, teacher-forced and free-running.  Also asserts that fp16 buys
+    what it should: max |logit error| against fp32 below 0.4 % of the logit range (bf16: ~1 %)."""
+    dt = torch.float16
+    ids = syn.token_ids(32000)
+    l = syn.LLAMA_7B
+    lsd = syn.llama_state(l["hidden"], l["inter"], l["layers"], ids.vocab, seed=seed, device=DEV, dtype=dt)
+    dec = LlamaDecoder(lsd, heads=l["heads"], max_positions=1024, device=DEV, dtype=dt)
+    g = torch.Generator().manual_seed(seed + 1)
+    emb = torch.randn(1, T_PROMPT, l["hidden"], generator=g).to(dt).float()          # fp16-representable prompt embeddings
+    hf_l = _hf_llama_fp32(lsd, ids, l["layers"])
     with torch.no_grad():
-        sp_dev = spliced.to(DEV)
-        want_em, trace_em = T.greedy_decode(w, sp_dev, lambda t: embed(t.to(DEV)), heads=l["heads"], n_new=n_new, emulate=True)
-        got_free = dec.greedy(sp_dev.to(torch.bfloat16), n_new)
+        want = hf_l(inputs_embeds=emb.to(DEV)).logits.float()[0]
         dec.reset(1)
-        lg = dec.forward(sp_dev.to(torch.bfloat16), all_logits=False)
-        forced, ties = [], []
-        for sidx in range(n_new):
-            mine = int(lg.view(-1).argmax())
-            forced.append(mine)
-            if mine != want_em[sidx]:
-                tr = trace_em[sidx].float()
-                top2 = tr.topk(2).values
-                ties.append((sidx, float(top2[0] - top2[1]), float(tr.max() - tr.min()), float(tr[want_em[sidx]] - tr[mine])))
-            e = lsd["model.embed_tokens.weight"][want_em[sidx]].view(1, 1, -1)
-            lg = dec.forward(e, all_logits=False)
-    print(f"emulating oracle (32 layers, greedy)     : {want_em}\nHIP, teacher-forced with the oracle's ids: {forced}\n"
-          f"HIP, free-running                        : {got_free}")
-    for (sidx, margin, span, gap) in ties:
-        print(f"  step {sidx}: different choice; oracle top-2 margin {margin:.3e} = {margin / span:.4f} of its logit range "
-              f"{span:.2f}; the oracle's own logit gap between the two choices {gap:.3e}")
-        assert margin < 1e-2 * span and gap < 1e-2 * span, f"step {sidx}: ids differ from the emulating oracle with a CLEAR margin"
-    print(f"{n_new - len(ties)} of {n_new} teacher-forced choices identical to the bf16-emulating oracle"
-          + ("" if not ties else f"; {len(ties)} near tie(s), listed above"))
-    assert len(ties) <= 2
+        got = dec.forward(emb.to(DEV).to(dt), all_logits=True).float()[0]
+    span = (want.max() - want.min()).item()
+    e = (got - want).abs().max().item()
+    print(f"seed {seed}: fp16 decoder, all {T_PROMPT} positions: max |logit err| vs HF fp32 {e:.4f} = {e / span:.5f} of the range")
+    assert e < 4e-3 * span
+    n_flips = _greedy_parity(dec, hf_l, emb, lsd, 16, torch.float16, f"fp16 decoder, seed {seed}")[0]
+    assert n_flips == 0, "these three draws hold no fp32 tie below the fp16 error: all 16 ids must be identical"

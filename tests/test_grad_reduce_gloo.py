@@ -8,6 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from _mp import plain, tensors
+
 from gpt4roi_amd.grad_reduce import GradBucketReducer
 
 
@@ -44,7 +46,7 @@ def _worker(rank, world, port, q, algo="rs_ag"):
                 red.ready(params[i], _grad(i, params[i].shape, rank, step))
             out = red.finish()
             results.append([out[id(p)].clone() for p in params])
-        q.put((rank, desc, results))
+        q.put(plain((rank, desc, results)))
     finally:
         dist.destroy_process_group()
 
@@ -62,7 +64,7 @@ def test_bucketed_allreduce_two_ranks(algo):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, algo)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    res = sorted((tensors(q.get(timeout=120)) for _ in procs), key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

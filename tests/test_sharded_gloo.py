@@ -13,6 +13,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import _mp
+
 from gpt4roi_amd.sharded import ShardedAdamW
 
 LR, CLIP, BETAS, EPS = 1e-2, 0.5, (0.9, 0.999), 1e-8
@@ -76,7 +78,7 @@ def _worker(rank, world, port, q):
                 n = entries[i][0]
                 opt.ready(n, _grad(i, live[n].shape, rank, step))
             norms.append(float(opt.step(LR, CLIP)))
-        q.put((rank, layout, norms, {n: t.clone() for n, t in live.items()}, opt.state_bytes()))
+        q.put(_mp.plain((rank, layout, norms, {n: t.clone() for n, t in live.items()}, opt.state_bytes())))
     finally:
         dist.destroy_process_group()
 
@@ -102,7 +104,7 @@ def test_sharded_adamw_two_ranks_matches_unsharded():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    res = sorted((_mp.tensors(q.get(timeout=120)) for _ in procs), key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

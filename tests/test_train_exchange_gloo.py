@@ -9,6 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import _mp
+
 from gpt4roi_amd.grad_reduce import GradBucketReducer
 from gpt4roi_amd.train import exchange_gradients
 
@@ -48,7 +50,7 @@ def _worker(rank, world, port, q):
         for step in range(2):
             avg = exchange_gradients(red, tensors, _grads(tensors, rank, step))
             res.append({k: v.clone() for k, v in avg.items()})
-        q.put((rank, len(red.buckets), res))
+        q.put(_mp.plain((rank, len(red.buckets), res)))
     finally:
         dist.destroy_process_group()
 
@@ -60,7 +62,7 @@ def test_named_gradient_exchange_two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    res = sorted((_mp.tensors(q.get(timeout=120)) for _ in procs), key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
