@@ -366,12 +366,11 @@ int launch_bwd(const AttnBwdArgs& a, int B, hipStream_t stream) {
                      stream, a);
   G4R_CHECK_LAUNCH("attn_bwd_dq");
   constexpr int DKV_LDS = (2 * TB * D + 2 * D * T_LD) * 2 + 2 * TB * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static G4rPerDeviceOnce attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
     if (e != hipSuccess) return g4r_note_hip_error(e, "attn_bwd_dkv: hipFuncSetAttribute");
-    attr_set = true;
   }
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, NW>), dim3(g4r_ceil_div(a.Tk, NW * 32), a.H, B), dim3(NW * 64), DKV_LDS,
                      stream, a);

@@ -459,11 +459,10 @@ int launch_attn2(const Attn2Args& a, int B, hipStream_t st) {
   static_assert(LDS >= (NG - 1) * NWG * (D / 32 * 16 + 2) * 64 * 4 + NWG * 32 * (D * 2 + 16),
                 "merge area + O staging fit the tile buffers");
   auto kfn = flash_attn_fwd2_kernel<D, NWG, NG, PP>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static G4rPerDeviceOnce attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return g4r_note_hip_error(e, "flash_attn_fwd2: hipFuncSetAttribute");
-    attr_set = true;
   }
   dim3 grid(g4r_ceil_div(a.Tq, NWG * 32), a.H, B);
   hipLaunchKernelGGL(kfn, grid, dim3(NWG * NG * 64), LDS, st, a);

@@ -74,4 +74,18 @@ __device__ __forceinline__ float h16lo(uint32_t w) { return __uint_as_float(w <<
 __device__ __forceinline__ float h16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 #endif
 
+// hipFuncSetAttribute(hipFuncAttributeMaxDynamicSharedMemorySize) applies to the CURRENT device only: launchers remember it
+// per (kernel, device), not in one process-wide flag (a second GPU or a device reset would otherwise launch the
+// > 64 KB LDS kernels without it).  A benign race between host threads sets the attribute twice.
+struct G4rPerDeviceOnce {
+  bool done[64] = {};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
 static inline int g4r_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -701,7 +701,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
   // vector path: 4 consecutive columns per thread, 16-byte loads of every partial (the scalar loops below moved 4 bytes per
   // lane per load: 10 us average over the 89 reduce launches of a round-2 step).  Same summation order (s = 0, 1, ...) and
   // the same bias -> activation -> residual -> one rounding sequence: bit-identical to the scalar path.
-  if ((p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.act != 4 || (p.ldc & 1) == 0)) {
+  // (base pointers too: gemm() passes column-sliced views of C / residual / bias -- 16-byte loads of the bias and 8/16-byte
+  // accesses of C and the residual need the slice itself aligned, not only its leading dimension)
+  const bool ptrs_aligned = ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.residual & 7) == 0 && ((uintptr_t)p.bias & 15) == 0 &&
+                            ((uintptr_t)p.ws & 15) == 0;
+  if (ptrs_aligned && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.act != 4 || (p.ldc & 1) == 0)) {
     const int n4 = p.N >> 2;
     const long quads = (long)p.M * n4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < quads; i += (long)gridDim.x * 256) {
@@ -1837,12 +1841,11 @@ int launch_w4(GemmArgs& p, hipStream_t stream) {
   const size_t ring = 4 * (256 + 256) * 32 * 2, epi = 4 * (size_t)EpiLds<4>::WAVE_BYTES;
   const size_t lds = ring > epi ? ring : epi;
   auto kern = gemm_bf16_w4_kernel<AMODE>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static G4rPerDeviceOnce attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_w4: hipFuncSetAttribute");
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(256), lds, stream, p);
   G4R_CHECK_LAUNCH("gemm_bf16_w4");
@@ -1879,12 +1882,11 @@ int launch_pp32(GemmArgs& p, hipStream_t stream) {
   const size_t ring = 4 * (BM + BN) * 32 * 2, epi = 8 * (size_t)EpiLds<TN, ((TN == 2 && TM % 2 == 0) ? 64 : 32)>::WAVE_BYTES;
   const size_t lds = ring > epi ? ring : epi;
   auto kern = gemm_bf16_pp32_kernel<AMODE, PROBE, BM, BN, BUF, SCHED>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static G4rPerDeviceOnce attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_pp32: hipFuncSetAttribute");
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(512), lds, stream, p);
   G4R_CHECK_LAUNCH("gemm_bf16_pp32");
@@ -1912,12 +1914,11 @@ int launch_pp(GemmArgs& p, hipStream_t stream) {
   const size_t ring = 2 * (256 + 256) * 64 * 2, epi = 8 * (size_t)EpiLds<2>::WAVE_BYTES;
   const size_t lds = ring > epi ? ring : epi;
   auto kern = gemm_bf16_pp_kernel<AMODE, PROBE>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static G4rPerDeviceOnce attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_pp: hipFuncSetAttribute");
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(512), lds, stream, p);
   G4R_CHECK_LAUNCH("gemm_bf16_pp");
@@ -1945,12 +1946,11 @@ int launch_tile(GemmArgs& p, hipStream_t stream) {
   const size_t ring = (size_t)STAGES * (BM + BN) * BKT * 2, epi = (size_t)WM * WN * EpiLds<BN / WN / 32, 32>::WAVE_BYTES;
   const size_t lds = ring > epi ? ring : epi;
   auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, AMODE, GLDS, STAGES, BKT, STYLE>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static G4rPerDeviceOnce attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return g4r_note_hip_error(e, "gemm: hipFuncSetAttribute");
-    attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, p.splits);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
@@ -2036,6 +2036,16 @@ int g4r_gemm_bf16_nt_partials(const void* A, const void* W, float* workspace, in
   G4R_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0, "gemm_partials: K must be a positive multiple of 64");
   G4R_REQUIRE(A && W && workspace && splits_out, "gemm_partials: null pointer");
   G4R_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && splits >= 2, "gemm_partials: 16-byte rows, splits >= 2");
+  {
+    // the slices the tile will really cut (its K tile is 32 for the ring ping-pong / one-wave-per-SIMD tiles, 64 otherwise),
+    // checked BEFORE the launch: a tile that clamps to one slice would run its normal epilogue into `workspace`
+    const bool k32 = tile_cfg == 24 || tile_cfg == 25 || tile_cfg == 26 || tile_cfg == 27 || tile_cfg == 28 || tile_cfg == 30 ||
+                     tile_cfg == 31 || tile_cfg == 33;
+    const int nt = K / (k32 ? 32 : 64);
+    const int s = splits > nt ? nt : splits;
+    G4R_REQUIRE(s >= 1 && g4r_ceil_div(nt, g4r_ceil_div(nt, s)) >= 2,
+                "gemm_partials: the tile's K slices collapse to one (K too short for `splits`)");
+  }
   GemmArgs p = {};
   p.A = (const h16_t*)A; p.W = (const h16_t*)W; p.C = workspace; p.ws = workspace;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = N; p.ldr = 0;

@@ -226,12 +226,11 @@ extern "C" int g4r_sample_advance_f32(const float* logits, int N, float temperat
     return g4r_note_error(G4R_ERR_UNSUPPORTED, "sample_advance: top_p < 1 needs top_k in [1, 1024] (below the vocabulary size)");
   const int in_lds = (size_t)N * 4 <= 140 * 1024;       // + 15 KB of static LDS: within the 160 KB of a CU
   const size_t lds = in_lds ? (size_t)N * 4 : 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static G4rPerDeviceOnce attr_set;
+  if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_advance_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
     if (e != hipSuccess) return g4r_note_hip_error(e, "sample_advance: hipFuncSetAttribute");
-    attr_set = true;
   }
   hipLaunchKernelGGL(sample_advance_kernel, dim3(1), dim3(SNT), lds, (hipStream_t)stream, logits, N, in_lds,
                      1.0f / temperature, top_k, top_p, seed, tok, out_ids, step, pos, max_steps, u_out);

@@ -682,11 +682,18 @@ def fuse_shuffle_mlvl(maps, affs, lvl_list, out):
     dt = _h16(*maps)
     L = len(maps)
     B, _, _, C = maps[0].shape
+    # every level exactly once as a target, neighbours inside the pyramid, and `out` laid out for THESE maps: the merged launch
+    # writes all levels through one table, so a missing / duplicated target or a mismatched MlvlMaps would silently use level
+    # 0 as the neighbour or write out of bounds
+    assert sorted(t for t, _, _ in lvl_list) == list(range(L)), "fuse_shuffle_mlvl: lvl_list must name every level once"
+    assert len(affs) == L and out.B == B and out.C == C and len(out.sizes) == L
     top, down = [0] * L, [0] * L
     for tar, tp, dn in lvl_list:
+        assert 0 <= tp < L and 0 <= dn < L
         top[tar], down[tar] = tp, dn
-    for m in maps:
+    for l, m in enumerate(maps):
         assert m.is_contiguous() and m.size(0) == B and m.size(3) == C
+        assert out.sizes[l] == (m.size(1), m.size(2)), "fuse_shuffle_mlvl: `out` was built for other map sizes"
     has_aff = any(a is not None for a in affs)
     if has_aff:
         _f32(*[a for a in affs if a is not None])
