@@ -1299,6 +1299,18 @@ __device__ __forceinline__ void g4r_buffer_piece(const void* base, unsigned byte
 // group 1's read of it).  Prefetch distance 2 in the ring of 4: the pieces of tile k+2 overwrite the buffer of tile k-2,
 // whose last reads were two barriers ago for BOTH groups; tile k's pieces were waited for (counted vmcnt, leaving only
 // tile k+1's in flight) before barrier k by every wave.
+// Round 4 (schedules measured and removed again; tools/gemm_bench.cpp, 4096^3 / 8192^2 x 4096 / 3068 x {12288, 4096, 22016}
+// x 4096, profiles/r04_gemm_schedules.txt): the wave's four pieces BETWEEN its MFMAs instead of behind its fragment reads
+// (unstaggered: 1235 vs 1227 TF/s = equal; staggered over the group's waves through scalar branches: 1084); 3 + 1 and 2 + 2
+// splits of the pieces between the two phases (1190 / 1183 vs 1186 = equal); the fragment reads of tile i+1 pipelined into
+// the tail of the wave's own MFMA phase (second register set, 236 VGPRs) with the pieces opening the read phase (1120 vs
+// 1187: slower).  Every re-arrangement lands within 1 % or loses, because it only moves work between two phases whose SUM per
+// wave is fixed: ~260 cycles of fragment reads + ~270 of pieces + 512 of MFMAs + two barrier hand-offs per K tile.  The
+// ablations (dbg 21-26, profiles/r04_gemm_ablation.txt) put numbers on it: per K = 32 tile the 32 pieces + reads WITHOUT the
+// MFMAs take 0.66 us, the MFMAs + reads WITHOUT the pieces 0.61 us, both together 0.85 us; all 256 workgroups streaming the
+// SAME tile's operands (L2-resident) runs within 2 % of the real access pattern -- the limiter is the CU's own load /
+// issue budget, not L2 or HBM.  What would cut it is fewer operand bytes and fragment reads per MFMA (a bigger tile than
+// 256 x 256 needs one wave per SIMD with 384 accumulator registers), not another order of the same instructions.
 template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true, int SCHED = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   constexpr int NW = 8, NT = 512, BKT = 32, RING = 4;
@@ -1323,6 +1335,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   const int tile_m = p.n_fastest ? wg / p.tiles_n : wg % p.tiles_m;
   const int tile_n = p.n_fastest ? wg % p.tiles_n : wg / p.tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // tools only (ablations of the K loop; results are wrong by construction): dbg 21 = every workgroup streams the operands
+  // of tile (0, 0) -- an L2-resident 4 MB working set, so what remains is the CU's own load path; 22 = no pieces after the
+  // ring fill (MFMA + fragment reads only); 23 = no MFMAs (loads + fragment reads only); 24 = no fragment reads either
+  const int lm0 = p.dbg == 21 ? 0 : m0, ln0 = p.dbg == 21 ? 0 : n0;
   const int t_begin = split * p.tiles_per_split;
   int t_end = t_begin + p.tiles_per_split;
   const int nt_total = p.K / BKT;
@@ -1343,9 +1359,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int pslot = (j * NW + wave) * 64 + lane;
-    const int row = pslot / SPR, ps = pslot % SPR;
-    const int kslot = ps ^ ((row >> 2) & 3);
-    int gm = m0 + row;
+    // tools only, dbg 25 / 26: every piece reads 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B (half lines)
+    const bool full_lines = p.dbg == 25 || p.dbg == 26;
+    const int row = full_lines ? pslot / 8 : pslot / SPR, ps = full_lines ? pslot % 8 : pslot % SPR;
+    const int kslot = full_lines ? ps : ps ^ ((row >> 2) & 3);
+    int gm = lm0 + row;
     if (gm > p.M - 1) gm = p.M - 1;
     a_src[j] = p.A + (size_t)gm * p.lda + kslot * 8;
     a_voff[j] = (gm * p.lda + kslot * 8) * 2;
@@ -1385,9 +1403,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int pslot = (j * NW + wave) * 64 + lane;
-    const int row = pslot / SPR, ps = pslot % SPR;
-    const int kslot = ps ^ ((row >> 2) & 3);
-    int gn = n0 + row;
+    const bool full_lines = p.dbg == 25 || p.dbg == 26;
+    const int row = full_lines ? pslot / 8 : pslot / SPR, ps = full_lines ? pslot % 8 : pslot % SPR;
+    const int kslot = full_lines ? ps : ps ^ ((row >> 2) & 3);
+    int gn = ln0 + row;
     if (gn > p.N - 1) gn = p.N - 1;
     b_src[j] = p.W + (size_t)gn * p.ldw + kslot * 8;
     b_voff[j] = (gn * p.ldw + kslot * 8) * 2;
@@ -1406,6 +1425,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   auto tile_src = [&](int t) {
     TileSrc ts;
     ts.k0 = t * BKT;
+    if (p.dbg == 25 || p.dbg == 26) ts.k0 = ((t * 64) % (p.K - 63)) & ~63;
     ts.a_off = ts.k0;
     ts.dy = ts.dx = ts.tap = ts.shift = 0;
     ts.soff = ts.k0 * 2;
@@ -1570,11 +1590,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
       // fragments first, pieces after.  Alternating them inside the wave is much slower (2150-2220 vs 1490 cycles
       // per K tile, with the builtin AND with raw-ISA pieces the compiler cannot see): a ds_read behind an LDS-DMA
       // piece of the same wave waits for it in hardware.
-      ldchunk(buf, 0);
-      ldchunk(buf, 1);
-      ldchunk(buf, 2);
+      if (p.dbg != 24 && p.dbg != 25) {
+        ldchunk(buf, 0);
+        ldchunk(buf, 1);
+        ldchunk(buf, 2);
+      }
       G4R_PP32_STAMP(1);
-      if (i + RING - 1 < nt) {
+      if (i + RING - 1 < nt && p.dbg != 22) {
         stage(t_begin + i + RING - 1, (i + RING - 1) & (RING - 1));
         G4R_PP32_STAMP(2);
         // tile i+1's pieces (issued two read phases ago) have landed: all but the two youngest tiles' pieces are waited for
@@ -1586,7 +1608,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
       G4R_PP32_STAMP(3);
       G4R_PP_BARRIER();
       G4R_PP32_STAMP(4);
-      mma();
+      if (p.dbg != 23 && p.dbg != 24 && p.dbg != 25) mma();
       G4R_PP_BARRIER();
       G4R_PP32_STAMP(5);
     }

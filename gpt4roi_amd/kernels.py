@@ -218,6 +218,16 @@ def pick_tile(M, N, K=0):
     # CUs (LLaMA fused qkv 767x12288: 144 tiles, 92 us vs 108 us for 128x128) or >= 85 % of several, and the M
     # padding costs < 10 %.  768x22016 (258 tiles = one wave + 2) and the N = 4096 projections (48 tiles) stay on
     # the 128-wide tiles.
+    if M >= 1024 and K >= 2048 and K % 64 == 0:
+        # Several requests in one launch sequence (round 4: bench --batch 4 -> M = 3068).  The ring ping-pong tiles run one
+        # workgroup per CU, so a launch costs whole waves of 256 workgroups; a 192 x 256 wave takes 0.92 of a 256 x 256 wave
+        # (0.75 of the MFMAs, 0.875 of the operand bytes: the K loop is bound by the CU's load path, profiles/
+        # r04_gemm_ablation.txt).  M = 3068 (tools/gemm_bench.cpp, profiles/r04_gemm_batch4_tiles.txt): q|k|v 768 tiles of
+        # 192 x 256 = 3 waves 283 us vs 303 (256 x 256: 2.25 -> 3 waves) vs 350 (128 x 128); o_proj 256 tiles = ONE wave 99 us vs
+        # 105 / 132; down_proj 247 vs 252 / 345; gate|up 256 x 256 (4.03 waves, see wave_split) 521 vs 560; lm_head 868 vs 1088.
+        t24 = -(-M // 256) * -(-N // 256)
+        t28 = -(-M // 192) * -(-N // 256)
+        return 28 if -(-t28 // 256) * 0.92 < -(-t24 // 256) else 24
     t256 = -(-M // 256) * -(-N // 256)
     if K >= 1024 and K % 64 == 0 and (-(-M // 256) * 256) <= 1.1 * M:     # K = 1024: ViT at batch 8 (4616x3072x1024: 715 vs 552 TF/s)
         eff = t256 / (-(-t256 // 256) * 256)
@@ -399,14 +409,26 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=None, spl
     assert out.stride(1) == 1 and out.shape == (M, n_out)
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
-    if tile_cfg is None and splits == 1 and pick_tile(M, N, K) not in (24, 28):
+    thin_tail = False
+    if tile_cfg is None and splits == 1 and M >= 1024 and pick_tile(M, N, K) == 24 and out.dtype != torch.float32:
+        # several whole waves of 256 x 256 tiles plus a THIN last one (batch-4 gate|up 3068 x 22016: 1032 tiles = 4 waves + 8
+        # tiles): the last columns go to a second launch as K slices instead of costing a fifth wave
+        t256 = -(-M // 256) * -(-N // 256)
+        thin_tail = t256 > 256 and 0 < t256 % 256 <= 48
+    if tile_cfg is None and splits == 1 and (pick_tile(M, N, K) not in (24, 28) or thin_tail):
         n_main = wave_split(M, N, K)
         if n_main is not None:
             o_main = n_main // 2 if act == "swiglu" else n_main
             gemm(a, w[:n_main], bias[:n_main] if bias is not None else None,
                  residual[:, :n_main] if residual is not None else None, act, out[:, :o_main], tile_cfg=24)
-            gemm(a, w[n_main:], bias[n_main:] if bias is not None else None,
-                 residual[:, n_main:] if residual is not None else None, act, out[:, o_main:])
+            rem_tiles = -(-M // 256) * -(-(N - n_main) // 256)
+            if thin_tail and rem_tiles <= 64:
+                gemm(a, w[n_main:], bias[n_main:] if bias is not None else None,
+                     residual[:, n_main:] if residual is not None else None, act, out[:, o_main:], tile_cfg=24,
+                     splits=max(2, min(16, 256 // rem_tiles, K // 256)))
+            else:
+                gemm(a, w[n_main:], bias[n_main:] if bias is not None else None,
+                     residual[:, n_main:] if residual is not None else None, act, out[:, o_main:])
             return out
     if tile_cfg is None and splits == 1 and long_k_plan(M, N, K) is not None:
         # LLaMA down_proj 767x4096x11008 (48 tiles of 256x256): 5 K-slices on the one-wave-per-SIMD kernel, 100.2 us

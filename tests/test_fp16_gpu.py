@@ -165,13 +165,13 @@ def test_f16_region_module_vs_oracle_with_fp16_rounding_points():
 def test_f16_small_pipeline_prefill_decode_and_greedy_ids_vs_oracle():
     """ViT -> region module -> projector -> splice -> 3-layer decoder, all fp16: logits against the fp16-emulating oracles,
     then KV-cache decode (fused RMSNorm GEMV, split-key attention) -- greedy ids identical to the oracle's."""
-    C, P, Hd, heads, inter, L = 256, 8, 512, 4, 1408, 3
+    C, P, Hd, heads, inter, L = 512, 8, 512, 4, 1408, 3
     ids = syn.token_ids(990)
     vsd = syn.vit_state(C, 4 * C, 12, 14 * P, seed=3)
     lsd = syn.llama_state(Hd, inter, L, ids.vocab, seed=4)
     vsd = {k: v.to(H).float() for k, v in vsd.items()}
     lsd = {k: v.to(H).float() for k, v in lsd.items()}
-    tower = ClipVisionTower(vsd, heads=4, device=DEV, dtype=H)
+    tower = ClipVisionTower(vsd, heads=8, device=DEV, dtype=H)
     dec = LlamaDecoder(lsd, heads=heads, max_positions=256, device=DEV, dtype=H)
     model = SPILlavaLlamaModel(tower, dec, ids, embed_dims=C)
     orc = S.MLVLROIQueryOracle(embed_dims=C, P=P)
@@ -187,7 +187,7 @@ def test_f16_small_pipeline_prefill_decode_and_greedy_ids_vs_oracle():
         pw, pb = model.mm_projector.weight.detach().clone(), model.mm_projector.bias.detach().clone()
         emb_hip = model.embed_inputs(prompt.to(DEV), img.to(DEV), [b.to(DEV) for b in boxes])
         model.check_status()
-        hs = T.clip_vit_hidden_states(vsd, img, heads=4, emulate=torch.float16)
+        hs = T.clip_vit_hidden_states(vsd, img, heads=8, emulate=torch.float16)
         img_feat, lv = T.select_spi_levels(hs, -2, 4)
         spi = orc(lv, boxes, emulate=torch.float16)
         r = lambda t: t.to(H).float()
