@@ -227,7 +227,8 @@ def pick_tile(M, N, K=0):
         # 105 / 132; down_proj 247 vs 252 / 345; gate|up 256 x 256 (4.03 waves, see wave_split) 521 vs 560; lm_head 868 vs 1088.
         t24 = -(-M // 256) * -(-N // 256)
         t28 = -(-M // 192) * -(-N // 256)
-        return 28 if -(-t28 // 256) * 0.92 < -(-t24 // 256) else 24
+        if max(t24, t28) >= 192:                    # narrow outputs (ViT fc2 at batch 8: 100 tiles) stay on the smaller tiles below
+            return 28 if -(-t28 // 256) * 0.92 < -(-t24 // 256) else 24
     t256 = -(-M // 256) * -(-N // 256)
     if K >= 1024 and K % 64 == 0 and (-(-M // 256) * 256) <= 1.1 * M:     # K = 1024: ViT at batch 8 (4616x3072x1024: 715 vs 552 TF/s)
         eff = t256 / (-(-t256 // 256) * 256)
