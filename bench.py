@@ -4,12 +4,14 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1], the one the metric is quoted on): ONE 336x336 image, 32 RoIs,
-batch 1 per GPU: CLIP ViT-L/14 (23 of 24 blocks) -> 4-level pyramid + 5 fuse rounds -> multi-level
+Workload (BASELINE.json configs[1], the one the metric is quoted on): batch-1 requests of ONE 336x336 image with 32 RoIs
+each: CLIP ViT-L/14 (23 of 24 blocks) -> 4-level pyramid + 5 fuse rounds -> multi-level
 RoIAlign -> pconvs / flatten_linear / pos-embed / updims -> mm_projector -> splice + <bbox>
-injection -> LLaMA-7B prefill forward with logits for every position.  A "step" is one such
-image; inputs (image, boxes, token ids) and all weights are resident in HBM before the timed
-region.  Weights are seeded random tensors of the real shapes (no checkpoints in this
+injection -> LLaMA-7B prefill forward with logits for every position.  A "step" is ONE launch sequence over
+`--batch` such requests merged (continuous batching, default 4: the weights are streamed once for all of them and the
+LLaMA GEMMs get M = 4 x 767 rows, i.e. whole waves of tiles on the 256 CUs); `value` counts every request's 32 region
+tokens.  `--batch 1 --streams 1` is the strictly serial batch-1 latency, reported beside the headline as `single_request`.
+Inputs (images, boxes, token ids) and all weights are resident in HBM before the timed region.  Weights are seeded random tensors of the real shapes (no checkpoints in this
 environment).  Multi-GPU: the path shards by image with no data-path collective (inference
 replicas), so scaling is weak and `value` = all ranks' region tokens / max-rank time.
 
@@ -46,8 +48,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=2,
-                    help="independent batch-1 requests in flight per GPU, one HIP stream each (1 = strictly serial)")
-    ap.add_argument("--batch", type=int, default=1,
+                    help="independent launch sequences in flight per GPU, one HIP stream each (1 = strictly serial)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
+                    help="16-bit storage type of the whole path: bf16 (the reference's training dtype; the default) or fp16 (its "
+                         "serving dtype, app.py:74-98) -- same MFMA rate, same bytes")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (fp16, 224^2, single request)")
+    ap.add_argument("--batch", type=int, default=4,
                     help="batch-1 requests merged into ONE launch sequence per step (continuous batching: the weights are "
                          "streamed once for all of them); value counts every request's region tokens")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
@@ -61,20 +67,20 @@ def parse():
     return ap.parse_args()
 
 
-def build_model(args, device, seed):
+def build_model(args, device, seed, dtype=torch.bfloat16):
     from gpt4roi_amd import synthetic as syn
     from gpt4roi_amd.llama import LlamaDecoder
     from gpt4roi_amd.spi_llava import SPILlavaLlamaModel
     from gpt4roi_amd.vit import ClipVisionTower
     ids = syn.token_ids(32000)
-    bf = torch.bfloat16
+    bf = dtype
     v = syn.CLIP_L14
     vsd = syn.vit_state(v["hidden"], v["inter"], v["layers"], args.image_size, seed=seed, device=device, dtype=bf)
-    tower = ClipVisionTower(vsd, heads=v["heads"], device=device)
+    tower = ClipVisionTower(vsd, heads=v["heads"], device=device, dtype=bf)
     del vsd
     l = syn.LLAMA_7B
     lsd = syn.llama_state(l["hidden"], l["inter"], args.llama_layers, ids.vocab, seed=seed + 1, device=device, dtype=bf)
-    dec = LlamaDecoder(lsd, heads=l["heads"], max_positions=2048, device=device)
+    dec = LlamaDecoder(lsd, heads=l["heads"], max_positions=2048, device=device, dtype=bf)
     del lsd
     model = SPILlavaLlamaModel(tower, dec, ids, embed_dims=v["hidden"])
     model.spi_module.to(device)
@@ -86,15 +92,49 @@ def build_model(args, device, seed):
     return model, ids
 
 
-def make_inputs(args, ids, device, seed):
+def make_inputs(args, ids, device, seed, batch=None, image_size=None):
     from gpt4roi_amd import synthetic as syn
     g = torch.Generator().manual_seed(seed)
-    P = args.image_size // 14
-    B = max(1, args.batch)
-    image = torch.randn(B, 3, args.image_size, args.image_size, generator=g).to(device)
+    size = image_size or args.image_size
+    P = size // 14
+    B = max(1, args.batch if batch is None else batch)
+    image = torch.randn(B, 3, size, size, generator=g).to(device)
     boxes = [syn.boxes(args.rois, g).to(device) for _ in range(B)]
     prompt = torch.stack([syn.prompt_ids(ids, P, args.rois, g) for _ in range(B)]).to(device)
     return image, boxes, prompt
+
+
+def timed_replay(model, image, boxes, prompt, steps, warmup=2, streams=1):
+    """Seconds per launch sequence of `model` over (image, boxes, prompt), hipGraph replay on `streams` HIP streams
+    (one request context each), device-synchronised both sides.  Used by the extra legs (never by `value`)."""
+    size = image.size(-1)
+    ctxs = [model] + [model.clone_context() for _ in range(streams - 1)]
+    sts = [torch.cuda.Stream(device=image.device) for _ in ctxs]
+    reqs = [c.prepare_boxes(boxes, size) for c in ctxs]
+    graphs = []
+    for c, st, rq in zip(ctxs, sts, reqs):
+        with torch.cuda.stream(st):
+            c(input_ids=prompt, images=image, bboxes=rq)
+            c(input_ids=prompt, images=image, bboxes=rq)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            keep = c(input_ids=prompt, images=image, bboxes=rq)
+        graphs.append((g, keep))
+    torch.cuda.synchronize()
+
+    def run(n):
+        for i in range(n):
+            with torch.cuda.stream(sts[i % len(sts)]):
+                graphs[i % len(sts)][0].replay()
+    run(warmup * len(sts))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del graphs
+    return dt
 
 
 def cpu_baseline(args):
@@ -158,29 +198,40 @@ def cpu_baseline(args):
 
 
 def vit_roofline(model, args, device):
-    """CLIP ViT-L/14 alone (FLOPs_ViT(23 layers) / t_ViT / 2.5 PF) at batch 1 and at the batch the training
-    configs feed it (configs 3/4: B = 8/16), timed with HIP events on the launch stream."""
+    """CLIP ViT-L/14 alone (FLOPs_ViT(23 layers) / t_ViT / 2.5 PF) at batch 1, at the batch the headline merges
+    and at the batch the training configs feed it (configs 3/4: B = 8/16).  Timed the way the path runs it: ONE hipGraph
+    replay of the tower per forward, HIP events on the launch stream (the eager timing of round 3 charged the
+    tower ~1 ms of host launch gaps at batch 1)."""
     tower = model.vision_tower[0]
     S = (args.image_size // 14) ** 2 + 1
     C = tower.hidden
     per_layer = 24.0 * S * C * C + 4.0 * S * S * C                  # 8SC^2 (q,k,v,o) + 16SC^2 (MLP) + 4S^2C (attention)
     flops1 = len(tower.layers) * per_layer + 2.0 * (S - 1) * 588 * C
-    out = {}
-    for B in (1, 8):
+    out = {"timing": "hipGraph replay of the tower, HIP events on the launch stream"}
+    st = torch.cuda.Stream(device=device)
+    for B in sorted({1, max(1, args.batch), 8}):
         img = torch.randn(B, 3, args.image_size, args.image_size, device=device)
-        for _ in range(2):
-            tower.forward(img)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 5
-        e0.record()
-        for _ in range(n):
-            tower.forward(img)
-        e1.record()
+        with torch.cuda.stream(st):
+            for _ in range(2):
+                tower.forward(img)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            keep = tower.forward(img)
+        n = 8
+        with torch.cuda.stream(st):
+            g.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                g.replay()
+            e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
+        del g, keep
         tf = B * flops1 / (ms * 1e-3) / 1e12
-        out[f"batch{B}"] = {"ms": round(ms, 3), "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(tf / PEAK_BF16_TFLOPS, 4), "flops": int(B * flops1)}
+        out[f"batch{B}"] = {"ms": round(ms, 3), "ms_per_image": round(ms / B, 3), "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "flops": int(B * flops1)}
     return out
 
 
@@ -246,7 +297,8 @@ def main():
             dist.init_process_group(backend)
     from gpt4roi_amd import kernels as K
 
-    model, ids = build_model(args, device, seed=100 + rank)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    model, ids = build_model(args, device, seed=100 + rank, dtype=dtype)
     image, boxes, prompt = make_inputs(args, ids, device, seed=rank)
 
     from gpt4roi_amd import replicas
@@ -324,7 +376,14 @@ def main():
                        "TFLOP/s": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 1) if a["flops"] else None,
                        "GB/s": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)}
                    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
-        dom, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        # dominant kernel BY DEVICE SYMBOL (the labels split one symbol -- the 192 x 256 ring kernel with and
+        # without K slices -- into two rows and so reported the conv): "+splitk" launches run the same kernel symbol
+        by_sym = {}
+        for k, a_ in agg.items():
+            b_ = by_sym.setdefault(k.replace("+splitk", ""), dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            for f_ in ("calls", "ms", "flops", "bytes"):
+                b_[f_] += a_[f_]
+        dom, a = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
         ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
@@ -380,6 +439,19 @@ def main():
                                 "algorithmic_bytes_per_launch": int(cv["bytes"] / cv["calls"]),
                                 "traffic": (crec["hbm_read_bytes"] + crec.get("hbm_write_bytes", 0)) if "hbm_read_bytes" in crec else None,
                                 "pmc": ({"mfma_util": crec["mfma_util"], "clock_GHz": crec["clock_GHz"]} if crec.get("mfma_util") is not None else None)}
+        # per-family fractions of the MFMA peak over the whole instrumented step (all launches of the family)
+        fams = {"gemm": lambda t: t.startswith("gemm_bf16_nt") or t.startswith("gemv") or t == "small_linear",
+                "conv": lambda t: t.startswith("conv3x3_igemm"), "attention": lambda t: t.startswith("flash_attn")}
+        roofline["families"] = {}
+        for fname, pred in fams.items():
+            ms_ = sum(a_["ms"] for t, a_ in agg.items() if pred(t))
+            fl_ = sum(a_["flops"] for t, a_ in agg.items() if pred(t))
+            if ms_ > 0:
+                tf_ = fl_ / (ms_ * 1e-3) / 1e12
+                roofline["families"][fname] = {"ms_per_step": round(ms_, 3), "ms_per_request": round(ms_ / max(1, args.batch), 3),
+                                               "share_of_step": round(ms_ / tot, 3), "achieved": round(tf_, 1), "unit": "TFLOP/s",
+                                               "frac": round(tf_ / PEAK_BF16_TFLOPS, 4),
+                                               "launches": sum(a_["calls"] for t, a_ in agg.items() if pred(t))}
         ra = agg.get("roi_align_mlvl_nhwc")
         if ra:
             gbs = ra["bytes"] / (ra["ms"] * 1e-3) / 1e9
@@ -444,9 +516,29 @@ def main():
             vit = {"error": repr(ex)}
         if roofline is not None:
             roofline["vit"] = vit
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        # extra legs, never part of `value`: (a) ONE batch-1 request, strictly serial (the per-request latency of configs[1]);
+        # (b) the reference-native 224^2 resolution (its RoI extractor asserts a 16 x 16 grid, layers.py:289-291), same merge;
+        # (c) the same merged launch sequence in the reference's SERVING dtype (fp16, app.py:74-98) when the headline is bf16
+        extras = {}
+        try:
+            i1, b1, p1 = make_inputs(args, ids, device, seed=9000, batch=1)
+            t1 = timed_replay(model, i1, b1, p1, steps=max(4, args.steps))
+            extras["single_request"] = {"ms": round(1e3 * t1, 3), "region_tokens_per_s": round(args.rois / t1, 1),
+                                        "what": "one batch-1 request, one stream, hipGraph replay (latency of configs[1])"}
+            i2, b2, p2 = make_inputs(args, ids, device, seed=9001, image_size=224)
+            t2 = timed_replay(model, i2, b2, p2, steps=max(4, args.steps // 2), streams=max(1, args.streams))
+            extras["native_224"] = {"ms_per_step": round(1e3 * t2, 3), "requests_per_step": int(i2.size(0)),
+                                    "region_tokens_per_s": round(args.rois * i2.size(0) / t2, 1), "prompt_tokens": int(p2.size(1)),
+                                    "what": "the reference-native 224^2 image (P = 16), 32 RoIs, same merge and streams; "
+                                            "position table of the 336^2 tower (first 257 rows), timing only"}
+            del i1, b1, p1, i2, b2, p2
+        except Exception as ex:
+            extras["error"] = repr(ex)
     train = None
     n_ctx, graph_ok = len(ctxs), all(g is not None for g in graphs)
-    if args.train_steps > 0:
+    if args.train_steps > 0 and args.dtype == "bf16":          # the reference trains in bf16 (train_stage1.sh:19)
         try:
             del graphs, ctxs, reqs                       # release the captured inference pools before training
             graph_error = last.get("graph_error")
@@ -458,6 +550,20 @@ def main():
             train = {"error": repr(ex)}                              # end and exits 0 (no collective follows this leg); a
             #                                                          rank left waiting in one gets the group's timeout here
 
+    if rank == 0 and extras is not None and args.dtype == "bf16" and world == 1:
+        try:
+            del model
+            torch.cuda.empty_cache()
+            m16, ids16 = build_model(args, device, seed=100 + rank, dtype=torch.float16)
+            i3, b3, p3 = make_inputs(args, ids16, device, seed=rank)
+            t3 = timed_replay(m16, i3, b3, p3, steps=max(4, args.steps // 2), streams=max(1, args.streams))
+            extras["fp16"] = {"ms_per_step": round(1e3 * t3, 3), "region_tokens_per_s": round(args.rois * i3.size(0) / t3, 1),
+                              "what": "the headline configuration with fp16 storage (the reference's serving dtype, app.py:74-98): "
+                                      "the -DG4R_F16 instantiation of the same kernels"}
+            del m16, i3, b3, p3
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            extras["fp16"] = {"error": repr(ex)}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -472,21 +578,21 @@ def main():
             "metric": "region-tokens/sec (336^2 img, 32 RoIs, CLIP ViT-L/14 + region module + LLaMA-7B fwd)",
             "value": round(total_regions / dt, 2), "unit": "region-tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "value_per_gpu": round(total_regions / dt / world, 2),
             "in_flight_requests_per_gpu": n_ctx, "hipMalloc_calls_in_timed_region": device_allocs_in_timed_region,
             "hipgraph": graph_ok, "hipgraph_error": last.get("graph_error"),
             "requests_per_step": args.batch,
             "single_stream": {"ms_per_image": round(1e3 * dt_serial / args.steps / args.batch, 3),
                               "region_tokens_per_s_per_gpu": round(args.rois * args.batch * args.steps / dt_serial, 2)},
-            "config": {"workload": f"configs[1]: 1x{args.image_size}^2 image, {args.rois} RoIs, batch 1 per GPU, "
-                                   f"ViT-L/14(23 blocks) + SPI(P={P}) + LLaMA-7B({args.llama_layers} layers) prefill "
-                                   f"T={prompt.size(1)} with full logits",
+            "config": {"workload": f"configs[1]: batch-1 requests of 1x{args.image_size}^2 image + {args.rois} RoIs, {args.batch} of them "
+                                   f"merged per launch sequence: ViT-L/14(23 blocks) + SPI(P={P}) + LLaMA-7B({args.llama_layers} "
+                                   f"layers) prefill T={prompt.size(1)} per request with full logits",
                        "image_size": args.image_size, "rois_per_image": args.rois, "prompt_tokens": int(prompt.size(1)),
-                       "parallelism": f"replicas x{world} (no data-path collective); {n_ctx} batch-1 requests in "
-                                      f"flight per GPU on separate HIP streams",
+                       "parallelism": f"replicas x{world} (no data-path collective); {n_ctx} launch sequences of {args.batch} "
+                                      f"requests in flight per GPU on separate HIP streams",
                        "valid": args.llama_layers == 32 and args.image_size == 336 and args.rois == 32},
-            "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "train": train, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "train": train, "extras": extras, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
