@@ -1306,6 +1306,15 @@ __device__ __forceinline__ void g4r_buffer_piece(const void* base, unsigned byte
 // the tail of the wave's own MFMA phase (second register set, 236 VGPRs) with the pieces opening the read phase (1120 vs
 // 1187: slower).  Every re-arrangement lands within 1 % or loses, because it only moves work between two phases whose SUM per
 // wave is fixed: ~260 cycles of fragment reads + ~270 of pieces + 512 of MFMAs + two barrier hand-offs per K tile.  The
+// Two further STRUCTURES were written, are correct (tools/gemm_bench.cpp: dense, conv, K slices, ragged shapes) and measure
+// the same again -- their text is kept in tools/probe/gemm_pp64_q8_experiment.hip.txt: (a) this kernel's phases over operands
+// staged in K = 64 super-tiles, so that every LDS-DMA piece is 8 rows x 128 B = WHOLE cache lines (a CU streams those at 33
+// B/clk against 24 for the 16 rows x 64 B pieces that K = 32 tiles force: tools/probe/loadpath_probe.hip) -- 4096^3 1164 vs
+// 1146 TF/s, 3068 x 12288 x 4096 1081 vs 1067, 8192^2 1046 vs 1130, conv 192^2 990 vs 1041; (b) the guide's "8-phase" form
+// (all eight waves in one role, quadrant phases, K 64 double buffer): 1186 vs 1176 / 1246 vs 1230 at K = 8192 / 1137 vs 1181.
+// What all of them share is the CHIP: on ZERO-filled operands this kernel runs 4096^3 at 1537 TF/s (the guide's reference
+// template: 1563), on uniform or normal random operands at 1090-1230 on the same box -- the clock under the power cap, not the
+// instruction schedule, sets the random-data number (profiles/r04_gemm_dvfs.txt; MFMA-only ablation: 1728 zeros / 1412 random).
 // ablations (dbg 21-26, profiles/r04_gemm_ablation.txt) put numbers on it: per K = 32 tile the 32 pieces + reads WITHOUT the
 // MFMAs take 0.66 us, the MFMAs + reads WITHOUT the pieces 0.61 us, both together 0.85 us; all 256 workgroups streaming the
 // SAME tile's operands (L2-resident) runs within 2 % of the real access pattern -- the limiter is the CU's own load /
