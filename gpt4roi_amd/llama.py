@@ -55,6 +55,11 @@ class LlamaDecoder:
         self.max_positions = max_positions
         self.device = device
         self.train_weights = False
+        # full sharding (gpt4roi_amd/fsdp.py): `unit_hook(phase, li)` is called around every decoder layer of the training
+        # forward ("fwd_pre" / "fwd_post") and backward ("bwd_pre" / "bwd_post"); with `lazy_transposes` the W^T buffers of a
+        # layer are made by that hook when the layer's weights are gathered, not for all layers up front
+        self.unit_hook = None
+        self.lazy_transposes = False
         self._alloc_cache(max_batch)
 
     def _alloc_cache(self, batch):
@@ -133,10 +138,31 @@ class LlamaDecoder:
         self.refresh_transposes()
 
     def refresh_transposes(self):
-        for L in self.layers:
-            for nm in ("wqkv", "wo", "wgu", "wd"):
-                L[nm + "_t"] = K.transpose(L[nm])
-        self.lm_head_t = K.transpose(self.lm_head, self.v_pad)
+        if not self.lazy_transposes:
+            for L in self.layers:
+                for nm in ("wqkv", "wo", "wgu", "wd"):
+                    L[nm + "_t"] = K.transpose(L[nm])
+        if self.lm_head is not None:
+            self.lm_head_t = K.transpose(self.lm_head, self.v_pad)
+
+    def layer_transposes(self, li, scratch=None):
+        """W^T of ONE layer (the input-gradient GEMMs of its backward), into `scratch` (name -> buffer) when given."""
+        L = self.layers[li]
+        for nm in ("wqkv", "wo", "wgu", "wd"):
+            L[nm + "_t"] = K.transpose(L[nm], out=None if scratch is None else scratch.get(nm))
+
+    def set_tensor(self, name, tensor):
+        """Point the kernels at `tensor` for `name` (a key of trainable_tensors()); None = released (a sharded unit whose
+        parameters are not gathered: touching it then fails loudly instead of reading stale weights)."""
+        if name == "embed_tokens":
+            self.embed = tensor
+        elif name == "norm":
+            self.norm = tensor
+        elif name == "lm_head":
+            self.lm_head = tensor
+        else:
+            li, nm = name.split(".")
+            self.layers[int(li)][nm] = tensor
 
     def trainable_tensors(self):
         """name -> tensor the kernels read, for stage-2 training (kernel layouts: fused q|k|v rows, interleaved
@@ -182,6 +208,8 @@ class LlamaDecoder:
 
     def _layer_forward_train(self, li, x, B, T):
         """One decoder layer of `forward_train`: x [B*T, C] -> (x_out, everything its backward reads)."""
+        if self.unit_hook is not None:
+            self.unit_hook("fwd_pre", li)
         L = self.layers[li]
         C, H, D = self.hidden, self.heads, self.head_dim
         h = K.rmsnorm(x, L['n1'], self.eps)
@@ -201,6 +229,8 @@ class LlamaDecoder:
         rec = dict(x=x, q=q, a=a, lse=lse, x1=x1, gu=gu)
         if self.train_weights:
             rec.update(h=h, h2=h2, f=f)
+        if self.unit_hook is not None:
+            self.unit_hook("fwd_post", li)
         return x2, rec
 
     def forward_train(self, inputs_embeds, checkpoint=False):
@@ -248,9 +278,13 @@ class LlamaDecoder:
         if tw:
             emit("lm_head", "norm")
         for li in range(len(self.layers) - 1, -1, -1):
+            if self.unit_hook is not None:
+                self.unit_hook("bwd_pre", li)
             L, S = self.layers[li], ctx["saved"][li]
             if ctx.get("checkpoint"):
+                hook, self.unit_hook = self.unit_hook, None               # (the recompute runs inside this layer's gather)
                 _, S = self._layer_forward_train(li, S['x'], B, T)        # recompute (also re-fills this layer's K/V)
+                self.unit_hook = hook
             df = K.gemm(dx, L['wd_t'])
             dgu = K.swiglu_il_bwd(S['gu'], df)
             dh2 = K.gemm(dgu, L['wgu_t'])
@@ -273,6 +307,8 @@ class LlamaDecoder:
             dx = K.rmsnorm_bwd(S['x'], L['n1'], dh, dres=dx1, dgamma=grads.get(f"{li}.n1"), eps=self.eps)
             if tw:
                 emit(f"{li}.n2", f"{li}.n1", f"{li}.wd", f"{li}.wgu", f"{li}.wo", f"{li}.wqkv")
+            if self.unit_hook is not None:
+                self.unit_hook("bwd_post", li)
         self.grads = grads
         return dx
 

@@ -20,6 +20,7 @@ import torch
 import torch.distributed as dist
 
 from . import kernels as K
+from .fsdp import FullShardManager
 from .sharded import ShardedAdamW
 from .grad_reduce import GradBucketReducer
 from .layers import PreparedBoxes
@@ -310,3 +311,107 @@ class ShardedFullTrainer(FullTrainer):
         self.sharded.load_masters()                         # live bf16 / fp32 parameters <- restored masters, all ranks
         self.model.prepare()
         self.model.llama.refresh_transposes()
+
+
+class FSDPFullTrainer(FullTrainer):
+    """Stage 2 with parameters, gradients and optimizer state fully sharded per LlamaDecoderLayer (gpt4roi_amd/fsdp.py) --
+    what `--fsdp "full_shard auto_wrap" --fsdp_transformer_layer_cls_to_wrap LlamaDecoderLayer` does in the reference's own
+    launch script (train_stage2.sh:51-52).  Units, as FSDP's auto-wrap forms them: unit 1 + li = decoder layer li (wqkv, wo,
+    wgu, wd, n1, n2); unit 0 = the root, everything outside the layers (region module, projector, embedding table, final
+    norm, lm_head), which stays gathered for the whole step as FSDP's root module does.  The forward gathers layer li+1 on the
+    communication stream while layer li computes and releases li afterwards (reshard after forward); the backward gathers
+    again in reverse, makes the layer's W^T buffers from the gathered weights (four transposes into reused scratch), and
+    reduce-scatters the layer's fp32 gradients as soon as its six tensors exist.  Per rank and for the 7 B decoder: 13.5 / w GB
+    of bf16 shards + 81 / w GB of master and moments + 27 / w GB of gradient slices, plus ~1.6 GB of transient pool, against
+    13.5 + 81 + 27 GB unsharded."""
+
+    def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
+                 prefetch=1, update_fn=None):
+        model.llama.lazy_transposes = True                    # no W^T for all layers up front: made per gathered layer
+        RegionTrainer.__init__(self, model, lr, betas, eps, weight_decay, max_grad_norm, train_projector=True, group=group,
+                               _build_reducer=False)
+        self.opt = None
+        self.reducer = None
+        dec = model.llama
+        dec.prepare_training(train_weights=True)
+        live = dec.trainable_tensors()
+        root = [(k, p.data) for k, p in self.params.items()] + [(f"llama.{k}", live[k]) for k in ("embed_tokens", "norm", "lm_head")]
+        units = [root]
+        for li in range(len(dec.layers)):
+            units.append([(f"llama.{li}.{nm}", live[f"{li}.{nm}"]) for nm in ("wqkv", "wo", "wgu", "wd", "n1", "n2")])
+        self._scratch = None                                  # W^T buffers of the layer in the backward, allocated once
+        self._empty = torch.empty(0, device=dec.device)
+
+        def rebind(name, tensor):
+            if name.startswith("llama."):
+                dec.set_tensor(name[len("llama."):], tensor)
+            else:
+                self.params[name].data = tensor if tensor is not None else self._empty
+
+        self.fsdp = FullShardManager(units, rebind, group=group, betas=betas, eps=eps, weight_decay=weight_decay,
+                                     prefetch=prefetch, update_fn=update_fn)
+        self.world = self.fsdp.world
+        for L in dec.layers:                                  # stale W^T of the unsharded construction
+            for nm in ("wqkv", "wo", "wgu", "wd"):
+                L.pop(nm + "_t", None)
+        dec.lm_head_t = None
+        dec.unit_hook = self._unit_hook
+        torch.cuda.empty_cache() if dec.embed is None and torch.cuda.is_available() else None
+
+    def _unit_hook(self, phase, li):
+        f, dec = self.fsdp, self.model.llama
+        if phase == "fwd_pre":
+            f.use(1 + li)
+        elif phase == "fwd_post":
+            f.release(1 + li)
+        elif phase == "bwd_pre":
+            f.use(1 + li)
+            if self._scratch is None:
+                L = dec.layers[li]
+                self._scratch = {nm: torch.empty((L[nm].size(1), L[nm].size(0)), dtype=L[nm].dtype, device=L[nm].device)
+                                 for nm in ("wqkv", "wo", "wgu", "wd")}
+            dec.layer_transposes(li, self._scratch)
+        else:
+            for nm in ("wqkv", "wo", "wgu", "wd"):
+                dec.layers[li].pop(nm + "_t", None)
+            f.release(1 + li)
+
+    @torch.no_grad()
+    def loss_and_grads(self, input_ids, images, bboxes, labels, exchange=True):
+        m, f = self.model, self.fsdp
+        dec = m.llama
+        f.begin_step()
+        f.direction(+1, root=0)
+        f.use(0)                                              # the root unit: region module, projector, embed, norm, lm_head
+        dec.refresh_transposes()                              # lazy: only lm_head^T, from the gathered lm_head
+        logits, ctx = m.forward_train(input_ids, images, bboxes)
+        loss, dlogits = dec.loss_and_dlogits(logits, labels)
+        f.direction(-1, root=0)
+        grads = m.backward(ctx, dlogits, train_projector=True, on_grad=f.grad_ready)
+        self._d_emb = m._d_emb
+        self._last_input_ids = input_ids
+        self._extra_grads(grads, f.grad_ready)
+        dec.grads = {}
+        dec.lm_head_t = None
+        f.release(0)
+        return loss, None
+
+    @torch.no_grad()
+    def apply(self, grads=None, lr=None, exchanged=True):
+        self.steps += 1
+        total_sq = self.fsdp.step(self.lr if lr is None else lr, self.max_grad_norm)
+        self.last_grad_norm = total_sq.sqrt() if total_sq is not None else None
+
+    def step(self, input_ids, images, bboxes, labels, lr=None):
+        loss, _ = self.loss_and_grads(input_ids, images, bboxes, labels)
+        self.apply(None, lr)
+        return loss
+
+    def full_state_dict(self):
+        """name -> full tensor (gathers unit by unit and clones: for checkpoints and tests)."""
+        out = {}
+        for ui in range(len(self.fsdp.units)):
+            for n, v in self.fsdp.full_state(ui).items():
+                out[n] = v.detach().clone()
+            self.fsdp.release(ui)
+        return out

@@ -668,6 +668,52 @@ def test_sharded_stage2_trainer_equals_unsharded_on_one_rank():
     assert tb.steps == 3 and len(sd["buckets"]) == len(tb.sharded.buckets)
 
 
+def test_fsdp_stage2_trainer_equals_unsharded_on_one_rank():
+    """train.FSDPFullTrainer (gpt4roi_amd/fsdp.py: parameters + gradients + optimizer state sharded per decoder layer, the
+    strategy of train_stage2.sh:51-52) at world size 1: the same losses and weights as FullTrainer over three steps -- the
+    per-layer gather / release around the forward and the backward (the live tensors are views of pool buffers only while
+    their layer runs, None otherwise), the per-layer W^T scratch, the transient full-gradient buffers and their hand-off to
+    the owned slices, the fused clip + AdamW on the slices.  The two-rank collectives run over gloo in tests/test_fsdp_gloo.py."""
+    from gpt4roi_amd.train import FSDPFullTrainer, FullTrainer
+    lr = 5e-5
+    ma, args = _tiny_stage2()
+    mb, _ = _tiny_stage2()
+    ta = FullTrainer(ma, lr=lr, max_grad_norm=1.0)
+    tb = FSDPFullTrainer(mb, lr=lr, max_grad_norm=1.0)
+    n_layers = len(mb.llama.layers)
+    assert len(tb.fsdp.units) == 1 + n_layers
+    # nothing but the shards persists: the live tensors are released
+    assert mb.llama.layers[0]["wqkv"] is None and mb.llama.lm_head is None and mb.mm_projector.weight.numel() == 0
+    la, lb = [], []
+    for _ in range(3):
+        la.append(ta.step(*args).item())
+        lb.append(tb.step(*args).item())
+        assert mb.llama.layers[0]["wo"] is None and "wo_t" not in mb.llama.layers[0]          # released again after the step
+    own, full, transient = tb.fsdp.memory()
+    print("losses unsharded:", la, "fsdp:", lb, "grad norms:", ta.last_grad_norm.item(), tb.last_grad_norm.item(),
+          "persistent bytes", own, "peak transient pool bytes", transient)
+    assert own == full                                              # one rank owns every slice
+    # the pool never held more than the root + (prefetch + 1) layers of parameters + one unit of gradients
+    per_layer = sum(f.padded * 2 for f in tb.fsdp.units[1]["flats"] if f.dtype == torch.bfloat16) + \
+        sum(f.padded * 4 for f in tb.fsdp.units[1]["flats"] if f.dtype == torch.float32)
+    root = sum(f.padded * (2 if f.dtype == torch.bfloat16 else 4) for f in tb.fsdp.units[0]["flats"])
+    root_g = sum(f.padded * 4 for f in tb.fsdp.units[0]["flats"])
+    assert transient <= root + root_g + 2 * per_layer + 2 * per_layer * 2 + 4096, (transient, root, per_layer)
+    for a, b in zip(la, lb):
+        assert abs(a - b) < 2e-3 * abs(a)
+    assert la[-1] < la[0]
+    assert abs(ta.last_grad_norm.item() - tb.last_grad_norm.item()) < 1e-2 * ta.last_grad_norm.item()
+    full_b = tb.full_state_dict()
+    live_a = ma.llama.trainable_tensors()
+    for k, va in live_a.items():
+        vb = full_b[f"llama.{k}"]
+        d = (va.float() - vb.float()).abs().max().item()
+        assert d <= 2 ** -7 * va.float().abs().max().item() + 1e-6, (k, d)
+    for k, pa in ma.spi_module.named_parameters():
+        d = (pa - full_b[f"spi_module.{k}"]).abs()
+        assert d.max().item() <= 2 * 3 * lr and d.mean().item() <= 0.05 * 3 * lr, k
+
+
 def test_sharded_stage2_trainer_steps_on_a_region_less_batch():
     """The same region-less batch through ShardedFullTrainer: every bucket's reduce-scatter must be fed -- a rank
     that reported no `spi_module.*` gradient would raise in `_wait()` while the other ranks block in the collective.  The step
