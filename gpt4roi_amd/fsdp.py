@@ -105,14 +105,20 @@ class FullShardManager:
     # ---- pool of transient full buffers -----------------------------------------------------------------------------------
     def _take(self, dtype, n):
         free = self._pool.setdefault((dtype, n), [])
-        buf = free.pop() if free else torch.empty(n, dtype=dtype, device=self.device)
+        if free:
+            buf, busy = free.pop()
+            if busy is not None:                                  # its last reader ran on the OTHER stream: order behind it
+                torch.cuda.current_stream(self.device).wait_event(busy)
+        else:
+            buf = torch.empty(n, dtype=dtype, device=self.device)
         self._live_transient += buf.numel() * buf.element_size()
         self.peak_transient = max(self.peak_transient, self._live_transient)
         return buf
 
-    def _give(self, buf):
+    def _give(self, buf, busy=None):
+        """Back to the pool; `busy` = event after which the buffer may be overwritten (a collective still reading it)."""
         self._live_transient -= buf.numel() * buf.element_size()
-        self._pool[(buf.dtype, buf.numel())].append(buf)
+        self._pool[(buf.dtype, buf.numel())].append((buf, busy))
 
     def _on_comm(self, fn):
         """Run fn on the communication stream behind everything the compute stream has issued; returns the event to wait on."""
@@ -169,9 +175,7 @@ class FullShardManager:
         for f in u["flats"]:
             for n, _ in f.entries:
                 self.rebind(n, None)
-            if self.comm_stream is not None:
-                f.full.record_stream(torch.cuda.current_stream(self.device))
-            self._give(f.full)
+            self._give(f.full)              # (the next gather into it is ordered behind this stream's work by _on_comm)
             f.full = None
         u["gathered"] = False
 
@@ -216,9 +220,7 @@ class FullShardManager:
                     f.grad_shard.copy_(f.gfull[f.lo:f.lo + f.shard])
         u["gevent"] = self._on_comm(run)
         for f in flats:
-            if self.comm_stream is not None:
-                f.gfull.record_stream(self.comm_stream)
-            self._give(f.gfull)
+            self._give(f.gfull, busy=u["gevent"])                 # the reduce-scatter reads it on the communication stream
             f.gfull = None
 
     # ---- update -------------------------------------------------------------------------------------------------------------------

@@ -383,6 +383,9 @@ class FSDPFullTrainer(FullTrainer):
         f.begin_step()
         f.direction(+1, root=0)
         f.use(0)                                              # the root unit: region module, projector, embed, norm, lm_head
+        m.prepare()                                           # kernel-ready bf16 copies of the region module / projector from
+        #                                                       the gathered fp32 parameters (the pool buffer may be the same
+        #                                                       address as last step: the parameter stamp cannot tell)
         dec.refresh_transposes()                              # lazy: only lm_head^T, from the gathered lm_head
         logits, ctx = m.forward_train(input_ids, images, bboxes)
         loss, dlogits = dec.loss_and_dlogits(logits, labels)
