@@ -8,8 +8,9 @@ Workload (BASELINE.json configs[1], the one the metric is quoted on): batch-1 re
 each: CLIP ViT-L/14 (23 of 24 blocks) -> 4-level pyramid + 5 fuse rounds -> multi-level
 RoIAlign -> pconvs / flatten_linear / pos-embed / updims -> mm_projector -> splice + <bbox>
 injection -> LLaMA-7B prefill forward with logits for every position.  A "step" is ONE launch sequence over
-`--batch` such requests merged (continuous batching, default 4: the weights are streamed once for all of them and the
-LLaMA GEMMs get M = 4 x 767 rows, i.e. whole waves of tiles on the 256 CUs); `value` counts every request's 32 region
+`--batch` such requests merged (continuous batching, default 8: the weights are streamed once for all of them and the
+LLaMA GEMMs get M = 8 x 767 rows, i.e. whole waves of tiles on the 256 CUs; profiles/r04_merge_sweep.txt: 1 x 1 1652, 1 x 2 1856,
+4 x 2 2011, 8 x 2 2096 region-tokens/s on one box); `value` counts every request's 32 region
 tokens.  `--batch 1 --streams 1` is the strictly serial batch-1 latency, reported beside the headline as `single_request`.
 Inputs (images, boxes, token ids) and all weights are resident in HBM before the timed region.  Weights are seeded random tensors of the real shapes (no checkpoints in this
 environment).  Multi-GPU: the path shards by image with no data-path collective (inference
@@ -53,7 +54,7 @@ def parse():
                     help="16-bit storage type of the whole path: bf16 (the reference's training dtype; the default) or fp16 (its "
                          "serving dtype, app.py:74-98) -- same MFMA rate, same bytes")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (fp16, 224^2, single request)")
-    ap.add_argument("--batch", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=8,
                     help="batch-1 requests merged into ONE launch sequence per step (continuous batching: the weights are "
                          "streamed once for all of them); value counts every request's region tokens")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")

@@ -169,12 +169,19 @@ def test_from_pretrained_directory_round_trip_on_the_gpu(tmp_path):
     lm.model.config.mm_vision_tower = clip
     d = str(tmp_path / "gpt4roi-mini")
     lm.save_pretrained(d)
-    back = SPILlavaMPTForCausalLM.from_pretrained(d, low_cpu_mem_usage=True, torch_dtype=torch.float16, use_cache=True)
+    back = SPILlavaMPTForCausalLM.from_pretrained(d, low_cpu_mem_usage=True, torch_dtype=torch.bfloat16, use_cache=True)
     with torch.no_grad():
         a = lm(input_ids=prompt, images=img, bboxes=boxes).logits
         b = back(input_ids=prompt, images=img, bboxes=boxes).logits
     # the vision tower was re-read from fp32 files, the decoder from its own bf16 export: same bf16 weights either way
     assert torch.equal(a, b)
+    # the call shape of app.py:70-75 (torch_dtype=torch.float16) selects the fp16 instantiation of the kernels (round 4):
+    # an fp16 model of the same weights -- logits within the bf16 model's own rounding of it
+    half = SPILlavaMPTForCausalLM.from_pretrained(d, low_cpu_mem_usage=True, torch_dtype=torch.float16, use_cache=True)
+    assert half.model.llama.dtype == torch.float16 and half.model.vision_tower[0].dtype == torch.float16
+    with torch.no_grad():
+        c = half(input_ids=prompt, images=img.half(), bboxes=[bx.half() for bx in boxes]).logits
+    assert c.dtype == torch.float32 and ((c - a).abs().max() / a.abs().max()).item() < 3e-2
     assert torch.equal(lm.generate(prompt, images=img, bboxes=boxes, max_new_tokens=6),
                        back.generate(prompt, images=img, bboxes=boxes, max_new_tokens=6))
     info = back.model.initialize_vision_modules(clip, mm_vision_select_layer=-2)
