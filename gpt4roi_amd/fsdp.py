@@ -273,6 +273,8 @@ class FullShardManager:
     def full_state(self, ui):
         """name -> full tensor of unit ui (gathers it; for checkpoints / tests).  The caller must release(ui)."""
         self.direction(1)
+        keep, self.prefetch = self.prefetch, 0                    # this unit only: no look-ahead gather left behind
         self.use(ui)
+        self.prefetch = keep
         u = self.units[ui]
         return {n: v for f in u["flats"] for (n, _), v in zip(f.entries, f.views(f.full))}

@@ -356,7 +356,8 @@ class FSDPFullTrainer(FullTrainer):
                 L.pop(nm + "_t", None)
         dec.lm_head_t = None
         dec.unit_hook = self._unit_hook
-        torch.cuda.empty_cache() if dec.embed is None and torch.cuda.is_available() else None
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()                          # the unsharded construction-time tensors are gone
 
     def _unit_hook(self, phase, li):
         f, dec = self.fsdp, self.model.llama
