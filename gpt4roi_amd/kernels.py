@@ -1065,12 +1065,13 @@ def relu_bwd(y, dy):
 
 
 def gather_rows(src, idx, out=None):
-    """src [R, C] bf16 (row-strided), idx int32 [n] (negative -> zero row) -> [n, C]."""
-    _bf16(src)
+    """src [R, C] 16-bit (bf16 or fp16; row-strided), idx int32 [n] (negative -> zero row) -> [n, C].  A pure 16-byte row
+    copy: one kernel serves both storage types (the batched decode gathers its next embedding rows with it)."""
+    dt = _h16(src, out)
     assert idx.dtype == torch.int32 and idx.is_contiguous()
     n, C = idx.numel(), src.size(1)
     if out is None:
-        out = torch.empty((n, C), dtype=torch.bfloat16, device=src.device)
+        out = torch.empty((n, C), dtype=dt, device=src.device)
     _launch("g4r_gather_rows_bf16", (_p(src), _p(idx), _p(out), n, C, src.stride(0), out.stride(0), _stream(src),),
             tag="g4r_gather_rows_bf16")
     return out

@@ -208,6 +208,25 @@ def test_f16_small_pipeline_prefill_decode_and_greedy_ids_vs_oracle():
     assert got_ids == want_ids
 
 
+def test_f16_batched_and_graph_decode_equal_the_single_sequence_loop():
+    """The device-resident decode loops in fp16: the hipGraph loop (greedy and sampled) and the batched loop give the ids of the
+    plain host loop -- the GEMV with the fused RMSNorm, the split-key attention with RoPE + cache append, the small-M GEMM
+    tiles and the row gather all run their -DG4R_F16 instantiation."""
+    Hd, heads, inter, L = 512, 4, 1408, 3
+    ids = syn.token_ids(990)
+    lsd = {k: v.to(H).float() for k, v in syn.llama_state(Hd, inter, L, ids.vocab, seed=14).items()}
+    dec = LlamaDecoder(lsd, heads=heads, max_positions=256, device=DEV, dtype=H, max_batch=3)
+    g = torch.Generator().manual_seed(15)
+    emb = (torch.randn(3, 40, Hd, generator=g) * 0.7).to(DEV).to(H)
+    with torch.no_grad():
+        single = [dec.greedy(emb[b:b + 1], 9) for b in range(3)]
+        assert dec.greedy_graph(emb[0:1], 9) == single[0]
+        assert dec.decode_graph_batch(emb, 9) == single
+        want, _ = T.greedy_decode(lsd, emb[1:2].float().cpu(), lambda t: lsd["model.embed_tokens.weight"][t], heads=heads, n_new=9,
+                                  emulate=torch.float16)
+    assert single[1] == want
+
+
 def test_roi_align_mlvl_edge_boxes_vs_the_reference_cpu_op():
     """the PRODUCTION multi-level NHWC kernel on edge boxes against a fixture made by the reference's own
     compiled CPU op (tests/golden/make_golden.py::edges_mlvl -> oracle/_ref): boxes off every border, fully outside,
