@@ -49,6 +49,7 @@ struct GemmArgs {
   int n_lvl;
   int tiles_m, tiles_n;
   int n_fastest;  // tile order: 1 = consecutive workgroups walk N first (share the A / activation tile)
+  int group_m;    // > 0: grouped tile order (g4r_tile_coords), row tiles per group
   int dbg;  // ablation probe (tools only): 1 = skip the loads after the first tile, 2 = skip the MFMAs
   unsigned a_bytes, w_bytes;   // extent of the A / W operands in bytes when < 2 GiB (buffer descriptors), else 0
   int defer_reduce;            // split-K: leave the fp32 partials in ws, the CALLER's next kernel combines them
@@ -87,6 +88,28 @@ __device__ __forceinline__ void g4r_workgroup_tile_slice(int nwg, bool tile_majo
   const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   slice = v / nwg;
   tile = v - slice * nwg;
+}
+
+// Tile id -> (row tile, column tile).  group_m == 0: the plain orders (M fastest: consecutive workgroups share a W panel; N
+// fastest: they share an A tile).  group_m > 0 (round 4, dense GEMMs with many row tiles): GROUPED order -- ids sweep `group_m`
+// row tiles x all column tiles, M fastest inside the group -- so that the 32 workgroups an XCD runs at a time form a compact
+// group_m x (32 / group_m) block of tiles instead of one column of 32 row tiles: its L2 then streams group_m A tiles + 32 /
+// group_m W panels per wave instead of ALL of A (8 merged requests, 6136 x 4096 x 4096: every XCD re-read the whole 50 MB
+// activation matrix for each of its waves, 1.65 GB of HBM-side reads per launch against 134 MB algorithmic,
+// profiles/r04_pmc_report.txt).
+__device__ __forceinline__ void g4r_tile_coords(int wg, int tiles_m, int tiles_n, int n_fastest, int group_m, int& tile_m, int& tile_n) {
+  if (group_m > 0) {
+    const int per_group = group_m * tiles_n;
+    const int gid = wg / per_group;
+    const int first_m = gid * group_m;
+    const int gsz = (tiles_m - first_m) < group_m ? (tiles_m - first_m) : group_m;
+    const int in_group = wg - gid * per_group;
+    tile_m = first_m + in_group % gsz;
+    tile_n = in_group / gsz;
+    return;
+  }
+  tile_m = n_fastest ? wg / tiles_n : wg % tiles_m;
+  tile_n = n_fastest ? wg % tiles_n : wg / tiles_m;
 }
 
 // waves per SIMD the kernel is allowed to assume = workgroups that fit the 160 KB LDS (<= 3)
@@ -1341,8 +1364,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32_kernel(GemmArgs p) {
   const int nwg = p.tiles_m * p.tiles_n;
   int wg, split;
   g4r_workgroup_tile_slice(nwg, p.dbg == 11, wg, split);
-  const int tile_m = p.n_fastest ? wg / p.tiles_n : wg % p.tiles_m;
-  const int tile_n = p.n_fastest ? wg % p.tiles_n : wg / p.tiles_m;
+  int tile_m, tile_n;
+  g4r_tile_coords(wg, p.tiles_m, p.tiles_n, p.n_fastest, p.group_m, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   // tools only (ablations of the K loop; results are wrong by construction): dbg 21 = every workgroup streams the operands
   // of tile (0, 0) -- an L2-resident 4 MB working set, so what remains is the CU's own load path; 22 = no pieces after the
@@ -2000,6 +2023,17 @@ template <int AMODE>
 int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
   if (g_gemm_dbg == 9) p.n_fastest = 0;     // tools: force the tile order (A/B of the L2 sharing pattern)
   if (g_gemm_dbg == 10) p.n_fastest = 1;
+  // grouped tile order for dense launches with many row tiles (ring ping-pong kernel): tools modes 31 / 32 / 33 force a group of
+  // 8 / 4 / 16 row tiles, 30 forces the plain order
+  p.group_m = 0;
+  if (AMODE == 0 && (tile_cfg == 24 || tile_cfg == 28)) {
+    const int tm = g4r_ceil_div(p.M, tile_cfg == 28 ? 192 : 256);
+    if (tm >= 12) p.group_m = 8;
+    if (g_gemm_dbg == 30) p.group_m = 0;
+    if (g_gemm_dbg == 31) p.group_m = 8;
+    if (g_gemm_dbg == 32) p.group_m = 4;
+    if (g_gemm_dbg == 33) p.group_m = 16;
+  }
   switch (tile_cfg) {
     case 0: return launch_tile<128, 128, 2, 2, AMODE, true>(p, stream);
     case 1: return launch_tile<256, 128, 4, 2, AMODE, true>(p, stream);

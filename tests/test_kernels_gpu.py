@@ -150,6 +150,18 @@ def test_roi_align_mlvl_staged_path_edge_boxes():
 
 
 # ------------------------------------------------------------------------------------------ GEMM / conv
+@pytest.mark.parametrize("tile", [24, 28])
+@pytest.mark.parametrize("M,N,K", [(3100, 1300, 256), (6136, 4096, 128), (3265, 520, 192)])
+def test_gemm_grouped_tile_order_with_ragged_groups(tile, M, N, K):
+    """Dense launches with >= 12 row tiles walk the tiles in groups of 8 row tiles x all column tiles (round 4: the 32
+    workgroups an XCD runs at a time then share 8 A tiles + 4 W panels instead of re-reading all of A).  Ragged cases: a last
+    group of fewer than 8 row tiles, a last row tile and a last column tile that are partly outside the matrix."""
+    a, w = rnd(M, K, seed=11), rnd(N, K, seed=12)
+    ref = a.float() @ w.float().t()
+    got = K_gemm(a, w, tile_cfg=tile)
+    close(got, ref, 0.06 * math.sqrt(K / 64), 1e-2, f"grouped gemm {M}x{N}x{K} tile {tile}")
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 22, 24, 26, 27, 28])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 328, 192), (37, 1024, 1024), (800, 512, 2048),
                                    (50, 30, 64), (300, 256, 128)])
