@@ -98,6 +98,18 @@ __device__ __forceinline__ void g4r_workgroup_tile_slice(int nwg, bool tile_majo
 // activation matrix for each of its waves, 1.65 GB of HBM-side reads per launch against 134 MB algorithmic,
 // profiles/r04_pmc_report.txt).
 __device__ __forceinline__ void g4r_tile_coords(int wg, int tiles_m, int tiles_n, int n_fastest, int group_m, int& tile_m, int& tile_n) {
+  if (group_m < 0) {
+    // groups of -group_m COLUMN tiles x all row tiles, N fastest inside the group (conv: few column tiles, a big W panel each)
+    const int gn = -group_m;
+    const int per_group = gn * tiles_m;
+    const int gid = wg / per_group;
+    const int first_n = gid * gn;
+    const int gsz = (tiles_n - first_n) < gn ? (tiles_n - first_n) : gn;
+    const int in_group = wg - gid * per_group;
+    tile_n = first_n + in_group % gsz;
+    tile_m = in_group / gsz;
+    return;
+  }
   if (group_m > 0) {
     const int per_group = group_m * tiles_n;
     const int gid = wg / per_group;
@@ -2034,6 +2046,8 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     if (g_gemm_dbg == 32) p.group_m = 4;
     if (g_gemm_dbg == 33) p.group_m = 16;
   }
+  if (AMODE >= 1 && g_gemm_dbg == 41) p.group_m = -2;   // tools: conv, an XCD's wave = 16 pixel tiles x 2 weight panels
+  if (AMODE >= 1 && g_gemm_dbg == 42) p.group_m = -1;   // tools: 32 pixel tiles x 1 weight panel
   switch (tile_cfg) {
     case 0: return launch_tile<128, 128, 2, 2, AMODE, true>(p, stream);
     case 1: return launch_tile<256, 128, 4, 2, AMODE, true>(p, stream);
@@ -2268,6 +2282,8 @@ int g4r_conv3x3_mlvl_nhwc_bf16(const void* X, const void* W, void* Y, const floa
   p.lda = Cin; p.ldw = p.K; p.ldc = Cout;
   p.act = act; p.H = level_h[0]; p.Wd = level_w[0]; p.Cin = Cin; p.groups = 1;
   p.n_fastest = 1; p.dbg = g_gemm_dbg; p.splits = 1;
+  if (g_gemm_dbg == 41) p.group_m = -2;     // tools: an XCD's wave = 16 pixel tiles x 2 weight panels (instead of 8 x 4)
+  if (g_gemm_dbg == 42) p.group_m = -1;     // tools: 32 pixel tiles x 1 weight panel
   return launch_pp32<2, false, 256, 256, true, 1>(p, (hipStream_t)stream);
 }
 
