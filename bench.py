@@ -265,12 +265,35 @@ def train_leg(args, model, ids, device, rank, world, dist, agg_device):
     regions = sum(n_i)
     tot, dt = replicas.aggregate(regions * args.train_steps, dt_local, dist, device=agg_device)
     tot = int(round(tot))
+    # per-family fractions of the MFMA peak over ONE instrumented extra step (HIP events per launch on the launch stream),
+    # rank 0 only, single-rank runs only (with world > 1 the extra step would need every rank in its collectives)
+    train_roofline = None
+    if rank == 0 and world == 1 and not args.no_roofline:
+        from gpt4roi_amd import kernels as K
+        K.PROFILER.start()
+        tr.step(prompt, images, boxes, labels)
+        agg = K.PROFILER.stop()
+        tsum = sum(a["ms"] for a in agg.values())
+        fams = {"gemm": lambda t: t.startswith("gemm_bf16_nt") or t.startswith("gemv") or t == "small_linear",
+                "conv": lambda t: t.startswith("conv3x3_igemm"), "attention_fwd": lambda t: t.startswith("flash_attn<"),
+                "attention_bwd": lambda t: t.startswith("flash_attn_bwd")}
+        train_roofline = {"instrumented_step_kernel_ms": round(tsum, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "families": {}}
+        for fname, pred in fams.items():
+            ms_ = sum(a["ms"] for t, a in agg.items() if pred(t))
+            fl_ = sum(a["flops"] for t, a in agg.items() if pred(t))
+            if ms_ > 0:
+                tf_ = fl_ / (ms_ * 1e-3) / 1e12
+                train_roofline["families"][fname] = {"ms": round(ms_, 2), "share": round(ms_ / tsum, 3), "achieved": round(tf_, 1),
+                                                     "frac": round(tf_ / PEAK_BF16_TFLOPS, 4),
+                                                     "launches": sum(a["calls"] for t, a in agg.items() if pred(t))}
+        other = sorted(((t, a["ms"]) for t, a in agg.items() if not any(pred(t) for pred in fams.values())), key=lambda kv: -kv[1])
+        train_roofline["other_top"] = {t: round(ms_, 2) for t, ms_ in other[:8]}
     out = {"what": "stage-1 step (SURVEY.md 8d config 3): forward + hand-written backward + exchange + clip + fused AdamW",
            "batch_per_gpu": B, "tokens_per_sequence": int(prompt.size(1)), "regions_per_step_all_ranks": tot // max(1, args.train_steps),
            "steps": args.train_steps, "ms_per_step": round(1e3 * dt / args.train_steps, 2),
            "images_per_s": round(B * world * args.train_steps / dt, 2),
            "region_tokens_trained_per_s": round(tot / dt, 1), "peak_mem_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
-           "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
+           "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)], "roofline": train_roofline,
            "exchange": None if tr.reducer is None else {"algo": tr.reducer.algo, "buckets": tr.reducer.describe(),
                                                         "overlapped_with_backward": True}}
     return out
