@@ -82,6 +82,52 @@ __device__ __forceinline__ void stage_transposed(h16_t* dst, const h16_t* src, l
   }
 }
 
+// Round 4: ONE global pass per streamed tile and a register prefetch.  A thread holds 4 consecutive rows x one 16-byte slot
+// (the mapping the transposed write needs); from those 4 registers it writes BOTH LDS images -- the row-major swizzled one
+// (4 x 16-byte stores) and the transposed one (8 x 8-byte stores) -- so a tile is read from memory once instead of twice, and
+// `tile_load` for tile i+1 is issued before the MFMAs of tile i (the kernels run ONE workgroup per CU at 284-358 registers per
+// lane: without the prefetch nothing overlapped the load latency, and a 64-row tile took ~11 us against ~1 us of MFMAs).
+template <int D, int NT>
+struct TileRegs {
+  static_assert(16 * (D / 8) == NT, "one (row quad, slot) unit per thread");
+  uint4v w[4];
+};
+
+template <int D, int NT>
+__device__ __forceinline__ void tile_load(TileRegs<D, NT>& t, const h16_t* src, long row_stride, int r0, int rmax, int tid) {
+  const int rq = tid % 16, vs = tid / 16;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int r = r0 + rq * 4 + j;
+    if (r > rmax - 1) r = rmax - 1;
+    t.w[j] = *reinterpret_cast<const uint4v*>(src + (size_t)r * row_stride + vs * 8);
+  }
+}
+
+template <int D, int NT>
+__device__ __forceinline__ void tile_store_rows(const TileRegs<D, NT>& t, h16_t* dst, int tid) {
+  const int rq = tid % 16, vs = tid / 16;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = rq * 4 + j;
+    *reinterpret_cast<uint4v*>(reinterpret_cast<char*>(dst) + row * (D * 2) + ((vs ^ row_swz<D>(row)) << 4)) = t.w[j];
+  }
+}
+
+template <int D, int NT>
+__device__ __forceinline__ void tile_store_transposed(const TileRegs<D, NT>& t, h16_t* dst, int tid) {
+  const int rq = tid % 16, vs = tid / 16;
+  const unsigned w[4][4] = {{t.w[0].x, t.w[0].y, t.w[0].z, t.w[0].w}, {t.w[1].x, t.w[1].y, t.w[1].z, t.w[1].w},
+                            {t.w[2].x, t.w[2].y, t.w[2].z, t.w[2].w}, {t.w[3].x, t.w[3].y, t.w[3].z, t.w[3].w}};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint2v lo = {(w[0][e] & 0xffffu) | (w[1][e] << 16), (w[2][e] & 0xffffu) | (w[3][e] << 16)};
+    const uint2v hi2 = {(w[0][e] >> 16) | (w[1][e] & 0xffff0000u), (w[2][e] >> 16) | (w[3][e] & 0xffff0000u)};
+    *reinterpret_cast<uint2v*>(dst + (vs * 8 + 2 * e) * T_LD + rq * 4) = lo;
+    *reinterpret_cast<uint2v*>(dst + (vs * 8 + 2 * e + 1) * T_LD + rq * 4) = hi2;
+  }
+}
+
 template <int D>
 __device__ __forceinline__ h16x8 frag_rows(const h16_t* tile, int row, int kk, int hi) {
   return *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(tile) + row * (D * 2) +
@@ -181,28 +227,48 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(AttnBwdArgs p) 
     const int last = qblock + QB - 1 + off + 1;
     if (last < kend) kend = last;
   }
+  TileRegs<D, NT> kreg, vreg;
+  if (kend > 0) {
+    tile_load<D, NT>(kreg, Kb, p.k_row, 0, p.Tk, tid);
+    tile_load<D, NT>(vreg, Vb, p.v_row, 0, p.Tk, tid);
+  }
   for (int j0 = 0; j0 < kend; j0 += TB) {
-    stage_rows<D, NT>(Ks, Kb, p.k_row, j0, p.Tk, tid);
-    stage_rows<D, NT>(Vs, Vb, p.v_row, j0, p.Tk, tid);
-    stage_transposed<D, NT>(Kt, Kb, p.k_row, j0, p.Tk, tid);
+    tile_store_rows<D, NT>(kreg, Ks, tid);
+    tile_store_rows<D, NT>(vreg, Vs, tid);
+    tile_store_transposed<D, NT>(kreg, Kt, tid);
     __syncthreads();
+    if (j0 + TB < kend) {                                   // the next tile's rows travel while this tile is multiplied
+      tile_load<D, NT>(kreg, Kb, p.k_row, j0 + TB, p.Tk, tid);
+      tile_load<D, NT>(vreg, Vb, p.v_row, j0 + TB, p.Tk, tid);
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       float16v sacc, dpacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[r] = 0.f, dpacc[r] = 0.f;
       const int row = kb * 32 + ql;
+      // all 2 x KSTEPS fragments of this key block first, in registers of their own, THEN the MFMAs: with one wave per SIMD
+      // a ds_read -> s_waitcnt -> v_mfma chain per step (what the compiler made of the fused loop) exposes the LDS latency
+      // 2 x KSTEPS times per block
+      h16x8 kfr[KSTEPS], vfr[KSTEPS];
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
-        sacc = G4R_MFMA_32X32X16(frag_rows<D>(Ks, row, kk, hi), qf[kk], sacc, 0, 0, 0);
-        dpacc = G4R_MFMA_32X32X16(frag_rows<D>(Vs, row, kk, hi), dof[kk], dpacc, 0, 0, 0);
+        kfr[kk] = frag_rows<D>(Ks, row, kk, hi);
+        vfr[kk] = frag_rows<D>(Vs, row, kk, hi);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        sacc = G4R_MFMA_32X32X16(kfr[kk], qf[kk], sacc, 0, 0, 0);
+        dpacc = G4R_MFMA_32X32X16(vfr[kk], dof[kk], dpacc, 0, 0, 0);
       }
       float ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const bool valid = key < p.Tk && qi < p.Tq && (!p.causal || key <= qi + off);
-        const float pr = valid ? __builtin_amdgcn_exp2f(sacc[r] * sc2 - lse_i) : 0.f;
+        const float e = __builtin_amdgcn_exp2f(sacc[r] * sc2 - lse_i);     // unconditional: a select, not a branch per element
+        const float pr = valid ? e : 0.f;
         ds[r] = pr * (dpacc[r] - delta_i) * p.scale;
       }
 #pragma unroll
@@ -281,29 +347,53 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnBwdArgs p)
   }
   const float* lse_b = p.lse + ((size_t)b * p.H + h) * p.Tq;
   const float* delta_b = p.delta + ((size_t)b * p.H + h) * p.Tq;
-  for (int i0 = q_begin; i0 < p.Tq; i0 += TB) {
-    stage_rows<D, NT>(Qs, Qb, p.q_row, i0, p.Tq, tid);
-    stage_rows<D, NT>(Gs, Gb, p.do_row, i0, p.Tq, tid);
-    stage_transposed<D, NT>(Qt, Qb, p.q_row, i0, p.Tq, tid);
-    stage_transposed<D, NT>(Gt, Gb, p.do_row, i0, p.Tq, tid);
+  TileRegs<D, NT> qreg, greg;
+  float lse_r = 0.f, delta_r = 0.f;
+  auto load_tile = [&](int i0) {
+    tile_load<D, NT>(qreg, Qb, p.q_row, i0, p.Tq, tid);
+    tile_load<D, NT>(greg, Gb, p.do_row, i0, p.Tq, tid);
     if (tid < TB) {
       int q = i0 + tid;
       if (q > p.Tq - 1) q = p.Tq - 1;
-      lse_s[tid] = lse_b[q];
-      delta_s[tid] = delta_b[q];
+      lse_r = lse_b[q];
+      delta_r = delta_b[q];
+    }
+  };
+  if (q_begin < p.Tq) load_tile(q_begin);
+  for (int i0 = q_begin; i0 < p.Tq; i0 += TB) {
+    tile_store_rows<D, NT>(qreg, Qs, tid);
+    tile_store_rows<D, NT>(greg, Gs, tid);
+    tile_store_transposed<D, NT>(qreg, Qt, tid);
+    tile_store_transposed<D, NT>(greg, Gt, tid);
+    if (tid < TB) {
+      lse_s[tid] = lse_r;
+      delta_s[tid] = delta_r;
     }
     __syncthreads();
+    if (i0 + TB < p.Tq) load_tile(i0 + TB);                  // the next tile's rows travel while this tile is multiplied
+    // Both 32-query blocks of the tile: S and dP of BOTH first (four independent accumulator chains), then the softmax
+    // arithmetic of block 0, then the dV / dK MFMAs of block 0 in one basic block with the arithmetic of block 1 (the wave has
+    // its SIMD to itself: independent VALU work is what can run under its own MFMAs), then the MFMAs of block 1.
+    float16v sacc[2], dpacc[2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      float16v sacc, dpacc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = 0.f, dpacc[r] = 0.f;
+      for (int r = 0; r < 16; ++r) sacc[qb][r] = 0.f, dpacc[qb][r] = 0.f;
       const int row = qb * 32 + ql;
+      h16x8 qfr[KSTEPS], gfr[KSTEPS];                 // fragments first, MFMAs after (see attn_bwd_dq_kernel)
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
-        sacc = G4R_MFMA_32X32X16(frag_rows<D>(Qs, row, kk, hi), kf[kk], sacc, 0, 0, 0);
-        dpacc = G4R_MFMA_32X32X16(frag_rows<D>(Gs, row, kk, hi), vf[kk], dpacc, 0, 0, 0);
+        qfr[kk] = frag_rows<D>(Qs, row, kk, hi);
+        gfr[kk] = frag_rows<D>(Gs, row, kk, hi);
       }
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        sacc[qb] = G4R_MFMA_32X32X16(qfr[kk], kf[kk], sacc[qb], 0, 0, 0);
+        dpacc[qb] = G4R_MFMA_32X32X16(gfr[kk], vf[kk], dpacc[qb], 0, 0, 0);
+      }
+    }
+    h16x8 pfr[2][2], sfr[2][2];
+    auto softmax_block = [&](int qb) {
       float pr[16], ds[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -315,22 +405,32 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnBwdArgs p)
           const int r = g * 4 + e;
           const int qi = i0 + il + e;
           const bool valid = qi < p.Tq && kj < p.Tk && (!p.causal || kj <= qi + off);
-          pr[r] = valid ? __builtin_amdgcn_exp2f(sacc[r] * sc2 - l4[e]) : 0.f;
-          ds[r] = pr[r] * (dpacc[r] - d4[e]) * p.scale;
+          const float ex = __builtin_amdgcn_exp2f(sacc[qb][r] * sc2 - l4[e]);
+          pr[r] = valid ? ex : 0.f;
+          ds[r] = pr[r] * (dpacc[qb][r] - d4[e]) * p.scale;
         }
       }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const h16x8 pf = pack8(pr + hf * 8);
-        const h16x8 sf = pack8(ds + hf * 8);
+        pfr[qb][hf] = pack8(pr + hf * 8);
+        sfr[qb][hf] = pack8(ds + hf * 8);
+      }
+    };
+    auto grad_block = [&](int qb) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
         const int ibase = qb * 32 + hf * 16 + 4 * hi;
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
-          dvacc[d] = G4R_MFMA_32X32X16(frag_transposed(Gt, d * 32 + ql, ibase), pf, dvacc[d], 0, 0, 0);
-          dkacc[d] = G4R_MFMA_32X32X16(frag_transposed(Qt, d * 32 + ql, ibase), sf, dkacc[d], 0, 0, 0);
+          dvacc[d] = G4R_MFMA_32X32X16(frag_transposed(Gt, d * 32 + ql, ibase), pfr[qb][hf], dvacc[d], 0, 0, 0);
+          dkacc[d] = G4R_MFMA_32X32X16(frag_transposed(Qt, d * 32 + ql, ibase), sfr[qb][hf], dkacc[d], 0, 0, 0);
         }
       }
-    }
+    };
+    softmax_block(0);
+    grad_block(0);
+    softmax_block(1);
+    grad_block(1);
     __syncthreads();
   }
   if (kj < p.Tk) {
