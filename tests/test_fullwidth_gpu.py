@@ -59,6 +59,14 @@ PROD_SHAPES = [
     (577, 3072, 1024, None, torch.bfloat16, "ViT fused q|k|v (+bias)"),
     (577, 4096, 1024, "quick_gelu", torch.bfloat16, "ViT fc1 (+bias, QuickGELU)"),
     (577, 1024, 4096, None, torch.bfloat16, "ViT fc2 (+bias, +residual)"),
+    # round 4: the shapes of 4 and 8 merged requests (bench --batch): whole-wave dispatch between the 192- and 256-row ring
+    # tiles, the grouped tile order (>= 12 row tiles), gate|up's thin last wave as K slices with the SwiGLU in the reduce
+    (3068, 12288, 4096, None, torch.bfloat16, "4 merged: fused q|k|v on 192 x 256 tiles, grouped order"),
+    (3068, 22016, 4096, "swiglu", torch.bfloat16, "4 merged: gate|up, 4 waves of 256 x 256 + thin tail as K slices"),
+    (6136, 4096, 4096, None, torch.bfloat16, "8 merged: o_proj (+residual), two waves of 192 x 256"),
+    (6136, 4096, 11008, None, torch.bfloat16, "8 merged: down_proj (+residual)"),
+    (6136, 22016, 4096, "swiglu", torch.bfloat16, "8 merged: gate|up, 8 waves + thin tail"),
+    (4616, 3072, 1024, None, torch.bfloat16, "ViT fused q|k|v at batch 8 (+bias)"),
 ]
 
 
