@@ -408,6 +408,7 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=None, spl
     if out is None:
         out = torch.empty((M, n_out), dtype=out_dtype or dt, device=a.device)
     assert out.stride(1) == 1 and out.shape == (M, n_out)
+    assert out.dtype in (dt, torch.float32), f"gemm: out is {out.dtype}, operands are {dt}"     # (the epilogue writes dt or fp32 bits)
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
     thin_tail = False
@@ -477,7 +478,7 @@ def gemv(x, w, norm_weight=None, eps=1e-6, bias=None, residual=None, act=None, o
     n_out = N // 2 if act == "swiglu" else N
     if out is None:
         out = torch.empty((1, n_out), dtype=out_dtype or dt, device=x.device)
-    assert out.numel() == n_out and out.is_contiguous()
+    assert out.numel() == n_out and out.is_contiguous() and out.dtype in (dt, torch.float32)
     if residual is not None:
         assert residual.numel() == N and residual.is_contiguous()
     _launch("g4r_gemv_rmsnorm_bf16", (_p(x), _p(norm_weight), float(eps), _p(w), _p(out), _p(bias), _p(residual), N, K,
@@ -505,6 +506,7 @@ def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=None, split
     assert w.size(1) == groups * 9 * Cin and w.is_contiguous()
     if out is None:
         out = torch.empty((B, H, W, Cout), dtype=out_dtype or dt, device=x.device)
+    assert out.dtype in (dt, torch.float32), f"conv3x3: out is {out.dtype}, operands are {dt}"
     if tile_cfg is None:
         tile_cfg, auto_splits = pick_conv_tile(B * H * W, Cout, groups * 9 * Cin)
         if splits == 1:
@@ -574,6 +576,7 @@ def flash_attn(q, k, v, heads, scale, causal=False, out=None, kv_len_dev=None, l
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
     if out is None:
         out = torch.empty((B, Tq, HD), dtype=dt, device=q.device)
+    assert out.dtype == dt, f"flash_attn: out is {out.dtype}, operands are {dt}"
     _launch("g4r_flash_attn_fwd_bf16", (
         _p(q), _p(k), _p(v), _p(out), B, heads, Tq, Tk, D, q.stride(1), k.stride(1), v.stride(1), out.stride(1),
         q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), int(bool(causal)), _p(kv_len_dev),
