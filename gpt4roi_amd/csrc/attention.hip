@@ -276,8 +276,11 @@ struct DecodeAttnArgs {
   int Tk, S, H;
   float scale;
   const int* kv_len_dev;
-  int defer;
-  long q_batch, k_batch, v_batch, o_batch;   // elements between the sequences of a batch (blockIdx.z); all share Tk           // 1: leave the S partials in ws for the consumer (g4r_gemv_attn_merge_bf16); O and cnt unused
+  int defer;           // 1: leave the S partials in ws for the consumer (g4r_gemv_attn_merge_bf16); O and cnt unused
+  long q_batch, k_batch, v_batch, o_batch;   // elements between the sequences of a batch (blockIdx.z)
+  int kv_len_stride;   // 0: the sequences share *kv_len_dev; 1: sequence z reads kv_len_dev[z] (ragged batch)
+  const int* rope_pos_dev;   // optional (with qkv): RoPE position of the new token when it is not its cache row -- a prompt
+                             // whose pad positions were squeezed out of the cache keeps the positions of the padded layout
 };
 
 __device__ __forceinline__ void unpack8(const uint4v& r, float* f) {
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeAttnArgs p) {
     if (p.ws) p.ws += bz * (size_t)p.H * S * (D + 2);
     if (p.cnt) p.cnt += bz * p.H;
   }
-  const int Tk = p.kv_len_dev ? *p.kv_len_dev + 1 : p.Tk;
+  const int Tk = p.kv_len_dev ? p.kv_len_dev[(size_t)blockIdx.z * p.kv_len_stride] + 1 : p.Tk;
   int chunk = (Tk + S - 1) / S;
   chunk = (chunk + NST - 1) / NST * NST;
   const int j_begin = s * chunk;
@@ -337,15 +340,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeAttnArgs p) {
     // roundings as rope_qkv_kernel (elementwise.hip); lane `sub` holds 8 dims, its partner half is lane sub ^ (LPK/2)
     constexpr int HL = LPK / 2;
     const int pos = Tk - 1, v8 = (sub & (HL - 1)) * 8;
+    const int rpos = p.rope_pos_dev ? *p.rope_pos_dev : pos;
     const bool second = sub >= HL;
     const size_t own = (size_t)h * D + sub * 8, oth = (size_t)h * D + (sub ^ HL) * 8;
     const size_t HD = (size_t)p.H * D;
     float c[8], sn[8], a[8], b[8];
     {
-      const float4v c0 = *reinterpret_cast<const float4v*>(p.cs + (size_t)pos * (D / 2) + v8);
-      const float4v c1 = *reinterpret_cast<const float4v*>(p.cs + (size_t)pos * (D / 2) + v8 + 4);
-      const float4v s0 = *reinterpret_cast<const float4v*>(p.sn + (size_t)pos * (D / 2) + v8);
-      const float4v s1 = *reinterpret_cast<const float4v*>(p.sn + (size_t)pos * (D / 2) + v8 + 4);
+      const float4v c0 = *reinterpret_cast<const float4v*>(p.cs + (size_t)rpos * (D / 2) + v8);
+      const float4v c1 = *reinterpret_cast<const float4v*>(p.cs + (size_t)rpos * (D / 2) + v8 + 4);
+      const float4v s0 = *reinterpret_cast<const float4v*>(p.sn + (size_t)rpos * (D / 2) + v8);
+      const float4v s1 = *reinterpret_cast<const float4v*>(p.sn + (size_t)rpos * (D / 2) + v8 + 4);
       c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
       sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
     }
@@ -559,10 +563,11 @@ int g4r_flash_attn_fwd_bf16(const void* Q, const void* K, const void* V, void* O
 // output (g4r_gemv_attn_merge_bf16, the o_proj of the decode step) -- no hand-off inside this launch; O/counters unused.
 // Replaces the Tq = 1 case of g4r_flash_attn_fwd_bf16 in the decode loop the reference reaches through HF generate()
 // (gpt4roi/app.py:293-300 -> transformers LlamaAttention with past_key_values).
-int g4r_attn_decode_bf16(const void* Q, const void* qkv, const float* cos_tab, const float* sin_tab, void* K, void* V,
+static int attn_decode_launch(const void* Q, const void* qkv, const float* cos_tab, const float* sin_tab, void* K, void* V,
                          void* O, float* workspace, unsigned* counters, int H, int head_dim, int Tk, long k_row,
                          long v_row, float scale, int splits, const int* kv_len_dev, int defer_merge, int batch,
-                         long q_batch, long k_batch, long v_batch, long o_batch, void* stream) {
+                         long q_batch, long k_batch, long v_batch, long o_batch, int kv_len_stride,
+                              const int* rope_pos_dev, void* stream) {
   G4R_REQUIRE(H > 0 && (Tk > 0 || kv_len_dev) && batch >= 1 && batch <= 65535, "attn_decode: bad shape");
   G4R_REQUIRE(head_dim == 64 || head_dim == 128, "attn_decode: head_dim must be 64 or 128");
   G4R_REQUIRE((Q || qkv) && K && V && (O || defer_merge), "attn_decode: null pointer");
@@ -574,7 +579,7 @@ int g4r_attn_decode_bf16(const void* Q, const void* qkv, const float* cos_tab, c
                   o_batch % 8 == 0, "attn_decode: strides must keep 16-byte alignment");
   DecodeAttnArgs a = {(const h16_t*)Q, (const h16_t*)qkv, cos_tab, sin_tab, (h16_t*)K, (h16_t*)V, (h16_t*)O,
                       workspace, counters, k_row, v_row, Tk, splits, H, scale, kv_len_dev, defer_merge,
-                      q_batch, k_batch, v_batch, o_batch};
+                      q_batch, k_batch, v_batch, o_batch, kv_len_stride, rope_pos_dev};
   dim3 grid(splits, H, batch);
   if (head_dim == 64)
     hipLaunchKernelGGL((attn_decode_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -582,6 +587,29 @@ int g4r_attn_decode_bf16(const void* Q, const void* qkv, const float* cos_tab, c
     hipLaunchKernelGGL((attn_decode_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, a);
   G4R_CHECK_LAUNCH("attn_decode");
   return G4R_OK;
+}
+
+int g4r_attn_decode_bf16(const void* Q, const void* qkv, const float* cos_tab, const float* sin_tab, void* K, void* V,
+                         void* O, float* workspace, unsigned* counters, int H, int head_dim, int Tk, long k_row,
+                         long v_row, float scale, int splits, const int* kv_len_dev, int defer_merge, int batch,
+                         long q_batch, long k_batch, long v_batch, long o_batch, void* stream) {
+  return attn_decode_launch(Q, qkv, cos_tab, sin_tab, K, V, O, workspace, counters, H, head_dim, Tk, k_row, v_row, scale,
+                            splits, kv_len_dev, defer_merge, batch, q_batch, k_batch, v_batch, o_batch, 0, nullptr, stream);
+}
+
+// Ragged batch: sequence z attends its own first kv_lens_dev[z] + 1 rows and appends the new row at kv_lens_dev[z]; the
+// RoPE position of the new tokens is *rope_pos_dev for every sequence (null: the cache row).  This is what HF's decoder
+// does for a batch with a padding mask (positions count the padded layout, masked keys are not attended; the reference
+// reaches it through generate() with attention_mask, llava/model/llava.py:263-283) once the pad rows have been squeezed
+// out of the cache.
+int g4r_attn_decode_ragged_bf16(const void* qkv, const float* cos_tab, const float* sin_tab, void* K, void* V, void* O,
+                                float* workspace, unsigned* counters, int H, int head_dim, long k_row, long v_row,
+                                float scale, int splits, const int* kv_lens_dev, const int* rope_pos_dev, int batch,
+                                long q_batch, long k_batch, long v_batch, long o_batch, void* stream) {
+  G4R_REQUIRE(qkv && kv_lens_dev, "attn_decode_ragged: needs the projection rows and the per-sequence lengths");
+  return attn_decode_launch(nullptr, qkv, cos_tab, sin_tab, K, V, O, workspace, counters, H, head_dim, 0, k_row, v_row,
+                            scale, splits, kv_lens_dev, 0, batch, q_batch, k_batch, v_batch, o_batch, 1, rope_pos_dev,
+                            stream);
 }
 
 }  // extern "C"

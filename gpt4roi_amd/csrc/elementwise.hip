@@ -572,7 +572,8 @@ __global__ __launch_bounds__(1024) void greedy_advance_kernel(const float* __res
 // *step; the shared counters advance once.  One block: nobody reads *step after it moved.
 __global__ __launch_bounds__(64) void batch_advance_kernel(const long* __restrict__ nxt, int B, long* __restrict__ tok,
                                                            int* __restrict__ tok32, long* __restrict__ out_ids,
-                                                           int* __restrict__ step, int* __restrict__ pos, int max_steps) {
+                                                           int* __restrict__ step, int* __restrict__ pos, int max_steps,
+                                                           int npos) {
   const int st = *step;
   for (int b = threadIdx.x; b < B; b += 64) {
     const long t = nxt[b];
@@ -581,10 +582,8 @@ __global__ __launch_bounds__(64) void batch_advance_kernel(const long* __restric
     if (st < max_steps) out_ids[(size_t)b * max_steps + st] = t;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    *step = st + 1;
-    *pos = *pos + 1;
-  }
+  if (threadIdx.x == 0) *step = st + 1;
+  for (int i = threadIdx.x; i < npos; i += 64) pos[i] += 1;      // one shared position, or one per sequence (+ the RoPE one)
 }
 
 // y[i] = a[i] + b[row(i) % brows]  (bf16; used for "+ pos_embedd" style adds), C % 8 == 0
@@ -812,8 +811,19 @@ int g4r_batch_advance(const long* nxt, int B, long* tok, int* tok32, long* out_i
   G4R_REQUIRE(B > 0 && max_steps >= 0, "batch_advance: bad shape");
   G4R_REQUIRE(nxt && tok && tok32 && out_ids && step && pos, "batch_advance: null pointer");
   hipLaunchKernelGGL(batch_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, nxt, B, tok, tok32, out_ids, step,
-                     pos, max_steps);
+                     pos, max_steps, 1);
   G4R_CHECK_LAUNCH("batch_advance");
+  return G4R_OK;
+}
+
+// Same step for a ragged batch: `pos` holds npos counters (the B cache lengths and the shared RoPE position), all advanced.
+int g4r_batch_advance_ragged(const long* nxt, int B, long* tok, int* tok32, long* out_ids, int* step, int* pos, int npos,
+                             int max_steps, void* stream) {
+  G4R_REQUIRE(B > 0 && max_steps >= 0 && npos >= 1, "batch_advance_ragged: bad shape");
+  G4R_REQUIRE(nxt && tok && tok32 && out_ids && step && pos, "batch_advance_ragged: null pointer");
+  hipLaunchKernelGGL(batch_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, nxt, B, tok, tok32, out_ids, step,
+                     pos, max_steps, npos);
+  G4R_CHECK_LAUNCH("batch_advance_ragged");
   return G4R_OK;
 }
 

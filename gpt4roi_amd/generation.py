@@ -96,13 +96,15 @@ class SamplingConfig:
         return (float(self.temperature), k, float(self.top_p))
 
 
-def check_right_padded(attention_mask):
-    """The decoder kernels are causal and position-indexed from 0: a batch may be right-padded (the collator pads on
-    the right and masks the pad labels with -100, data_modules.py:22-56) but not left-padded.  Raises otherwise instead
-    of silently attending to pad tokens.  One small device->host read, batches of more than one row only."""
-    if attention_mask is None or attention_mask.dim() != 2 or attention_mask.size(0) == 1 and bool(attention_mask.all()):
-        return
+def dense_or_mask(attention_mask):
+    """Training batches: None when the mask is absent, all ones or RIGHT-padded (what the collator produces,
+    data_modules.py:22-56) -- causal attention already hides the pad keys from every real row and the pad rows carry no
+    loss (labels -100), so the dense kernels give the reference's logits on the real rows and its gradients; any other
+    pattern (left padding, holes) is returned as a bool mask for the unpad -> varlen -> pad path the reference's
+    flash-attention patch takes (llama_flash_attn_monkey_patch.py:60-85).  One small device->host read."""
+    if attention_mask is None or attention_mask.dim() != 2:
+        return None
     m = attention_mask.to(torch.bool)
-    if m.size(1) > 1 and not bool((m[:, :-1] | ~m[:, 1:]).all()):
-        raise ValueError("attention_mask must be all ones or right-padded: left padding / holes are not supported by the "
-                         "position-indexed KV cache of this path")
+    if m.size(1) <= 1 or bool((m[:, :-1] | ~m[:, 1:]).all()):
+        return None
+    return m

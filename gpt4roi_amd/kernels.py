@@ -24,6 +24,9 @@ _SIGS = {
     "g4r_gemv_rmsnorm_bf16": [P, P, c_float, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "g4r_attn_decode_bf16": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_long, c_long, c_float, c_int, P, c_int,
                              c_int, c_long, c_long, c_long, c_long, P],
+    "g4r_attn_decode_ragged_bf16": [P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, c_int, P, P, c_int,
+                                    c_long, c_long, c_long, c_long, P],
+    "g4r_batch_advance_ragged": [P, c_int, P, P, P, P, P, c_int, c_int, P],
     "g4r_gemv_attn_merge_bf16": [P, c_int, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "g4r_flash_attn_bwd_bf16": [P] * 10 + [c_int] * 5 + [c_long] * 16 + [c_float, c_int, P],
     "g4r_rmsnorm_bwd_bf16": [P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_long, c_long, c_float, P],
@@ -596,13 +599,15 @@ class DecodeAttnWorkspace:
 
 
 def attn_decode(q, k, v, heads, scale, work, kv_len_dev=None, kv_len=None, out=None, qkv=None, cos=None, sin=None,
-                defer_merge=False):
+                defer_merge=False, kv_lens_dev=None, rope_pos_dev=None):
     """One query row per sequence against its KV cache.  Single sequence: q [heads*D] (any shape with that many elements),
     k/v [T_max, heads*D] row-strided views.  Batch of B equal-length sequences: q [B, heads*D] (or qkv [B, 3*heads*D]),
     k/v [B, T_max, heads*D] views -> out [B, heads*D].  Attends the first *kv_len_dev + 1 (or kv_len) rows.
     qkv (instead of q): the raw q|k|v projection rows of the new tokens -- RoPE (cos/sin tables) and the cache append at row
     kv_len - 1 happen inside the launch (rope_qkv + attention in one).
-    defer_merge (single sequence): returns None; the per-split partials stay in work.ws for gemv_attn_merge (the o_proj)."""
+    defer_merge (single sequence): returns None; the per-split partials stay in work.ws for gemv_attn_merge (the o_proj).
+    kv_lens_dev (int32 [B], with qkv): RAGGED batch -- sequence b attends its first kv_lens_dev[b] + 1 rows and appends at
+    row kv_lens_dev[b]; rope_pos_dev (int32 [1]) = the RoPE position of the new tokens (the padded-layout position)."""
     dt = _h16(q, k, v, qkv)
     batched = k.dim() == 3
     B = k.size(0) if batched else 1
@@ -615,12 +620,20 @@ def attn_decode(q, k, v, heads, scale, work, kv_len_dev=None, kv_len=None, out=N
     if qkv is not None:
         _f32(cos, sin)
         assert cos.size(1) == D // 2 and cos.is_contiguous()
-    assert kv_len_dev is not None or kv_len is not None
+    assert kv_len_dev is not None or kv_len is not None or kv_lens_dev is not None
     assert not (defer_merge and batched)
     if out is None and not defer_merge:
         out = torch.empty((B, HD) if batched else HD, dtype=dt, device=k.device)
     if out is not None:
         assert out.numel() == B * HD and out.is_contiguous()
+    if kv_lens_dev is not None:
+        assert qkv is not None and batched and kv_lens_dev.dtype == torch.int32 and kv_lens_dev.numel() >= B
+        assert rope_pos_dev is None or rope_pos_dev.dtype == torch.int32
+        _launch("g4r_attn_decode_ragged_bf16", (_p(qkv), _p(cos), _p(sin), _p(k), _p(v), _p(out), _p(work.ws), _p(work.cnt),
+                                                heads, D, k.stride(-2), v.stride(-2), float(scale), work.splits,
+                                                _p(kv_lens_dev), _p(rope_pos_dev), B, src.numel() // B, k.stride(0),
+                                                v.stride(0), HD, _stream(k),), tag=f"attn_decode<{D}>", dt=dt)
+        return out
     _launch("g4r_attn_decode_bf16", (_p(q), _p(qkv), _p(cos), _p(sin), _p(k), _p(v), _p(out), _p(work.ws), _p(work.cnt),
                                      heads, D, int(kv_len or 0), k.stride(-2), v.stride(-2), float(scale), work.splits,
                                      _p(kv_len_dev), int(bool(defer_merge)), B, src.numel() // B,
@@ -837,10 +850,16 @@ def greedy_advance(logits_row, tok, out_ids, step, pos):
 
 
 def batch_advance(nxt, tok, tok32, out_ids, step, pos):
-    """tok[b] = tok32[b] = nxt[b]; out_ids[b, step[0]] = nxt[b]; step += 1; pos += 1 -- the batched greedy step."""
+    """tok[b] = tok32[b] = nxt[b]; out_ids[b, step[0]] = nxt[b]; step += 1; pos += 1 -- the batched greedy step.
+    pos with more than one element (ragged batch: B cache lengths + the RoPE position): every counter advances."""
     B = nxt.numel()
     assert nxt.dtype == torch.int64 and tok.dtype == torch.int64 and tok32.dtype == torch.int32 and out_ids.dtype == torch.int64
     assert tok.numel() == B and tok32.numel() == B and out_ids.dim() == 2 and out_ids.size(0) == B and out_ids.is_contiguous()
+    if pos.numel() > 1:
+        assert pos.dtype == torch.int32 and pos.is_contiguous()
+        _launch("g4r_batch_advance_ragged", (_p(nxt), B, _p(tok), _p(tok32), _p(out_ids), _p(step), _p(pos), pos.numel(),
+                                             out_ids.size(1), _stream(nxt),))
+        return
     _launch("g4r_batch_advance", (_p(nxt), B, _p(tok), _p(tok32), _p(out_ids), _p(step), _p(pos), out_ids.size(1),
                                   _stream(nxt),))
 
@@ -943,8 +962,8 @@ def roi_align_mlvl(feats, rois, output_size, scales, sampling_ratio=2, aligned=T
 
 
 # ---- training rows (include/g4r_train.h) ------------------------------------------------------------------
-def flash_attn_bwd(q, k, v, o, do, lse, heads, scale, causal=True):
-    """-> dq, dk, dv (bf16, [B, T, heads*D] contiguous)."""
+def flash_attn_bwd(q, k, v, o, do, lse, heads, scale, causal=True, out=None):
+    """-> dq, dk, dv (bf16, [B, T, heads*D] contiguous; or written into the three row-strided views of `out`)."""
     _bf16(q, k, v, o, do)
     _f32(lse)
     B, Tq, HD = q.shape
@@ -952,9 +971,15 @@ def flash_attn_bwd(q, k, v, o, do, lse, heads, scale, causal=True):
     D = HD // heads
     for t in (q, k, v, o, do):
         assert t.stride(2) == 1
-    dq = torch.empty((B, Tq, HD), dtype=torch.bfloat16, device=q.device)
-    dk = torch.empty((B, Tk, HD), dtype=torch.bfloat16, device=q.device)
-    dv = torch.empty((B, Tk, HD), dtype=torch.bfloat16, device=q.device)
+    if out is not None:
+        dq, dk, dv = out
+        _bf16(dq, dk, dv)
+        assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
+        assert dq.stride(2) == 1 and dk.stride(2) == 1 and dv.stride(2) == 1
+    else:
+        dq = torch.empty((B, Tq, HD), dtype=torch.bfloat16, device=q.device)
+        dk = torch.empty((B, Tk, HD), dtype=torch.bfloat16, device=q.device)
+        dv = torch.empty((B, Tk, HD), dtype=torch.bfloat16, device=q.device)
     delta = torch.empty((B, heads, Tq), dtype=torch.float32, device=q.device)
     _launch("g4r_flash_attn_bwd_bf16", (
         _p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, heads, Tq, Tk, D,

@@ -16,6 +16,50 @@ import torch
 from . import kernels as K
 
 
+class RaggedLayout:
+    """Which positions of a padded [B, T] batch are real tokens, as the index sets the kernels consume.
+
+    The reference's training attention unpads the batch with the mask, runs varlen flash attention over the kept tokens and
+    pads the result back with zeros (llava/train/llama_flash_attn_monkey_patch.py:60-85: unpad_input -> cu_seqlens ->
+    pad_input); its serving path hands the same mask to HF's LlamaModel (llava/model/llava.py:263-283).  Here the kept rows
+    are gathered into one packed [nnz, C] buffer (sequence b = rows cu[b]:cu[b+1], order preserved = the causal order),
+    attention runs per sequence on views of it, and `inv` scatters the result back (pad rows = zero rows).  RoPE has
+    already been applied at the positions of the PADDED layout, as the reference applies it before unpadding (:46-50).
+    Building the layout reads the mask once on the host (B lengths)."""
+
+    def __init__(self, mask, max_positions):
+        m = mask.to(torch.bool)
+        assert m.dim() == 2
+        B, T = m.shape
+        dev = m.device
+        keep = torch.nonzero(m.reshape(-1)).view(-1)
+        self.B, self.T = B, T
+        self.lens = [int(n) for n in m.sum(1).tolist()]
+        self.cu = [0]
+        for n in self.lens:
+            self.cu.append(self.cu[-1] + n)
+        self.nnz = self.cu[-1]
+        b = torch.div(keep, T, rounding_mode="floor")
+        self.idx = keep.to(torch.int32).contiguous()                                     # row of the [B*T, C] activations
+        self.idx_cache = (b * max_positions + (keep - b * T)).to(torch.int32).contiguous()   # row of a layer's [B_alloc*maxpos, C] cache
+        inv = torch.full((B * T,), -1, dtype=torch.int32, device=dev)
+        inv[keep] = torch.arange(self.nnz, dtype=torch.int32, device=dev)
+        self.inv = inv                                                                   # padded row -> packed row (-1: pad)
+        keep_h = keep.tolist()
+        self.last = torch.tensor([keep_h[self.cu[i + 1] - 1] if self.lens[i] else -1 for i in range(B)], dtype=torch.int32,
+                                 device=dev)                                             # padded row of each sequence's last token
+
+    @staticmethod
+    def of(mask, max_positions):
+        """None for `no mask` / all ones (the dense path), a layout otherwise."""
+        if mask is None:
+            return None
+        m = mask.to(torch.bool)
+        if bool(m.all()):
+            return None
+        return RaggedLayout(m, max_positions)
+
+
 class LlamaDecoder:
     def __init__(self, state_dict, heads, eps=1e-6, theta=10000.0, max_positions=2048, device="cuda",
                  num_layers=None, max_batch=1, dtype=torch.bfloat16):
@@ -67,6 +111,7 @@ class LlamaDecoder:
         self.kc = torch.zeros((L, batch, self.max_positions, self.hidden), dtype=self.dtype, device=self.device)
         self.vc = torch.zeros_like(self.kc)
         self.pos = 0
+        self.ragged = None             # RaggedLayout of the prompt in the cache (pad rows squeezed out), or None
         self._dstate = None            # a captured decode graph points into the old cache
         self._bstate = None
 
@@ -74,14 +119,71 @@ class LlamaDecoder:
         if self.kc.size(1) < batch:
             self._alloc_cache(batch)
         self.pos = 0
+        self.ragged = None
+
+    def _attn_ragged(self, li, q, rag, want_lse=False, compact=False):
+        """Causal attention of a masked batch (see RaggedLayout): q [B, T, C] rotated, K/V of this layer already in the
+        cache at the padded positions.  -> (a [B, T, C] with zero pad rows, packed operands for the backward).
+        compact: each sequence's kept K/V rows move to the front of its cache slot (rows [0, n_b)), which is what the
+        ragged decode launch continues from."""
+        B, T, C = q.shape
+        H, D = self.heads, self.head_dim
+        scale = 1.0 / math.sqrt(D)
+        qp = K.gather_rows(q.view(B * T, C), rag.idx)
+        kp = K.gather_rows(self.kc[li].view(-1, C), rag.idx_cache)
+        vp = K.gather_rows(self.vc[li].view(-1, C), rag.idx_cache)
+        ap = torch.empty_like(qp)
+        lses = []
+        for b in range(B):
+            lo, hi = rag.cu[b], rag.cu[b + 1]
+            if hi == lo:
+                lses.append(None)
+                continue
+            lse = torch.empty((1, H, hi - lo), dtype=torch.float32, device=q.device) if want_lse else None
+            K.flash_attn(qp[lo:hi][None], kp[lo:hi][None], vp[lo:hi][None], H, scale, True, out=ap[lo:hi][None], lse=lse)
+            lses.append(lse)
+            if compact:
+                self.kc[li, b, :hi - lo].copy_(kp[lo:hi])
+                self.vc[li, b, :hi - lo].copy_(vp[lo:hi])
+        a = K.gather_rows(ap, rag.inv).view(B, T, C)
+        return a, dict(qp=qp, kp=kp, vp=vp, ap=ap, lses=lses)
+
+    def _attn_ragged_bwd(self, pk, da, rag):
+        """Backward of `_attn_ragged`: da [B, T, C] -> dq, dk, dv [B, T, C] (zero pad rows)."""
+        B, T, C = da.shape
+        H = self.heads
+        scale = 1.0 / math.sqrt(self.head_dim)
+        dap = K.gather_rows(da.reshape(B * T, C), rag.idx)
+        dqp, dkp, dvp = torch.empty_like(dap), torch.empty_like(dap), torch.empty_like(dap)
+        for b in range(B):
+            lo, hi = rag.cu[b], rag.cu[b + 1]
+            if hi == lo:
+                continue
+            K.flash_attn_bwd(pk['qp'][lo:hi][None], pk['kp'][lo:hi][None], pk['vp'][lo:hi][None], pk['ap'][lo:hi][None],
+                             dap[lo:hi][None], pk['lses'][b], H, scale, True,
+                             out=(dqp[lo:hi][None], dkp[lo:hi][None], dvp[lo:hi][None]))
+        return tuple(K.gather_rows(t, rag.inv).view(B, T, C) for t in (dqp, dkp, dvp))
 
     @torch.no_grad()
-    def forward(self, inputs_embeds, all_logits=True, return_hidden=False):
+    def forward(self, inputs_embeds, all_logits=True, return_hidden=False, key_padding_mask=None):
         """inputs_embeds [B,T,C] bf16, appended at the current cache position.  Returns logits fp32
-        [B,T,V] (all_logits) or [B,1,V] (last position only)."""
+        [B,T,V] (all_logits) or [B,1,V] (last position only).
+        key_padding_mask (bool [B,T], True = real token; with the PROMPT only): any mask -- right / left padding, holes.
+        Masked keys are attended by nobody, masked query rows leave attention as zeros, positions are those of the padded
+        layout (RaggedLayout); the kept K/V rows are squeezed to the front of each cache slot, later one-token calls continue
+        every sequence at its own length, and `all_logits=False` returns each sequence's LAST KEPT position."""
         B, T, C = inputs_embeds.shape
         assert self.pos + T <= self.max_positions and B <= self.kc.size(1)
         H, D, pos0 = self.heads, self.head_dim, self.pos
+        rag = RaggedLayout.of(key_padding_mask, self.max_positions)
+        if rag is not None:
+            assert pos0 == 0 and T > 1 and (rag.B, rag.T) == (B, T), "a padding mask enters with the prompt (empty cache)"
+            self.ragged = rag
+            self._rag_pos = torch.tensor(rag.lens + [T], dtype=torch.int32, device=inputs_embeds.device)
+        elif pos0 == 0:
+            self.ragged = None
+        elif self.ragged is not None:
+            assert T == 1, "after a masked prompt the sequences continue one token at a time"
         x = inputs_embeds.reshape(B * T, C)
         if x.dtype != self.dtype:
             x = x.to(self.dtype)
@@ -95,8 +197,13 @@ class LlamaDecoder:
             if T == 1:                                       # decode step: RoPE + cache append + split-key attention,
                 qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
                 a = torch.empty_like(q)                      # one launch for the B sequences of the batch
-                K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, self._attn_work(B), kv_len=pos0 + 1,
-                              out=a.view(B, C), qkv=qkv.view(B, 3 * C), cos=self.cos, sin=self.sin)
+                if self.ragged is not None:                  # every sequence at its own length, RoPE at the padded position
+                    K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, self._attn_work(B), out=a.view(B, C),
+                                  qkv=qkv.view(B, 3 * C), cos=self.cos, sin=self.sin, kv_lens_dev=self._rag_pos[:B],
+                                  rope_pos_dev=self._rag_pos[B:])
+                else:
+                    K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, self._attn_work(B), kv_len=pos0 + 1,
+                                  out=a.view(B, C), qkv=qkv.view(B, 3 * C), cos=self.cos, sin=self.sin)
             else:
                 # prefill: RoPE and the cache append ride in the projection's epilogue (one launch instead of 1 + B)
                 if K.gemm_qkv_rope(h, L['wqkv'], B, T, H, D, q, self.kc[li, :B], self.vc[li, :B], self.cos, self.sin,
@@ -104,7 +211,10 @@ class LlamaDecoder:
                     qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
                     for b in range(B):
                         K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, pos0)
-                a = K.flash_attn(q, self.kc[li, :B, :pos0 + T], self.vc[li, :B, :pos0 + T], H, scale, True)
+                if rag is not None:
+                    a, _ = self._attn_ragged(li, q, rag, compact=True)
+                else:
+                    a = K.flash_attn(q, self.kc[li, :B, :pos0 + T], self.vc[li, :B, :pos0 + T], H, scale, True)
             x = K.gemm(a.view(B * T, C), L['wo'], residual=x)
             h = K.rmsnorm(x, L['n2'], self.eps)
             f = K.gemm(h, L['wgu'], act="swiglu")            # gate|up GEMM with the SiLU*up epilogue
@@ -119,11 +229,13 @@ class LlamaDecoder:
                 x = K.gemm(f, L['wd'], residual=x)
                 h = None
         self.pos = pos0 + T
+        if T == 1 and self.ragged is not None:
+            self._rag_pos += 1
         xn = (h if h is not None else K.rmsnorm(x, self.norm, self.eps)).view(B, T, C)
         if return_hidden:
             return xn
         if not all_logits:
-            xn = xn[:, -1:, :].contiguous()
+            xn = K.gather_rows(xn.view(B * T, C), rag.last).view(B, 1, C) if rag is not None else xn[:, -1:, :].contiguous()
         logits = K.gemm(xn.reshape(-1, C), self.lm_head, out_dtype=torch.float32)
         return logits.view(B, -1, self.vocab)
 
@@ -206,8 +318,9 @@ class LlamaDecoder:
             sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = L['n1'], L['n2']
         return {k: v.detach().clone() for k, v in sd.items()}
 
-    def _layer_forward_train(self, li, x, B, T):
-        """One decoder layer of `forward_train`: x [B*T, C] -> (x_out, everything its backward reads)."""
+    def _layer_forward_train(self, li, x, B, T, rag=None):
+        """One decoder layer of `forward_train`: x [B*T, C] -> (x_out, everything its backward reads).
+        rag: RaggedLayout of a masked batch (the reference's unpad -> varlen attention -> pad_input) or None."""
         if self.unit_hook is not None:
             self.unit_hook("fwd_pre", li)
         L = self.layers[li]
@@ -219,22 +332,29 @@ class LlamaDecoder:
             qkv = K.gemm(h, L['wqkv']).view(B, T, 3 * C)
             for b in range(B):
                 K.rope_qkv(qkv[b], self.cos, self.sin, q[b], self.kc[li, b], self.vc[li, b], H, D, 0)
-        lse = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
-        a = K.flash_attn(q, self.kc[li, :B, :T], self.vc[li, :B, :T], H, 1.0 / math.sqrt(D), True, lse=lse)
+        pk = lse = None
+        if rag is not None:
+            a, pk = self._attn_ragged(li, q, rag, want_lse=True)
+        else:
+            lse = torch.empty((B, H, T), dtype=torch.float32, device=x.device)
+            a = K.flash_attn(q, self.kc[li, :B, :T], self.vc[li, :B, :T], H, 1.0 / math.sqrt(D), True, lse=lse)
         x1 = K.gemm(a.view(B * T, C), L['wo'], residual=x)
         h2 = K.rmsnorm(x1, L['n2'], self.eps)
         gu = K.gemm(h2, L['wgu'])
         f = K.swiglu_il(gu)
         x2 = K.gemm(f, L['wd'], residual=x1)
-        rec = dict(x=x, q=q, a=a, lse=lse, x1=x1, gu=gu)
+        rec = dict(x=x, q=q, a=a, lse=lse, x1=x1, gu=gu, pk=pk)
         if self.train_weights:
             rec.update(h=h, h2=h2, f=f)
         if self.unit_hook is not None:
             self.unit_hook("fwd_post", li)
         return x2, rec
 
-    def forward_train(self, inputs_embeds, checkpoint=False):
-        """inputs_embeds [B,T,C] bf16 at positions 0..T-1 -> (logits fp32 [B*T, V], ctx).  Same kernels as
+    def forward_train(self, inputs_embeds, checkpoint=False, key_padding_mask=None):
+        """inputs_embeds [B,T,C] bf16 at positions 0..T-1 -> (logits fp32 [B*T, V], ctx).  key_padding_mask (bool [B,T]):
+        the `attention_mask` the reference's flash-attention patch unpads with (llama_flash_attn_monkey_patch.py:60-85), any
+        pattern; a right-padded batch may also come without it (causal attention hides the pad keys from the real rows and
+        the pad rows carry no loss: same logits on the real rows, same gradients).  Same kernels as
         `forward` except that the gate|up GEMM keeps its pre-activation output for the SwiGLU backward and
         the attention kernel also returns the log-sum-exp.
         checkpoint=True (`--gradient_checkpointing True`, train_stage1.sh:36; torch.utils.checkpoint per decoder layer in
@@ -244,15 +364,17 @@ class LlamaDecoder:
         B, T, C = inputs_embeds.shape
         assert T <= self.max_positions and B <= self.kc.size(1)
         x = inputs_embeds.reshape(B * T, C).contiguous()
+        rag = RaggedLayout.of(key_padding_mask, self.max_positions)
+        assert rag is None or (rag.B, rag.T) == (B, T)
         saved = []
         for li in range(len(self.layers)):
-            x2, rec = self._layer_forward_train(li, x, B, T)
+            x2, rec = self._layer_forward_train(li, x, B, T, rag)
             saved.append(dict(x=x) if checkpoint else rec)
             x = x2
         xn = K.rmsnorm(x, self.norm, self.eps)
         logits = K.gemm(xn, self.lm_head, out_dtype=torch.float32)
         self.pos = T
-        return logits, dict(B=B, T=T, saved=saved, x_final=x, xn=xn, checkpoint=checkpoint)
+        return logits, dict(B=B, T=T, saved=saved, x_final=x, xn=xn, checkpoint=checkpoint, rag=rag)
 
     def backward(self, ctx, dlogits, on_grad=None):
         """dlogits bf16 [B*T, v_pad] (zero in the pad columns) -> d(inputs_embeds) [B*T, C] bf16.
@@ -283,7 +405,7 @@ class LlamaDecoder:
             L, S = self.layers[li], ctx["saved"][li]
             if ctx.get("checkpoint"):
                 hook, self.unit_hook = self.unit_hook, None               # (the recompute runs inside this layer's gather)
-                _, S = self._layer_forward_train(li, S['x'], B, T)        # recompute (also re-fills this layer's K/V)
+                _, S = self._layer_forward_train(li, S['x'], B, T, ctx.get("rag"))   # recompute (also re-fills this layer's K/V)
                 self.unit_hook = hook
             df = K.gemm(dx, L['wd_t'])
             dgu = K.swiglu_il_bwd(S['gu'], df)
@@ -295,8 +417,11 @@ class LlamaDecoder:
                 grads[f"{li}.n1"] = torch.zeros_like(L['n1'])
             dx1 = K.rmsnorm_bwd(S['x1'], L['n2'], dh2, dres=dx, dgamma=grads.get(f"{li}.n2"), eps=self.eps)
             da = K.gemm(dx1, L['wo_t']).view(B, T, C)
-            dq, dk, dv = K.flash_attn_bwd(S['q'], self.kc[li, :B, :T], self.vc[li, :B, :T], S['a'], da, S['lse'], H,
-                                          scale, True)
+            if ctx.get("rag") is not None:
+                dq, dk, dv = self._attn_ragged_bwd(S['pk'], da, ctx["rag"])
+            else:
+                dq, dk, dv = K.flash_attn_bwd(S['q'], self.kc[li, :B, :T], self.vc[li, :B, :T], S['a'], da, S['lse'], H,
+                                              scale, True)
             dqkv = torch.empty((B * T, 3 * C), dtype=torch.bfloat16, device=dq.device)
             for b in range(B):                               # every sequence's rows written in place (no concatenation pass)
                 K.rope_qkv_bwd(dq[b], dk[b], dv[b], self.cos, self.sin, H, D, 0, out=dqkv[b * T:(b + 1) * T])
@@ -468,8 +593,12 @@ class LlamaDecoder:
         for li, L in enumerate(self.layers):
             h = K.rmsnorm(x, L['n1'], self.eps)
             qkv = K.gemm(h, L['wqkv'])
-            a = K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, work, kv_len_dev=st["pos"], qkv=qkv,
-                              cos=self.cos, sin=self.sin)
+            if st.get("ragged"):            # pos = [B cache lengths | RoPE position], all advanced by batch_advance
+                a = K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, work, qkv=qkv, cos=self.cos,
+                                  sin=self.sin, kv_lens_dev=st["pos"][:B], rope_pos_dev=st["pos"][B:])
+            else:
+                a = K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, work, kv_len_dev=st["pos"], qkv=qkv,
+                                  cos=self.cos, sin=self.sin)
             x = K.gemm(a, L['wo'], residual=x)
             h = K.rmsnorm(x, L['n2'], self.eps)
             f = K.gemm(h, L['wgu'], act="swiglu")
@@ -478,29 +607,38 @@ class LlamaDecoder:
         K.batch_advance(K.argmax_rows(logits), st["tok"], st["tok32"], st["out"], st["step"], st["pos"])
 
     @torch.no_grad()
-    def decode_graph_batch(self, inputs_embeds, max_new_tokens, stop_ids=(), use_graph=True):
-        """generate(do_sample=False) for B sequences with prompts of EQUAL length, per-token loop on the device: prefill
+    def decode_graph_batch(self, inputs_embeds, max_new_tokens, stop_ids=(), use_graph=True, key_padding_mask=None):
+        """generate(do_sample=False) for B sequences, per-token loop on the device.  Prompts of equal length, or -- with
+        key_padding_mask (bool [B, T]) -- prompts padded to a common T on either side (HF batch generation pads on the
+        left; merged serving requests of different lengths pad on the right): see `forward`.  Prefill
         eagerly, then one captured hipGraph replay per step for the whole batch (token ids, position and output slots stay
         in device memory).  The 13.2 GB weight stream of a step is shared by the B sequences -- the throughput mode of
         SURVEY.md 8d config 5.  Sequences that hit a stop id keep running; their later tokens are cut from the result.
         Returns a list of B id lists (same ids as greedy_batch, the host-loop form)."""
         B = inputs_embeds.size(0)
         self.reset(B)
-        logits = self.forward(inputs_embeds, all_logits=False)
+        logits = self.forward(inputs_embeds, all_logits=False, key_padding_mask=key_padding_mask)
         T = self.pos
         assert T + max_new_tokens <= self.max_positions
         dev = inputs_embeds.device
-        bs = getattr(self, "_bstate", None)
-        if bs is None or bs["B"] != B or bs["out"].size(1) < max_new_tokens:
+        ragged = self.ragged is not None
+        pool = getattr(self, "_bstate", None)
+        if pool is None:
+            pool = self._bstate = {}
+        bs = pool.get((B, ragged))
+        if bs is None or bs["out"].size(1) < max_new_tokens:
             cap = max(64, 1 << (max_new_tokens - 1).bit_length())      # output slots: the captured graph knows this stride
             with torch.inference_mode(False):
-                bs = self._bstate = dict(B=B, tok=torch.zeros(B, dtype=torch.int64, device=dev),
-                                         tok32=torch.zeros(B, dtype=torch.int32, device=dev),
-                                         out=torch.zeros((B, cap), dtype=torch.int64, device=dev),
-                                         pos=torch.zeros(1, dtype=torch.int32, device=dev),
-                                         step=torch.zeros(1, dtype=torch.int32, device=dev), graph=None)
+                bs = pool[(B, ragged)] = dict(B=B, ragged=ragged, tok=torch.zeros(B, dtype=torch.int64, device=dev),
+                                              tok32=torch.zeros(B, dtype=torch.int32, device=dev),
+                                              out=torch.zeros((B, cap), dtype=torch.int64, device=dev),
+                                              pos=torch.zeros(B + 1 if ragged else 1, dtype=torch.int32, device=dev),
+                                              step=torch.zeros(1, dtype=torch.int32, device=dev), graph=None)
         st = bs
-        st["pos"].fill_(T - 1)
+        if ragged:
+            st["pos"].copy_(self._rag_pos - 1)                          # [n_b - 1 ..., T - 1]: the advance below moves them on
+        else:
+            st["pos"].fill_(T - 1)
         st["step"].zero_()
         K.batch_advance(K.argmax_rows(logits.view(B, -1)), st["tok"], st["tok32"], st["out"], st["step"], st["pos"])
         done = 1
@@ -528,14 +666,15 @@ class LlamaDecoder:
         return res
 
     @torch.no_grad()
-    def greedy_batch(self, inputs_embeds, max_new_tokens, stop_ids=()):
-        """generate(do_sample=False) for B sequences with prompts of EQUAL length (the reference stacks its samples,
+    def greedy_batch(self, inputs_embeds, max_new_tokens, stop_ids=(), key_padding_mask=None):
+        """generate(do_sample=False) for B sequences with prompts of EQUAL length, or padded to one length under
+        key_padding_mask (see `forward`; the reference stacks its samples,
         spi_llava.py:196, so a batch always has one T): one decoder pass per step for the whole batch, i.e. the
         13.5 GB weight stream of a decode step is shared by B sequences.  Sequences that hit a
         stop id keep running (their later tokens are cut from the result).  Returns a list of B id lists."""
         B = inputs_embeds.size(0)
         self.reset(B)
-        logits = self.forward(inputs_embeds, all_logits=False)
+        logits = self.forward(inputs_embeds, all_logits=False, key_padding_mask=key_padding_mask)
         assert self.pos + max_new_tokens <= self.max_positions
         out = torch.empty((B, max_new_tokens), dtype=torch.int64, device=inputs_embeds.device)
         for s in range(max_new_tokens):

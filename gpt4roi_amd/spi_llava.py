@@ -39,7 +39,7 @@ import torch.nn as nn
 
 from . import kernels as K
 from .generation import (KeywordsStoppingCriteria, SamplingConfig, StoppingCriteria,  # noqa: F401 (re-exported)
-                         check_right_padded, prepare_inputs_for_generation)
+                         dense_or_mask, prepare_inputs_for_generation)
 from .layers import MLVLROIQueryModule, PreparedBoxes
 from .llama import LlamaDecoder
 from .vit import ClipVisionTower
@@ -75,9 +75,9 @@ class _RegionPathFn(torch.autograd.Function):
     region-module / projector parameter gradients, returned to autograd in the order the parameters were passed."""
 
     @staticmethod
-    def forward(ctx, model, input_ids, images, bboxes, names, *params):
+    def forward(ctx, model, input_ids, images, bboxes, attention_mask, names, *params):
         with torch.no_grad():
-            logits, pctx = model.forward_train(input_ids, images, bboxes)
+            logits, pctx = model.forward_train(input_ids, images, bboxes, attention_mask=attention_mask)
         ctx.model, ctx.pctx, ctx.names = model, pctx, names
         ctx.shape = (input_ids.size(0), input_ids.size(1))
         return logits.view(input_ids.size(0), input_ids.size(1), -1)
@@ -91,7 +91,7 @@ class _RegionPathFn(torch.autograd.Function):
             dl[:, :dec.vocab] = dlogits.reshape(B * T, dec.vocab)
             grads = model.backward(ctx.pctx, dl, train_projector=any(n.startswith("mm_projector.") for n in ctx.names))
         ctx.pctx = None
-        return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
+        return (None, None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
 
 class _ShiftedCrossEntropyFn(torch.autograd.Function):
@@ -247,9 +247,11 @@ class SPILlavaLlamaModel(nn.Module):
 
     # ---- training rows: the forward that keeps what the backward needs, and that backward ----------------------
     @torch.no_grad()
-    def forward_train(self, input_ids, images, bboxes):
+    def forward_train(self, input_ids, images, bboxes, attention_mask=None):
         """-> (logits fp32 [B*T, V], ctx).  Raises on a malformed prompt (per-sample <bbox>/region count,
-        <im_start>/<im_end>) exactly where the reference does (spi_llava.py:115-157)."""
+        <im_start>/<im_end>) exactly where the reference does (spi_llava.py:115-157).  attention_mask: the collator's
+        key padding mask (data_modules.py:22-56), handed to the decoder as the reference's flash-attention patch receives it
+        (llama_flash_attn_monkey_patch.py:60-85); right padding takes the dense path (same real rows, same gradients)."""
         self._maybe_prepare()
         cfg = self.config
         B, T = input_ids.shape
@@ -276,7 +278,8 @@ class SPILlavaLlamaModel(nn.Module):
         if not hasattr(self.llama, "lm_head_t"):
             self.llama.prepare_training(train_weights=False)
         self.llama.reset(B)
-        logits, lctx = self.llama.forward_train(embeds, checkpoint=self.gradient_checkpointing)
+        logits, lctx = self.llama.forward_train(embeds, checkpoint=self.gradient_checkpointing,
+                                                key_padding_mask=dense_or_mask(attention_mask))
         return logits, dict(sctx=sctx, lctx=lctx, input_ids=input_ids, boxes=bboxes, image_features=image_features)
 
     @torch.no_grad()
@@ -329,18 +332,20 @@ class SPILlavaLlamaModel(nn.Module):
                 use_cache: Optional[bool] = None, output_attentions: Optional[bool] = None,
                 output_hidden_states: Optional[bool] = None, images: Optional[torch.Tensor] = None,
                 return_dict: Optional[bool] = None, all_logits=True):
-        check_right_padded(attention_mask)
         if torch.is_grad_enabled() and inputs_embeds is None and images is not None and input_ids.size(1) != 1:
             named = self.trainable_named()
             if named:
                 names = tuple(named)
-                return _RegionPathFn.apply(self, input_ids, images, bboxes, names, *named.values())
+                return _RegionPathFn.apply(self, input_ids, images, bboxes, attention_mask, names, *named.values())
         with torch.no_grad():
             if inputs_embeds is None:
                 inputs_embeds = self.embed_inputs(input_ids, images, bboxes)
             if past_key_values is None:
                 self.llama.reset(inputs_embeds.size(0))
-            return self.llama.forward(inputs_embeds, all_logits=all_logits)
+            # the prompt's mask: any pattern (HF LlamaModel semantics: masked keys unseen, positions of the padded layout);
+            # on the later one-token calls HF's mask only grows by ones, which the ragged cache already encodes
+            mask = attention_mask if (past_key_values is None and inputs_embeds.size(1) > 1) else None
+            return self.llama.forward(inputs_embeds, all_logits=all_logits, key_padding_mask=mask)
 
 
 class _EmbeddingView:
@@ -498,15 +503,20 @@ class SPILlavaMPTForCausalLM(nn.Module):
     @torch.no_grad()
     def generate(self, input_ids=None, images=None, max_new_tokens=64, do_sample=None, temperature=None, top_k=None,
                  top_p=None, stopping_criteria=None, eos_token_id=None, seed=None, bboxes=None, stop_ids=(),
-                 check_every=None, return_new_tokens=False, **_):
-        """HF-style `generate` for batch 1 (what gpt4roi/app.py:293-300 calls): prefill through `self.forward` -- so a
+                 check_every=None, return_new_tokens=False, attention_mask=None, pad_token_id=None, **_):
+        """HF-style `generate`.  Batch 1 (what gpt4roi/app.py:293-300 calls): prefill through `self.forward` -- so a
         `partial(orig_forward, img_metas=..., bboxes=...)` bound by the caller is honoured (app.py:286-291; `bboxes=`
         may also be passed here) -- then the device-resident decode loop.  do_sample=False: greedy (the parity mode);
         do_sample=True: temperature / top-k / top-p sampling on the device with a Philox stream keyed by `seed`
         (drawn from torch's generator when None).  `stopping_criteria`: callables criteria(ids [1, T+n], scores) -> bool
         evaluated per generated token like HF (KeywordsStoppingCriteria); `eos_token_id` / `stop_ids` end the sequence
-        (inclusive).  Returns the full sequence LongTensor [1, T + n] (or the list of new ids if return_new_tokens)."""
-        assert input_ids.size(0) == 1, "generate() serves one request (the reference's app is batch 1)"
+        (inclusive).  Returns the full sequence LongTensor [1, T + n] (or the list of new ids if return_new_tokens).
+        Batch B > 1 (greedy only): prompts padded to one length with `attention_mask` marking the real tokens (left padding
+        as HF batch generation uses it, or right padding) decode together, every sequence continuing from its own length
+        with the positions of the padded layout (LlamaDecoder.forward); rows that stopped are filled with pad_token_id."""
+        if input_ids.size(0) > 1:
+            return self._generate_batch(input_ids, images, max_new_tokens, do_sample, stopping_criteria, eos_token_id,
+                                        bboxes, stop_ids, return_new_tokens, attention_mask, pad_token_id)
         gc = self.generation_config
         cfg = SamplingConfig(do_sample=gc.do_sample if do_sample is None else bool(do_sample),
                              temperature=gc.temperature if temperature is None else temperature,
@@ -543,6 +553,25 @@ class SPILlavaMPTForCausalLM(nn.Module):
         if return_new_tokens:
             return new
         return torch.cat([input_ids, torch.tensor([new], dtype=input_ids.dtype, device=input_ids.device)], 1)
+
+    def _generate_batch(self, input_ids, images, max_new_tokens, do_sample, stopping_criteria, eos_token_id, bboxes,
+                        stop_ids, return_new_tokens, attention_mask, pad_token_id):
+        if (self.generation_config.do_sample if do_sample is None else do_sample) or stopping_criteria:
+            raise NotImplementedError("batched generate() is greedy and stops on ids (sampling / criteria: one request at a time)")
+        kw = dict(bboxes=bboxes) if bboxes is not None else {}
+        embeds = self._prefill_embeds(self.forward, self.prepare_inputs_for_generation(input_ids, images=images), kw)
+        stops = set(int(s) for s in stop_ids)
+        if eos_token_id is None:
+            eos_token_id = getattr(self.config, "eos_token_id", None)
+        if eos_token_id is not None:
+            stops.update([int(eos_token_id)] if not isinstance(eos_token_id, (list, tuple)) else map(int, eos_token_id))
+        new = self.model.llama.decode_graph_batch(embeds, max_new_tokens, stop_ids=stops, key_padding_mask=attention_mask)
+        if return_new_tokens:
+            return new
+        pad = pad_token_id if pad_token_id is not None else (getattr(self.config, "pad_token_id", None) or 0)
+        n = max(len(r) for r in new)
+        tail = torch.tensor([r + [pad] * (n - len(r)) for r in new], dtype=input_ids.dtype, device=input_ids.device)
+        return torch.cat([input_ids, tail], 1)
 
     def _prefill_embeds(self, fwd, model_inputs, kw):
         """The spliced prompt embeddings of step 0.  When `forward` was rebound with partial(bboxes=...) the boxes live

@@ -83,13 +83,13 @@ class RegionTrainer:
         return self.params
 
     @torch.no_grad()
-    def loss_and_grads(self, input_ids, images, bboxes, labels, exchange=False):
+    def loss_and_grads(self, input_ids, images, bboxes, labels, exchange=False, attention_mask=None):
         """One forward + backward.  exchange=True (world > 1): every gradient is handed to the bucketed reducer the
         moment its kernel sequence has been issued (`on_grad`), so a bucket's reduce-scatter + all-gather runs on the
         communication stream while the backward of the earlier layers is still executing; the returned gradients are
         then the rank-averaged views into the reducer's flat buckets."""
         m = self.model
-        logits, ctx = m.forward_train(input_ids, images, bboxes)
+        logits, ctx = m.forward_train(input_ids, images, bboxes, attention_mask=attention_mask)
         loss, dlogits = m.llama.loss_and_dlogits(logits, labels)
         on_grad = None
         live = exchange and self.reducer is not None
@@ -140,8 +140,9 @@ class RegionTrainer:
     def _all_names(self):
         return self.params.keys()
 
-    def step(self, input_ids, images, bboxes, labels, lr=None):
-        loss, grads = self.loss_and_grads(input_ids, images, bboxes, labels, exchange=self.reducer is not None)
+    def step(self, input_ids, images, bboxes, labels, lr=None, attention_mask=None):
+        loss, grads = self.loss_and_grads(input_ids, images, bboxes, labels, exchange=self.reducer is not None,
+                                          attention_mask=attention_mask)
         self.apply(grads, lr, exchanged=self.reducer is not None)
         return loss
 
@@ -263,12 +264,12 @@ class ShardedFullTrainer(FullTrainer):
         dec.refresh_transposes()
 
     @torch.no_grad()
-    def loss_and_grads(self, input_ids, images, bboxes, labels, exchange=True):
+    def loss_and_grads(self, input_ids, images, bboxes, labels, exchange=True, attention_mask=None):
         """Forward + backward; every gradient goes straight into its flat bucket (`ShardedAdamW.ready`), full buckets are
         reduce-scattered on the communication stream while the backward continues.  Returns (loss, None): the gradients
         live in the buckets, `apply()` consumes them."""
         m = self.model
-        logits, ctx = m.forward_train(input_ids, images, bboxes)
+        logits, ctx = m.forward_train(input_ids, images, bboxes, attention_mask=attention_mask)
         loss, dlogits = m.llama.loss_and_dlogits(logits, labels)
         self.sharded.reset()
         grads = m.backward(ctx, dlogits, train_projector=True, on_grad=self.sharded.ready)
@@ -286,8 +287,8 @@ class ShardedFullTrainer(FullTrainer):
         self.model.prepare()
         self.model.llama.refresh_transposes()
 
-    def step(self, input_ids, images, bboxes, labels, lr=None):
-        loss, _ = self.loss_and_grads(input_ids, images, bboxes, labels)
+    def step(self, input_ids, images, bboxes, labels, lr=None, attention_mask=None):
+        loss, _ = self.loss_and_grads(input_ids, images, bboxes, labels, attention_mask=attention_mask)
         self.apply(None, lr)
         return loss
 
@@ -378,7 +379,7 @@ class FSDPFullTrainer(FullTrainer):
             f.release(1 + li)
 
     @torch.no_grad()
-    def loss_and_grads(self, input_ids, images, bboxes, labels, exchange=True):
+    def loss_and_grads(self, input_ids, images, bboxes, labels, exchange=True, attention_mask=None):
         m, f = self.model, self.fsdp
         dec = m.llama
         f.begin_step()
@@ -388,7 +389,7 @@ class FSDPFullTrainer(FullTrainer):
         #                                                       the gathered fp32 parameters (the pool buffer may be the same
         #                                                       address as last step: the parameter stamp cannot tell)
         dec.refresh_transposes()                              # lazy: only lm_head^T, from the gathered lm_head
-        logits, ctx = m.forward_train(input_ids, images, bboxes)
+        logits, ctx = m.forward_train(input_ids, images, bboxes, attention_mask=attention_mask)
         loss, dlogits = dec.loss_and_dlogits(logits, labels)
         f.direction(-1, root=0)
         grads = m.backward(ctx, dlogits, train_projector=True, on_grad=f.grad_ready)
@@ -406,8 +407,8 @@ class FSDPFullTrainer(FullTrainer):
         total_sq = self.fsdp.step(self.lr if lr is None else lr, self.max_grad_norm)
         self.last_grad_norm = total_sq.sqrt() if total_sq is not None else None
 
-    def step(self, input_ids, images, bboxes, labels, lr=None):
-        loss, _ = self.loss_and_grads(input_ids, images, bboxes, labels)
+    def step(self, input_ids, images, bboxes, labels, lr=None, attention_mask=None):
+        loss, _ = self.loss_and_grads(input_ids, images, bboxes, labels, attention_mask=attention_mask)
         self.apply(None, lr)
         return loss
 

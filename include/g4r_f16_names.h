@@ -23,6 +23,7 @@
 #define g4r_attn2_dispatch                  g4r_attn2_dispatch_f16
 #define g4r_flash_attn_fwd_bf16             g4r_flash_attn_fwd_f16
 #define g4r_attn_decode_bf16                g4r_attn_decode_f16
+#define g4r_attn_decode_ragged_bf16         g4r_attn_decode_ragged_f16
 #define g4r_groupnorm_affine_mlvl_nhwc_bf16 g4r_groupnorm_affine_mlvl_nhwc_f16
 #define g4r_layernorm_bf16                  g4r_layernorm_f16
 #define g4r_rmsnorm_bf16                    g4r_rmsnorm_f16

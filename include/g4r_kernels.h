@@ -108,6 +108,20 @@ int g4r_attn_decode_bf16(const void* Q, const void* qkv, const float* cos_tab, c
                          long q_batch, long k_batch, long v_batch, long o_batch, void* stream);
 
 /*
+ * The same launch for a RAGGED batch -- prompts of different lengths, or a batch that carried a padding mask
+ * (HF LlamaModel with attention_mask: masked keys are never attended and positions count the padded layout; the reference
+ * reaches it through generate(), llava/model/llava.py:263-283; its training path unpads with the mask,
+ * llava/train/llama_flash_attn_monkey_patch.py:60-85).  The pad rows are squeezed out of the cache at prefill, so sequence
+ * b holds kv_lens_dev[b] rows: it attends rows [0, kv_lens_dev[b]] and appends the new token at row kv_lens_dev[b].  The
+ * RoPE position of the new tokens is *rope_pos_dev for every sequence (the padded-layout position; null: the cache row).
+ * `qkv` [batch, 3*H*head_dim] raw projection rows (always the fused form); other arguments as above.
+ */
+int g4r_attn_decode_ragged_bf16(const void* qkv, const float* cos_tab, const float* sin_tab, void* K, void* V, void* O,
+                                float* workspace, unsigned* counters, int H, int head_dim, long k_row, long v_row,
+                                float scale, int splits, const int* kv_lens_dev, const int* rope_pos_dev, int batch,
+                                long q_batch, long k_batch, long v_batch, long o_batch, void* stream);
+
+/*
  * o_proj of the decode step with the merge of the attention partials fused into its input staging:
  * C [N] = W [N, K] . a + bias + residual, a [K = H*head_dim] = the attention output assembled from
  * `partials` [H][splits][head_dim + 2] fp32 as written by g4r_attn_decode_bf16(..., defer_merge = 1).  Bit-identical to
@@ -221,6 +235,10 @@ int g4r_greedy_advance_f32(const float* logits, int N, long* tok, long* out_ids,
  * g4r_argmax_rows_f32), out_ids[b][*step] = nxt[b] (row stride max_steps), then ++*step, ++*pos -- all on the device. */
 int g4r_batch_advance(const long* nxt, int B, long* tok, int* tok32, long* out_ids, int* step, int* pos, int max_steps,
                       void* stream);
+/* Ragged batch: `pos` is an array of npos counters (the B per-sequence cache lengths and the shared RoPE position of
+ * g4r_attn_decode_ragged_bf16), every one advanced by 1. */
+int g4r_batch_advance_ragged(const long* nxt, int B, long* tok, int* tok32, long* out_ids, int* step, int* pos, int npos,
+                             int max_steps, void* stream);
 /* greedy decode: out[r] = argmax(logits[r, :N]) (lowest index on ties). */
 int g4r_argmax_rows_f32(const float* logits, long ld, int rows, int N, long* out, void* stream);
 /* y = a + b[row % brows]  ("fuse_roi_feats + pos_embedd", layers.py:328). */

@@ -39,8 +39,12 @@ def _lin(x, w, b, emulate):
     return y
 
 
-def attention(q, k, v, heads, scale, causal, emulate=False):
-    """q [B,Tq,H*D], k/v [B,Tk,H*D] -> [B,Tq,H*D]; causal: query i sees keys <= i + (Tk - Tq)."""
+def attention(q, k, v, heads, scale, causal, emulate=False, key_padding_mask=None):
+    """q [B,Tq,H*D], k/v [B,Tk,H*D] -> [B,Tq,H*D]; causal: query i sees keys <= i + (Tk - Tq).
+    key_padding_mask (bool [B,Tk], True = a real token): the arithmetic of the reference's unpad -> varlen flash attention
+    -> pad_input (llava/train/llama_flash_attn_monkey_patch.py:60-85): a masked key is attended by nobody, the order of the
+    kept tokens is the causal order, and a masked QUERY row comes back as zeros (pad_input scatters into zeros).  The
+    valid rows equal HF LlamaModel's with the same attention_mask (its additive -inf mask; llava.py:263-283 for decode)."""
     B, Tq, HD = q.shape
     Tk, D = k.shape[1], HD // heads
     qh = q.view(B, Tq, heads, D).transpose(1, 2)
@@ -50,10 +54,17 @@ def attention(q, k, v, heads, scale, causal, emulate=False):
     if causal:
         i = torch.arange(Tq, device=q.device)[:, None] + (Tk - Tq)
         s = s.masked_fill(torch.arange(Tk, device=q.device)[None, :] > i, float("-inf"))
+    if key_padding_mask is not None:
+        km = key_padding_mask.to(device=q.device, dtype=torch.bool)
+        s = s.masked_fill(~km[:, None, None, :], float("-inf"))
     m = s.max(-1, keepdim=True).values
+    m = torch.where(torch.isinf(m), torch.zeros_like(m), m)          # a row with no visible key
     e = torch.exp(s - m)
-    o = (_r(e, emulate) @ vh) / e.sum(-1, keepdim=True)
-    return o.transpose(1, 2).reshape(B, Tq, HD)
+    o = (_r(e, emulate) @ vh) / e.sum(-1, keepdim=True).clamp_min(1e-30)
+    o = o.transpose(1, 2).reshape(B, Tq, HD)
+    if key_padding_mask is not None:
+        o = o * km[:, Tk - Tq:, None].to(o.dtype)                    # queries are the last Tq positions of the mask
+    return o
 
 
 # ------------------------------------------------------------------------------------------ CLIP ViT
@@ -122,9 +133,11 @@ def rmsnorm(x, g, eps, emulate=False):
 
 
 def llama_forward(w, inputs_embeds, heads, eps=1e-6, theta=10000.0, kv_cache=None, pos0=0, emulate=False,
-                  n_layers=None, prefix="model."):
+                  n_layers=None, prefix="model.", key_padding_mask=None):
     """inputs_embeds [B,T,C] -> (final hidden [B,T,C], kv_cache).  kv_cache: list of (k, v) per
-    layer with the previously cached positions [B, pos0, C]."""
+    layer with the previously cached positions [B, pos0, C].
+    key_padding_mask: bool [B, pos0 + T] over cached + new positions (see `attention`); positions stay those of the padded
+    layout (the pinned LlamaModel numbers them arange(past, past + T) whatever the mask)."""
     B, T, C = inputs_embeds.shape
     D = C // heads
     cos, sin = (t.to(inputs_embeds.device) for t in rope_tables(pos0 + T, D, theta))   # tests may run this on the GPU
@@ -143,7 +156,7 @@ def llama_forward(w, inputs_embeds, heads, eps=1e-6, theta=10000.0, kv_cache=Non
             k = torch.cat([kv_cache[i][0], k], 1)
             v = torch.cat([kv_cache[i][1], v], 1)
         new_cache.append((k, v))
-        a = _r(attention(q, k, v, heads, 1.0 / math.sqrt(D), True, emulate), emulate)
+        a = _r(attention(q, k, v, heads, 1.0 / math.sqrt(D), True, emulate, key_padding_mask), emulate)
         x = _r(_lin(a, w[p + "self_attn.o_proj.weight"], None, emulate) + x, emulate)
         h = _r(rmsnorm(x, w[p + "post_attention_layernorm.weight"], eps, emulate), emulate)
         g = _r(_lin(h, w[p + "mlp.gate_proj.weight"], None, emulate), emulate)

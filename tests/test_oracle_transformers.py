@@ -55,6 +55,46 @@ def test_llama_matches_hf_prefill_and_cached_decode():
     torch.testing.assert_close(T.lm_logits(w, h2), want2, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("kind", ["left", "right", "holes"])
+def test_llama_with_padding_mask_matches_hf_on_the_kept_rows(kind):
+    """key_padding_mask of the oracle == HF LlamaModel with attention_mask and the pinned commit's positions
+    (arange over the padded layout, whatever the mask): prefill and one cached decode step, compared on the kept rows;
+    the masked query rows of the oracle are zeros after attention as pad_input leaves them
+    (llama_flash_attn_monkey_patch.py:60-85)."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(5)
+    cfg = LlamaConfig(vocab_size=97, hidden_size=64, intermediate_size=176, num_hidden_layers=3,
+                      num_attention_heads=4, num_key_value_heads=4, rms_norm_eps=1e-6, max_position_embeddings=64,
+                      attention_bias=False, tie_word_embeddings=False)
+    m = LlamaForCausalLM(cfg).eval()
+    w = {k: v.float() for k, v in m.state_dict().items()}
+    B, Tn = 3, 12
+    mask = torch.ones(B, Tn, dtype=torch.bool)
+    if kind == "left":
+        mask[0, :5] = False
+        mask[2, :2] = False
+    elif kind == "right":
+        mask[0, 8:] = False
+        mask[1, 11:] = False
+    else:
+        mask[0, [0, 3, 4, 9]] = False
+        mask[1, [5]] = False
+    emb = m.get_input_embeddings()(torch.randint(0, 97, (B, Tn)))
+    pos = torch.arange(Tn)[None].expand(B, Tn)
+    with torch.no_grad():
+        want = m(inputs_embeds=emb, attention_mask=mask.long(), position_ids=pos).logits
+    h, cache = T.llama_forward(w, emb, heads=4, key_padding_mask=mask)
+    got = T.lm_logits(w, h)
+    torch.testing.assert_close(got[mask], want[mask], rtol=1e-4, atol=1e-4)
+    e2 = m.get_input_embeddings()(torch.randint(0, 97, (B, 1)))
+    mask2 = torch.cat([mask, torch.ones(B, 1, dtype=torch.bool)], 1)
+    h2, _ = T.llama_forward(w, e2, heads=4, kv_cache=cache, pos0=Tn, key_padding_mask=mask2)
+    with torch.no_grad():
+        want2 = m(inputs_embeds=torch.cat([emb, e2], 1), attention_mask=mask2.long(),
+                  position_ids=torch.arange(Tn + 1)[None].expand(B, Tn + 1)).logits[:, -1:]
+    torch.testing.assert_close(T.lm_logits(w, h2), want2, rtol=1e-4, atol=1e-4)
+
+
 def test_greedy_decode_matches_hf_generate():
     from transformers import LlamaConfig, LlamaForCausalLM
     torch.manual_seed(2)

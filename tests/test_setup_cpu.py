@@ -19,7 +19,7 @@ from make_setup_golden import delta_case, stopping_cases, tokenizer_case, toy_to
 
 from gpt4roi_amd import checkpoint as ckpt  # noqa: E402
 from gpt4roi_amd import synthetic as syn  # noqa: E402
-from gpt4roi_amd.generation import (KeywordsStoppingCriteria, SamplingConfig, check_right_padded,  # noqa: E402
+from gpt4roi_amd.generation import (KeywordsStoppingCriteria, SamplingConfig, dense_or_mask,  # noqa: E402
                                     prepare_inputs_for_generation)
 from gpt4roi_amd.llama import LlamaDecoder  # noqa: E402
 from gpt4roi_amd.spi_llava import SPILlavaLlamaModel, SPILlavaMPTForCausalLM  # noqa: E402
@@ -183,10 +183,12 @@ def test_sampling_config_and_mask_validation():
         SamplingConfig(do_sample=True, temperature=0.0).sampler()
     with pytest.raises(NotImplementedError):
         SamplingConfig(do_sample=True, top_k=0, top_p=0.9).sampler()
-    check_right_padded(None)
-    check_right_padded(torch.tensor([[1, 1, 1, 0], [1, 1, 1, 1]]))
-    with pytest.raises(ValueError):
-        check_right_padded(torch.tensor([[0, 1, 1, 1], [1, 1, 1, 1]]))
+    # training batches: right padding (the collator's) rides the dense kernels, anything else is handed on as a mask
+    assert dense_or_mask(None) is None
+    assert dense_or_mask(torch.tensor([[1, 1, 1, 0], [1, 1, 1, 1]])) is None
+    m = dense_or_mask(torch.tensor([[0, 1, 1, 1], [1, 1, 1, 1]]))
+    assert m.dtype == torch.bool and m.tolist() == [[False, True, True, True], [True] * 4]
+    assert dense_or_mask(torch.tensor([[1, 0, 1, 1]])) is not None
 
 
 def test_prompt_assembly_matches_the_reference(ref):
