@@ -5,6 +5,7 @@ stream, and raises on a non-zero status.  Output tensors are allocated by the ca
 here with torch.empty (PyTorch is only the allocator / stream provider).
 """
 import ctypes
+import os
 from ctypes import c_float, c_int, c_long, c_void_p
 
 import torch
@@ -49,6 +50,9 @@ _SIGS = {
     "g4r_fuse_shuffle_bwd_nhwc_bf16": [P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P],
     "g4r_fuse_shuffle_bwd_gather_nhwc_bf16": [P, P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int,
                                               c_int, P],
+    "g4r_nhwc_pad_bf16": [P, P, c_int, c_int, c_int, c_int, c_long, P],
+    "g4r_conv3x3_wgrad_nhwc_bf16": [P, P, c_int, P, P, c_int, c_int, c_int, c_int, P, P, c_int, P],
+    "g4r_conv3x3_wgrad_nhwc_slices": [c_int, P, P, c_int, c_int, c_int, c_int],
     "g4r_nhwc_to_cm_padded_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_int, P],
     "g4r_roi_align_mlvl_nhwc_bwd_bf16": [P, c_long, c_long, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_int, P],
@@ -107,10 +111,12 @@ class _Profiler:
 
     def __init__(self):
         self.enabled = False
+        self.detail = False
         self.records = []
 
-    def start(self):
-        self.records, self.enabled = [], True
+    def start(self, detail=False):
+        """detail: GEMM / conv tags also carry the problem shape (tools/train_step_bench.py --by-shape)."""
+        self.records, self.enabled, self.detail = [], True, bool(detail)
 
     def stop(self):
         """-> {tag: dict(calls, ms, flops, bytes)}"""
@@ -333,8 +339,8 @@ def gemm_partials(a, w, splits, tile_cfg):
     n = c_int(0)
     _launch("g4r_gemm_bf16_nt_partials", (_p(a), _p(w), _p(ws), M, N, K, a.stride(0), w.stride(0), int(splits), int(tile_cfg),
                                           ctypes.byref(n), _stream(a),),
-            tag=f"gemm_bf16_nt<{TILE_NAMES.get(tile_cfg, tile_cfg)}>+splitk", flops=2.0 * M * N * K,
-            nbytes=2.0 * (M * K + N * K) + 4.0 * splits * M * N, dt=dt)
+            tag=f"gemm_bf16_nt<{TILE_NAMES.get(tile_cfg, tile_cfg)}>+splitk" + (f" {M}x{N}x{K}/{splits}" if PROFILER.detail else ""),
+            flops=2.0 * M * N * K, nbytes=2.0 * (M * K + N * K) + 4.0 * splits * M * N, dt=dt)
     return ws, n.value
 
 
@@ -466,7 +472,8 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=None, spl
         1 if out.dtype == torch.float32 else 0, splits, tile_cfg, _stream(a),),
         tag="gemv_bf16" if (M == 1 and splits == 1 and K >= 512 and K % 8 == 0) else
         ((f"gemm_bf16_nt<{TILE_NAMES.get(tile_cfg, tile_cfg)}>" + ("+splitk" if splits > 1 else "")) if K % 64 == 0
-         else "small_linear"), flops=2.0 * M * N * K, nbytes=2.0 * (M * K + N * K) + out.element_size() * M * N, dt=dt)
+         else "small_linear") + (f" {M}x{N}x{K}" if PROFILER.detail else ""),
+        flops=2.0 * M * N * K, nbytes=2.0 * (M * K + N * K) + out.element_size() * M * N, dt=dt)
     return out
 
 
@@ -519,7 +526,8 @@ def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=None, split
     _launch("g4r_conv3x3_nhwc_bf16", (
         _p(x), _p(w), _p(out), _p(bias), _p(zeros_line(x.device)), _p(workspace), B, H, W, Cin, Cout, groups,
         gstride, ACT[act], 1 if out.dtype == torch.float32 else 0, splits, tile_cfg, _stream(x),),
-        tag=f"conv3x3_igemm<{TILE_NAMES.get(tile_cfg, tile_cfg)}>", flops=2.0 * B * H * W * Cout * groups * 9 * Cin,
+        tag=f"conv3x3_igemm<{TILE_NAMES.get(tile_cfg, tile_cfg)}>" + (f" {B}x{H}x{W} {Cin}->{Cout} g{groups}/{splits}" if PROFILER.detail else ""),
+        flops=2.0 * B * H * W * Cout * groups * 9 * Cin,
         nbytes=2.0 * (groups * B * H * W * Cin + Cout * groups * 9 * Cin + B * H * W * Cout), dt=dt)
     return out
 
@@ -1341,12 +1349,86 @@ def conv3x3_dgrad_weight(ws):
     return prep_conv3x3_weight(wt)
 
 
+_WGRAD_PARTIALS = {}
+
+
+def _wgrad_partials(n_floats, device):
+    """One fp32 workspace per device for the pixel-slice partials of g4r_conv3x3_wgrad_nhwc (the launches of a step run back
+    to back on one stream; the largest one sizes it)."""
+    key = str(device)
+    ws = _WGRAD_PARTIALS.get(key)
+    if ws is None or ws.numel() < n_floats:
+        ws = _WGRAD_PARTIALS[key] = torch.empty(n_floats, dtype=torch.float32, device=device)
+    return ws
+
+
+class ConvWgradNHWC:
+    """3x3 weight gradient from NHWC operands for the map geometries that share ONE weight (the levels of a fuse round, or a
+    single conv): zero-bordered copies of each level's input and output gradient (buffers reused across steps, the borders
+    stay zero) and one launch of the TN kernel over all levels (csrc/conv_wgrad_tn.hip).  Channels: multiples of 256."""
+
+    def __init__(self, B, sizes, cin, cout, device):
+        self.B, self.sizes, self.cin, self.cout = B, [(int(h), int(w)) for h, w in sizes], cin, cout
+        assert cin % 256 == 0 and cout % 256 == 0 and 1 <= len(self.sizes) <= 4
+        self.xp, self.dp, self.guard, nks = [], [], [], []
+        for h, w in self.sizes:
+            krows = -(-(B * (h + 2) * (w + 2)) // 32) * 32
+            self.guard.append(w + 3)
+            self.xp.append(torch.zeros((krows + 2 * (w + 3), cin), dtype=torch.bfloat16, device=device))
+            self.dp.append(torch.zeros((krows, cout), dtype=torch.bfloat16, device=device))
+            nks.append(krows // 32)
+        L = len(self.sizes)
+        self._h = (c_int * L)(*[h for h, _ in self.sizes])
+        self._w = (c_int * L)(*[w for _, w in self.sizes])
+        # slices of equal length over all levels, about 16 for the largest level: 144 workgroups (16 tiles x 9 taps at
+        # 1024 x 1024) per slice -> ~3000 work items of ~600 K tiles for the 336^2 pyramid at 8 images
+        self.slice_tiles = max(64, -(-max(nks) // 16))
+        self.slices = _fn("g4r_conv3x3_wgrad_nhwc_slices")(L, ctypes.cast(self._h, P), ctypes.cast(self._w, P), B, cin, cout,
+                                                            self.slice_tiles)
+        assert self.slices > 0, "conv3x3_wgrad_nhwc: shape not supported"
+        self.flops = 2.0 * 9 * cout * cin * sum(nks) * 32
+
+    def wgrad(self, xs, dys, accumulate_into=None):
+        """xs[l] [B,H_l,W_l,Cin], dys[l] [B,H_l,W_l,Cout] bf16 NHWC -> dW [Cout, Cin, 3, 3] fp32, summed over the levels."""
+        L = len(self.sizes)
+        assert len(xs) == L and len(dys) == L
+        for l, (x, dy) in enumerate(zip(xs, dys)):
+            _bf16(x, dy)
+            h, w = self.sizes[l]
+            assert x.is_contiguous() and dy.is_contiguous()
+            assert x.shape == (self.B, h, w, self.cin) and dy.shape == (self.B, h, w, self.cout)
+            _launch("g4r_nhwc_pad_bf16", (_p(x), _p(self.xp[l]), self.B, h, w, self.cin, self.guard[l], _stream(x),),
+                    tag="g4r_nhwc_pad_bf16", nbytes=4.0 * x.numel())
+            _launch("g4r_nhwc_pad_bf16", (_p(dy), _p(self.dp[l]), self.B, h, w, self.cout, 0, _stream(x),),
+                    tag="g4r_nhwc_pad_bf16", nbytes=4.0 * dy.numel())
+        dev = xs[0].device
+        ws = _wgrad_partials(self.slices * 9 * self.cout * self.cin, dev)
+        dw = accumulate_into
+        if dw is None:
+            dw = torch.empty((self.cout, self.cin, 3, 3), dtype=torch.float32, device=dev)
+        _f32(dw)
+        assert dw.shape == (self.cout, self.cin, 3, 3) and dw.is_contiguous()
+        PA = c_void_p * L
+        da, xa = PA(*[t.data_ptr() for t in self.dp]), PA(*[t.data_ptr() for t in self.xp])
+        _launch("g4r_conv3x3_wgrad_nhwc_bf16", (ctypes.cast(da, P), ctypes.cast(xa, P), L, ctypes.cast(self._h, P),
+                                                ctypes.cast(self._w, P), self.B, self.cin, self.cout, self.slice_tiles,
+                                                _p(ws), _p(dw), int(accumulate_into is not None), _stream(xs[0]),),
+                tag="conv3x3_wgrad_tn" + (f" {self.B}x{self.sizes} {self.cin}->{self.cout}/{self.slices}" if PROFILER.detail else ""),
+                flops=self.flops, nbytes=2.0 * self.flops / (2.0 * 9 * max(self.cin, self.cout)))
+        return dw
+
+
 class ConvWgradPlan:
-    """Buffers for the 3x3 weight gradient of ONE map geometry [B, H, W]: channel-major zero-bordered copies of
-    the input (3 column shifts) and of the output gradient, reused across steps (the borders stay zero)."""
+    """Buffers for the 3x3 weight gradient of ONE map geometry [B, H, W], reused across steps (the borders stay zero).
+    Channel counts that are multiples of 256 (every conv of the region module): the NHWC form above.  Otherwise:
+    channel-major zero-bordered copies (3 column shifts of the input) for the NT GEMM."""
 
     def __init__(self, B, H, W, cin, cout, device):
         self.B, self.H, self.W, self.cin, self.cout = B, H, W, cin, cout
+        self.nhwc = cin % 256 == 0 and cout % 256 == 0 and os.environ.get("G4R_WGRAD_CM", "0") != "1"
+        if self.nhwc:
+            self.tn = ConvWgradNHWC(B, [(H, W)], cin, cout, device)
+            return
         self.Wp = -(-(W + 2) // 8) * 8
         self.seg = (H + 2) * self.Wp
         self.base = self.Wp + 8
@@ -1354,18 +1436,20 @@ class ConvWgradPlan:
         self.ltot = -(-(self.base + self.kp + self.Wp + 8) // 64) * 64
         self.xt = torch.zeros((3, cin, self.ltot), dtype=torch.bfloat16, device=device)
         self.dt = torch.zeros((1, cout, self.ltot), dtype=torch.bfloat16, device=device)
-
     def _fill(self, src, dst, n_shift):
         B, H, W, C = src.shape
         _launch("g4r_nhwc_to_cm_padded_bf16", (_p(src), _p(dst), B, H, W, C, self.Wp, self.seg, self.base, self.ltot,
                                                n_shift, _stream(src),), tag="g4r_nhwc_to_cm_padded_bf16",
                 nbytes=2.0 * src.numel() * (1 + n_shift))
 
-    def wgrad(self, x, dy):
-        """x [B,H,W,Cin], dy [B,H,W,Cout] bf16 NHWC -> dW [Cout, Cin, 3, 3] fp32 (torch conv layout)."""
+    def wgrad(self, x, dy, accumulate_into=None):
+        """x [B,H,W,Cin], dy [B,H,W,Cout] bf16 NHWC -> dW [Cout, Cin, 3, 3] fp32 (torch conv layout).
+        accumulate_into: a previous result to add this geometry's gradient to (the levels of a pyramid share the weight)."""
         _bf16(x, dy)
         assert x.is_contiguous() and dy.is_contiguous()
         assert x.shape == (self.B, self.H, self.W, self.cin) and dy.shape == (self.B, self.H, self.W, self.cout)
+        if self.nhwc:
+            return self.tn.wgrad([x], [dy], accumulate_into=accumulate_into)
         self._fill(x, self.xt, 3)
         self._fill(dy, self.dt, 1)
         a = self.dt[0][:, self.base:self.base + self.kp]
@@ -1385,4 +1469,5 @@ class ConvWgradPlan:
                 o = self.base + (ky - 1) * self.Wp
                 taps.append(gemm(a, self.xt[kx][:, o:o + self.kp], out_dtype=torch.float32, splits=splits,
                                  tile_cfg=tile))
-        return torch.stack(taps, 2).view(self.cout, self.cin, 3, 3)
+        dw = torch.stack(taps, 2).view(self.cout, self.cin, 3, 3)
+        return dw if accumulate_into is None else accumulate_into.add_(dw)

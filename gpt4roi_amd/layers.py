@@ -146,7 +146,7 @@ class MLVLFuseModule(nn.Module):
             y = K.gemm(x.view(B * H * H, self.cpad), r['w_in'][lvl], bias=r['b_in'][lvl])
             xs.append(x)
             maps.append(y.view(B, H, H, self.embed_dims))
-        all_maps, all_affs = [maps], [[None] * self.num_levels]
+        all_maps, all_affs, inps = [maps], [[None] * self.num_levels], []
         hw = [(m.size(1), m.size(2)) for m in maps]
         dev = maps[0].device
         for rnd in range(self.num_fuse):
@@ -156,7 +156,9 @@ class MLVLFuseModule(nn.Module):
             z = K.conv3x3_mlvl(inp, r['w_f'][rnd])
             all_maps.append(z.levels)
             all_affs.append(K.groupnorm_affine_mlvl(z, g, bt, groups, eps))
-        return all_maps[-1], all_affs[-1], dict(xs=xs, maps=all_maps, affs=all_affs, B=B)
+            inps.append(inp.levels)            # the convs' inputs stay resident for their weight gradients (0.8 GB per round
+            #                                    at 8 x 336^2: re-deriving them cost 20 shuffle launches, 4.5 ms per step)
+        return all_maps[-1], all_affs[-1], dict(xs=xs, maps=all_maps, affs=all_affs, inps=inps, B=B)
 
     def backward(self, ctx, d_y, on_grad=None):
         """d_y: list[num_levels] of fp32 NHWC gradients w.r.t. the POST GN+ReLU maps of the last round.
@@ -166,9 +168,12 @@ class MLVLFuseModule(nn.Module):
         C, B = self.embed_dims, ctx['B']
         dev = d_y[0].device
         grads = {}
-        if getattr(self, '_wgrad_plans', None) is None or self._wgrad_plans[0].B != B or \
-                [p.H for p in self._wgrad_plans] != [m.size(1) for m in ctx['maps'][0]]:
-            self._wgrad_plans = [K.ConvWgradPlan(B, m.size(1), m.size(2), C, C, dev) for m in ctx['maps'][0]]
+        hw = [(m.size(1), m.size(2)) for m in ctx['maps'][0]]
+        merged = C % 256 == 0                       # all levels of a round in ONE weight-gradient launch (they share the weight)
+        if getattr(self, '_wgrad_key', None) != (B, tuple(hw), merged):
+            self._wgrad_key = (B, tuple(hw), merged)
+            self._wgrad_mlvl = K.ConvWgradNHWC(B, hw, C, C, dev) if merged else None
+            self._wgrad_plans = None if merged else [K.ConvWgradPlan(B, h, w, C, C, dev) for h, w in hw]
         for rnd in range(self.num_fuse - 1, -1, -1):
             g, bt, groups, eps = r['gn'][rnd]
             z_r, aff_r = ctx['maps'][rnd + 1], ctx['affs'][rnd + 1]
@@ -181,9 +186,10 @@ class MLVLFuseModule(nn.Module):
             for tar, top, dow in self.fuse_lvl_list:
                 stats = K.groupnorm_stats(z_r[tar], groups, eps)
                 dz = K.gn_relu_bwd(z_r[tar], d_y[tar], aff_r[tar], g, stats, dgamma, dbeta, groups, out=dzs.levels[tar])
-                inp = K.fuse_shuffle(prev[tar], prev[top], prev[dow], paff[tar], paff[top], paff[dow])
-                w = self._wgrad_plans[tar].wgrad(inp, dz)
-                dW = w if dW is None else dW + w
+                if not merged:
+                    dW = self._wgrad_plans[tar].wgrad(ctx['inps'][rnd][tar], dz, accumulate_into=dW)   # the levels share the weight
+            if merged:
+                dW = self._wgrad_mlvl.wgrad(ctx['inps'][rnd], dzs.levels)
             dinps = K.conv3x3_mlvl(dzs, wt).levels          # the input gradients of every level: one implicit GEMM
             grads[f'fuse_convs.{rnd}.conv.weight'] = dW
             grads[f'fuse_convs.{rnd}.gn.weight'] = dgamma

@@ -117,6 +117,24 @@ int g4r_fuse_shuffle_bwd_gather_nhwc_bf16(float* d_src, const void* dinp_own, in
                                           int Hf, int Wf, const void* dinp_coarse, int Hc, int Wc, int self_top,
                                           int self_down, int B, int C, void* stream);
 
+/* 3x3 weight gradient read straight from NHWC operands (round 4; csrc/conv_wgrad_tn.hip).  The reference gets these from
+ * torch autograd for the convs of gpt4roi/models/layers.py:129-144,191-195,321-325.
+ * g4r_nhwc_pad_bf16: src [B][H][W][C] -> the zero-bordered grid [B][H+2][W+2][C] starting at row `row0` of dst (interior
+ * only; border and guard rows stay as the caller zeroed them).
+ * g4r_conv3x3_wgrad_nhwc_bf16: dw [Cout][Cin][3][3] fp32, summed over the n_levels (1..4) map geometries that share the
+ * weight (the levels of a fuse round; 1 for a plain conv).  Level l: dy_pads[l] [krows][Cout] (row = bordered pixel index,
+ * krows = B (H_l+2) (W_l+2) rounded up to 32, zero border) and x_pads[l] [guard + krows + guard][Cin] (guard = W_l + 3
+ * zero rows in front of bordered pixel 0 and behind the last row).  The pixel axis of every level is cut into slices of
+ * about slice_tiles K tiles of 32 pixels; partials = fp32 workspace [slices][9][Cout][Cin] with slices =
+ * g4r_conv3x3_wgrad_nhwc_slices(same arguments) (< 0: shape not supported).  Cout, Cin multiples of 256;
+ * accumulate != 0: dw += . */
+int g4r_nhwc_pad_bf16(const void* src, void* dst, int B, int H, int W, int C, long row0, void* stream);
+int g4r_conv3x3_wgrad_nhwc_slices(int n_levels, const int* heights, const int* widths, int B, int Cin, int Cout,
+                                  int slice_tiles);
+int g4r_conv3x3_wgrad_nhwc_bf16(const void* const* dy_pads, const void* const* x_pads, int n_levels, const int* heights,
+                                const int* widths, int B, int Cin, int Cout, int slice_tiles, float* partials, float* dw,
+                                int accumulate, void* stream);
+
 /* NHWC bf16 [B, H, W, C] -> channel-major rows with a zero border:
  *   dst[s][c][base + b*seg + (y+1)*Wp + (x+1) - (s - n_shift/2)] = src[b][y][x][c],   dst [n_shift, C, ltot]
  * The 3x3 weight gradient is then 9 NT GEMMs over the pixel axis,

@@ -165,7 +165,15 @@ def test_malformed_training_batch_raises_like_the_reference():
     bad = [boxes[0][:2], torch.cat([boxes[1], boxes[0][2:]])]       # totals match (2 + 2), per-sample counts do not
     with pytest.raises(ValueError):
         lm(input_ids=prompt, images=img, bboxes=bad, labels=labels)
+    # a left-padded batch is NOT malformed: the mask reaches the decoder (unpad -> varlen attention -> pad back,
+    # llama_flash_attn_monkey_patch.py:60-85; tests/test_varlen_gpu.py checks the arithmetic) and the loss differentiates
     left_padded = torch.ones_like(prompt)
     left_padded[0, :3] = 0
-    with pytest.raises(ValueError):
-        lm(input_ids=prompt, attention_mask=left_padded, images=img, bboxes=boxes, labels=labels)
+    lab = labels.clone()
+    lab[0, :3] = -100
+    plain = lm(input_ids=prompt, images=img, bboxes=boxes, labels=lab).loss
+    out = lm(input_ids=prompt, attention_mask=left_padded, images=img, bboxes=boxes, labels=lab)
+    assert torch.isfinite(out.loss) and a.llama.pos == prompt.size(1)
+    assert abs(float(out.loss) - float(plain)) > 0                   # three keys fewer for every later row of sample 0
+    out.loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in a.spi_module.parameters() if p.requires_grad)

@@ -311,8 +311,11 @@ def test_fuse_shuffle_backward_gather_equals_scatter():
         assert relerr(got, want[l]) < 1e-5, l
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout", [(1, 14, 14, 64, 128), (2, 20, 12, 128, 64)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(1, 14, 14, 64, 128), (2, 20, 12, 128, 64),
+                                            (2, 20, 12, 256, 256), (1, 24, 24, 512, 256), (3, 7, 33, 256, 768)])
 def test_conv3x3_weight_and_input_gradients(B, H, W, cin, cout):
+    """Channel counts that are multiples of 256 take the NHWC (TN) kernel of csrc/conv_wgrad_tn.hip, the others the
+    channel-major NT path."""
     x, dy = rnd(B, H, W, cin, seed=80), rnd(B, H, W, cout, seed=81)
     w = rnd(cout, cin, 3, 3, scale=0.1, seed=82)
     xr, wr = leaf(x), leaf(w)
@@ -320,10 +323,36 @@ def test_conv3x3_weight_and_input_gradients(B, H, W, cin, cout):
     plan = K.ConvWgradPlan(B, H, W, cin, cout, DEV)
     dw = plan.wgrad(x, dy)
     assert relerr(dw, wr.grad) < 1e-2
+    assert plan.nhwc == (cin % 256 == 0 and cout % 256 == 0)
     dw2 = plan.wgrad(x, dy)                                     # plan buffers are reusable
     assert torch.equal(dw, dw2)
+    dw3 = plan.wgrad(x, dy, accumulate_into=dw2.clone())        # += form (the levels of a pyramid share the weight)
+    assert relerr(dw3, 2 * wr.grad) < 1e-2
     dx = K.conv3x3(dy, K.conv3x3_dgrad_weight(w))
     assert relerr(dx, xr.grad) < 1e-2
+
+
+def test_conv3x3_weight_gradient_of_a_pyramid_in_one_launch():
+    """ConvWgradNHWC over several map geometries that share the weight (the levels of a fuse round,
+    gpt4roi/models/layers.py:218-236) == the sum of the per-level autograd gradients; slices of different levels end up in
+    one partial buffer and one reduce."""
+    B, cin, cout = 2, 256, 512
+    sizes = [(24, 24), (12, 12), (6, 6), (3, 3)]
+    w = rnd(cout, cin, 3, 3, scale=0.1, seed=90)
+    wr = leaf(w)
+    xs = [rnd(B, h, ww, cin, seed=91 + i) for i, (h, ww) in enumerate(sizes)]
+    dys = [rnd(B, h, ww, cout, seed=95 + i) for i, (h, ww) in enumerate(sizes)]
+    for x, dy in zip(xs, dys):
+        F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, padding=1).backward(dy.float().cpu().permute(0, 3, 1, 2))
+    plan = K.ConvWgradNHWC(B, sizes, cin, cout, DEV)
+    assert plan.slices >= len(sizes)
+    dw = plan.wgrad(xs, dys)
+    assert relerr(dw, wr.grad) < 1e-2
+    assert torch.equal(plan.wgrad(xs, dys), dw)                 # fixed summation order: bit-reproducible
+    singles = None
+    for (h, ww), x, dy in zip(sizes, xs, dys):
+        singles = K.ConvWgradPlan(B, h, ww, cin, cout, DEV).wgrad(x, dy, accumulate_into=singles)
+    assert relerr(singles, dw) < 1e-5                           # the same products, another grouping of the fp32 sums
 
 
 def test_roi_align_mlvl_backward():

@@ -24,6 +24,7 @@ ap.add_argument("--rois", type=int, default=32)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--llama-layers", type=int, default=32)
 ap.add_argument("--stage", type=int, default=1, help="1: region module trainable; 2: everything but the ViT")
+ap.add_argument("--by-shape", action="store_true", help="GEMM / conv rows of the breakdown per problem shape, with TFLOP/s")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 margs = SimpleNamespace(image_size=336, llama_layers=a.llama_layers)
@@ -48,10 +49,15 @@ for _ in range(a.steps):
     losses.append(tr.step(prompt, img, boxes, labels).item())
 torch.cuda.synchronize()
 ms = (time.time() - t0) / a.steps * 1e3
-K.PROFILER.start()
+K.PROFILER.start(detail=a.by_shape)
 tr.step(prompt, img, boxes, labels)
 agg = K.PROFILER.stop()
 top = sorted(((v["ms"], k, v["calls"]) for k, v in agg.items()), reverse=True)[:14]
+if a.by_shape:
+    print("per-shape rows of one instrumented step (ms total, calls, avg us, TFLOP/s):")
+    for v_ms, k, c in sorted(((v["ms"], k, v["calls"]) for k, v in agg.items()), reverse=True)[:60]:
+        fl = agg[k]["flops"]
+        print(f"  {v_ms:9.3f} {c:5d} {v_ms / c * 1e3:9.1f} {fl / v_ms / 1e9 if fl else 0:8.1f}  {k}")
 print(json.dumps(dict(metric=("stage-2 training step (ViT-L/14@336 frozen; region module, projector and LLaMA-7B trainable)" if a.stage == 2 else
                               "stage-1 training step (ViT-L/14@336 frozen, region module trainable, LLaMA-7B frozen)"),
                       batch=a.batch, rois=a.rois, tokens=int(prompt.size(1)), ms_per_step=round(ms, 2),
