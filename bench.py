@@ -275,7 +275,8 @@ def train_leg(args, model, ids, device, rank, world, dist, agg_device):
         agg = K.PROFILER.stop()
         tsum = sum(a["ms"] for a in agg.values())
         fams = {"gemm": lambda t: t.startswith("gemm_bf16_nt") or t.startswith("gemv") or t == "small_linear",
-                "conv": lambda t: t.startswith("conv3x3_igemm"), "attention_fwd": lambda t: t.startswith("flash_attn<"),
+                "conv": lambda t: t.startswith("conv3x3_igemm"), "weight_grad_tn": lambda t: t.startswith("conv3x3_wgrad_tn")
+                or t.startswith("gemm_tn"), "attention_fwd": lambda t: t.startswith("flash_attn<"),
                 "attention_bwd": lambda t: t.startswith("flash_attn_bwd")}
         train_roofline = {"instrumented_step_kernel_ms": round(tsum, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "families": {}}
         for fname, pred in fams.items():

@@ -1,4 +1,6 @@
-// 3x3 convolution WEIGHT gradient read straight from NHWC operands (training rows; the convs are
+// "TN" GEMM: C = A^T B with the reduction over the ROWS of both operands -- the weight gradients of the training rows,
+// read from the operands as they lie in memory.  g4r_gemm_tn_bf16 is the plain form (a Linear's dW = dY^T X); the description
+// below is the 3x3 convolution WEIGHT gradient read straight from NHWC operands (training rows; the convs are
 // gpt4roi/models/layers.py:129-144,191-195,321-325, their weight gradients what torch autograd computes for them in the
 // reference's backward).
 //
@@ -34,14 +36,16 @@ struct TnLevel {        // one map geometry (pyramid level); the levels of a fus
   int nk, tiles_per_slice, slice0, n_slices;
   int tap_row[9];
   unsigned a_bytes, b_bytes;
+  int lda, ldb;
 };
 struct TnArgs {
   TnLevel lv[4];
   int n_lvl, slices;   // pixel slices of all levels together
   int xcd_first[9];    // XCD x runs work items [xcd_first[x], xcd_first[x + 1]): ranges of equal WORK (items differ in length)
-  float* P;            // partials [slices][9][M][N]
+  float* P;            // partials [slices][ntaps][M][N] -- or, `direct`, the result itself [M][ldc] (one slice, one tap)
   int M, N;
   int tiles_m, tiles_n;
+  int ntaps, direct, ldc;
 };
 
 __device__ __forceinline__ void tn_piece(const void* base, unsigned bytes, void* lds, int voff, int soff) {
@@ -56,7 +60,7 @@ __device__ __forceinline__ void tn_piece(const void* base, unsigned bytes, void*
     __builtin_amdgcn_sched_barrier(0);                     \
   } while (0)
 
-__global__ __launch_bounds__(512) void conv_wgrad_tn_kernel(TnArgs p) {
+__global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs p) {
   constexpr int NW = 8, BM = 256, BN = 256, BKT = 32, RING = 4;
   constexpr int ROWB = 512;                       // bytes of one image row (256 channels)
   constexpr int A_BYTES = BKT * ROWB, STAGE_BYTES = 2 * A_BYTES;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_tn_kernel(TnArgs p) {
   // work item: slice-major over the XCDs (workgroup id -> XCD id % 8 in hardware; XCD x owns a contiguous range of items,
   // cut by the host so that the ranges carry equal work)
   const int tiles = p.tiles_m * p.tiles_n;
-  const int per_slice = tiles * 9;
+  const int per_slice = tiles * p.ntaps;
   const int lin = blockIdx.x;
   const int xcd = lin & 7, idx = lin >> 3;
   const int v = p.xcd_first[xcd] + idx;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_tn_kernel(TnArgs p) {
   const h16_t* const Ap = L.A;
   const h16_t* const Bp = L.B;
   const unsigned a_bytes = L.a_bytes, b_bytes = L.b_bytes;
-  const int lda = p.M, ldb = p.N;
+  const int lda = L.lda, ldb = L.ldb;
 
   // pieces of a K tile: 16 of A + 16 of B, 1 KiB = image rows 2q, 2q + 1 each; wave w carries A pieces w, w + 8 and B
   // pieces w, w + 8.  Lane l writes LDS bytes [16 l, 16 l + 16) of the piece = row 2q + (l >> 5), slot l & 31, and reads the
@@ -103,8 +107,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_tn_kernel(TnArgs p) {
   for (int j = 0; j < 2; ++j) {
     const int prow = 2 * (wave + 8 * j) + (lane >> 5);
     const int slot = (lane & 31) ^ (4 * (prow & 3));
-    a_voff[j] = (prow * lda + m0 + slot * 8) * 2;
-    b_voff[j] = (prow * ldb + n0 + slot * 8) * 2;
+    // columns beyond M / N (edge tiles): an offset past the descriptor's num_records, which the hardware reads as zeros
+    a_voff[j] = m0 + slot * 8 < p.M ? (prow * lda + m0 + slot * 8) * 2 : (int)0x80000000;
+    b_voff[j] = n0 + slot * 8 < p.N ? (prow * ldb + n0 + slot * 8) * 2 : (int)0x80000000;
   }
   const int b_row0 = L.tap_row[tap];
   auto stage = [&](int t, int buf) {
@@ -231,42 +236,59 @@ __global__ __launch_bounds__(512) void conv_wgrad_tn_kernel(TnArgs p) {
     }
     if (grp == 0) TN_BARRIER();
   }
-  // partials: accumulator register r of block (i, j) is row (r & 3) + 8 (r >> 2) + 4 hi, column lane & 31
-  float* out = p.P + ((size_t)(slice * 9 + tap) * p.M + m0 + wm * 128) * p.N + n0 + wn * 64 + (lane & 31);
+  // accumulator register r of block (i, j) is row (r & 3) + 8 (r >> 2) + 4 hi, column lane & 31
+  const int row0 = m0 + wm * 128, col0 = n0 + wn * 64 + (lane & 31);
+  float* out;
+  long ld;
+  if (p.direct) {
+    out = p.P;
+    ld = p.ldc;
+  } else {
+    out = p.P + (size_t)(slice * p.ntaps + tap) * p.M * p.N;
+    ld = p.N;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        out[(size_t)row * p.N + j * 32] = acc[i][j][r];
+        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, col = col0 + j * 32;
+        if (row < p.M && col < p.N) out[(size_t)row * ld + col] = acc[i][j][r];
       }
 }
 
-// dW[co][ci][tap] = sum_s P[s][tap][co][ci]: one thread per (co, 4 ci); the nine taps of an output element are contiguous
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ P, float* __restrict__ dw, int M,
-                                                                int N, int splits, int accumulate) {
+// dW[co][ci][tap] = sum_s P[s][tap][co][ci]: one thread per (co, 4 ci); the taps of an output element are contiguous
+// (NTAPS = 9: the torch conv layout [Cout][Cin][3][3]; NTAPS = 1: a plain [M][N] matrix)
+template <int NTAPS>
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ P, float* __restrict__ dw, int M, int N,
+                                                        int splits, int accumulate) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long n4 = N / 4;
   if (i >= (long)M * n4) return;
   const long co = i / n4, c4 = (i - co * n4) * 4;
-  float4v s[9];
+  float4v s[NTAPS];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) s[t] = float4v{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NTAPS; ++t) s[t] = float4v{0.f, 0.f, 0.f, 0.f};
   const size_t plane = (size_t)M * N;
   for (int sp = 0; sp < splits; ++sp) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float4v v = *reinterpret_cast<const float4v*>(P + ((size_t)sp * 9 + t) * plane + co * N + c4);
+    for (int t = 0; t < NTAPS; ++t) {
+      const float4v v = *reinterpret_cast<const float4v*>(P + ((size_t)sp * NTAPS + t) * plane + co * N + c4);
       s[t] += v;
     }
   }
-  float* o = dw + (co * N + c4) * 9;
+  float* o = dw + (co * N + c4) * NTAPS;
+  if (NTAPS == 1) {
+    float4v r = s[0];
+    if (accumulate) r += *reinterpret_cast<const float4v*>(o);
+    *reinterpret_cast<float4v*>(o) = r;
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) o[e * 9 + t] = accumulate ? o[e * 9 + t] + s[t][e] : s[t][e];
+    for (int t = 0; t < NTAPS; ++t) o[e * NTAPS + t] = accumulate ? o[e * NTAPS + t] + s[t][e] : s[t][e];
 }
 
 // NHWC [B][H][W][C] -> the bordered grid [B][H+2][W+2][C] starting at row `row0` of dst (interior only: the border and the
@@ -312,10 +334,55 @@ int g4r_nhwc_pad_bf16(const void* src, void* dst, int B, int H, int W, int C, lo
 // The pixel axis of every level is cut into slices of about `slice_tiles` K tiles (32 pixels each); partials
 // [total slices][9][Cout][Cin] fp32 -- g4r_conv3x3_wgrad_nhwc_slices() returns the count for the same arguments.
 // Cout and Cin multiples of 256; accumulate: dw += .
+// items in (slice, tap, tile) order cut into eight ranges of equal work; an item costs its K tiles + ~48 tiles' worth of
+// ring fill, epilogue and launch
+static void tn_balance(TnArgs& a) {
+  const int per_slice = a.tiles_m * a.tiles_n * a.ntaps;
+  long total_work = 0;
+  for (int l = 0; l < a.n_lvl; ++l) {
+    const TnLevel& L = a.lv[l];
+    for (int s = 0; s < L.n_slices; ++s) {
+      int len = L.nk - s * L.tiles_per_slice;
+      if (len > L.tiles_per_slice) len = L.tiles_per_slice;
+      total_work += (long)(len + 48) * per_slice;
+    }
+  }
+  long done = 0;
+  int item = 0, x = 1;
+  a.xcd_first[0] = 0;
+  for (int l = 0; l < a.n_lvl; ++l) {
+    const TnLevel& L = a.lv[l];
+    for (int s = 0; s < L.n_slices; ++s) {
+      int len = L.nk - s * L.tiles_per_slice;
+      if (len > L.tiles_per_slice) len = L.tiles_per_slice;
+      for (int i = 0; i < per_slice; ++i) {
+        while (x < 8 && done * 8 >= total_work * x) a.xcd_first[x++] = item;
+        done += len + 48;
+        ++item;
+      }
+    }
+  }
+  while (x <= 8) a.xcd_first[x++] = item;
+}
+
+static int tn_launch(TnArgs& a, void* stream) {
+  const int lds = 4 * 32768;
+  if (g_tn_lds.first())
+    G4R_REQUIRE(hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) ==
+                    hipSuccess, "gemm_tn: cannot raise the dynamic LDS limit");
+  int longest = 0;
+  for (int x = 0; x < 8; ++x)
+    if (a.xcd_first[x + 1] - a.xcd_first[x] > longest) longest = a.xcd_first[x + 1] - a.xcd_first[x];
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(8 * longest), dim3(512), lds, (hipStream_t)stream, a);
+  G4R_CHECK_LAUNCH("gemm_tn");
+  return G4R_OK;
+}
+
 static int tn_plan(TnArgs& a, int n_levels, const int* heights, const int* widths, int B, int Cin, int Cout, int slice_tiles) {
   a.n_lvl = n_levels;
   a.M = Cout; a.N = Cin;
   a.tiles_m = Cout / 256; a.tiles_n = Cin / 256;
+  a.ntaps = 9; a.direct = 0; a.ldc = Cin;
   int slices = 0;
   for (int l = 0; l < n_levels; ++l) {
     const int H = heights[l], W = widths[l];
@@ -333,35 +400,10 @@ static int tn_plan(TnArgs& a, int n_levels, const int* heights, const int* width
     slices += L.n_slices;
     for (int t = 0; t < 9; ++t) L.tap_row[t] = (int)(guard + (t / 3 - 1) * (W + 2) + (t % 3 - 1));
     L.a_bytes = (unsigned)a_bytes; L.b_bytes = (unsigned)b_bytes;
+    L.lda = Cout; L.ldb = Cin;
   }
   a.slices = slices;
-  // items in (slice, tap, tile) order; an item costs its K tiles + ~48 tiles' worth of ring fill, epilogue and launch
-  const int per_slice = a.tiles_m * a.tiles_n * 9;
-  long total_work = 0;
-  for (int l = 0; l < n_levels; ++l) {
-    const TnLevel& L = a.lv[l];
-    for (int s = 0; s < L.n_slices; ++s) {
-      int len = L.nk - s * L.tiles_per_slice;
-      if (len > L.tiles_per_slice) len = L.tiles_per_slice;
-      total_work += (long)(len + 48) * per_slice;
-    }
-  }
-  long done = 0;
-  int item = 0, x = 1;
-  a.xcd_first[0] = 0;
-  for (int l = 0; l < n_levels; ++l) {
-    const TnLevel& L = a.lv[l];
-    for (int s = 0; s < L.n_slices; ++s) {
-      int len = L.nk - s * L.tiles_per_slice;
-      if (len > L.tiles_per_slice) len = L.tiles_per_slice;
-      for (int i = 0; i < per_slice; ++i) {
-        while (x < 8 && done * 8 >= total_work * x) a.xcd_first[x++] = item;
-        done += len + 48;
-        ++item;
-      }
-    }
-  }
-  while (x <= 8) a.xcd_first[x++] = item;
+  tn_balance(a);
   return slices;
 }
 
@@ -395,19 +437,61 @@ int g4r_conv3x3_wgrad_nhwc_bf16(const void* const* dy_pads, const void* const* x
     a.lv[l].B = (const h16_t*)x_pads[l];
   }
   a.P = partials;
-  const int lds = 4 * 32768;
-  if (g_tn_lds.first())
-    G4R_REQUIRE(hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) ==
-                    hipSuccess, "conv3x3_wgrad_nhwc: cannot raise the dynamic LDS limit");
-  int longest = 0;
-  for (int x = 0; x < 8; ++x)
-    if (a.xcd_first[x + 1] - a.xcd_first[x] > longest) longest = a.xcd_first[x + 1] - a.xcd_first[x];
-  hipLaunchKernelGGL(conv_wgrad_tn_kernel, dim3(8 * longest), dim3(512), lds, (hipStream_t)stream, a);
-  G4R_CHECK_LAUNCH("conv3x3_wgrad_nhwc");
+  {
+    const int rc = tn_launch(a, stream);
+    if (rc != G4R_OK) return rc;
+  }
   const long n = (long)Cout * (Cin / 4);
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((tn_reduce_kernel<9>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)partials, dw, Cout, Cin, slices, accumulate);
   G4R_CHECK_LAUNCH("conv3x3_wgrad_reduce");
+  return G4R_OK;
+}
+
+// C [M][N] fp32 (+)= A^T B with A [K][lda] (element (k, m)), B [K][ldb] (element (k, n)) bf16: the reduction index is the
+// ROW of both operands -- the weight gradient of a Linear, dW [N_out][K_in] = dY^T X with dY [tokens][N_out], X [tokens][K_in]
+// (torch autograd's grad_weight for the nn.Linear layers of the decoder, the projector and the 1x1 input convs), read as it
+// lies: no transposed copies.  M, N, lda, ldb multiples of 8; K any (the rows beyond K read as zeros).
+// slices = 1 and accumulate = 0: stored directly (ldc = row stride of C).  Otherwise the K axis is cut into `slices`
+// ranges, partials [slices][M][N] fp32, and a reduce writes (or adds to) C, which must then be dense (ldc == N).
+int g4r_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, float* partials,
+                     int slices, int accumulate, void* stream) {
+  G4R_REQUIRE(M > 0 && N > 0 && K > 0 && M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N,
+              "gemm_tn: M, N and the row strides must be multiples of 8");
+  G4R_REQUIRE(A && B && C && slices >= 1 && slices <= 256, "gemm_tn: bad arguments");
+  const bool direct = slices == 1 && !accumulate;
+  G4R_REQUIRE(direct || (partials && ldc == N), "gemm_tn: sliced / accumulating form needs the workspace and a dense C");
+  G4R_REQUIRE(ldc >= N, "gemm_tn: ldc < N");
+  const long a_bytes = (long)K * lda * 2, b_bytes = (long)K * ldb * 2;
+  G4R_REQUIRE(a_bytes < 0x7fffffffL && b_bytes < 0x7fffffffL, "gemm_tn: operand beyond the 2 GiB of a 32-bit offset");
+  TnArgs a;
+  a.n_lvl = 1;
+  a.M = M; a.N = N;
+  a.tiles_m = (M + 255) / 256; a.tiles_n = (N + 255) / 256;
+  a.ntaps = 1; a.direct = direct ? 1 : 0; a.ldc = ldc;
+  TnLevel& L = a.lv[0];
+  L.A = (const h16_t*)A; L.B = (const h16_t*)B;
+  L.nk = (K + 31) / 32;
+  L.n_slices = slices > L.nk ? L.nk : slices;
+  L.tiles_per_slice = (L.nk + L.n_slices - 1) / L.n_slices;
+  L.n_slices = (L.nk + L.tiles_per_slice - 1) / L.tiles_per_slice;
+  L.slice0 = 0;
+  for (int t = 0; t < 9; ++t) L.tap_row[t] = 0;
+  L.a_bytes = (unsigned)a_bytes; L.b_bytes = (unsigned)b_bytes;
+  L.lda = lda; L.ldb = ldb;
+  a.slices = L.n_slices;
+  a.P = direct ? C : partials;
+  tn_balance(a);
+  {
+    const int rc = tn_launch(a, stream);
+    if (rc != G4R_OK) return rc;
+  }
+  if (!direct) {
+    const long n = (long)M * (N / 4);
+    hipLaunchKernelGGL((tn_reduce_kernel<1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)partials, C, M, N, a.slices, accumulate);
+    G4R_CHECK_LAUNCH("gemm_tn_reduce");
+  }
   return G4R_OK;
 }
 

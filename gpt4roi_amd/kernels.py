@@ -52,6 +52,7 @@ _SIGS = {
                                               c_int, P],
     "g4r_nhwc_pad_bf16": [P, P, c_int, c_int, c_int, c_int, c_long, P],
     "g4r_conv3x3_wgrad_nhwc_bf16": [P, P, c_int, P, P, c_int, c_int, c_int, c_int, P, P, c_int, P],
+    "g4r_gemm_tn_bf16": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
     "g4r_conv3x3_wgrad_nhwc_slices": [c_int, P, P, c_int, c_int, c_int, c_int],
     "g4r_nhwc_to_cm_padded_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_int, P],
     "g4r_roi_align_mlvl_nhwc_bwd_bf16": [P, c_long, c_long, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
@@ -1232,8 +1233,42 @@ def linear_dgrad(dy, w_t, out=None, residual=None):
     return gemm(dy, w_t, residual=residual, out=out)
 
 
+def gemm_tn(a, b, out=None, accumulate=False, slices=None):
+    """C [M, N] fp32 (+)= a^T b with a [K, M], b [K, N] bf16 row-strided: the reduction runs over the ROWS of both operands,
+    read as they lie (csrc/gemm_tn.hip).  Few output tiles and a long K: the K axis is cut into slices (fp32 partials)."""
+    _bf16(a, b)
+    Kd, M = a.shape
+    N = b.size(1)
+    assert b.size(0) == Kd and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        assert not accumulate
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _f32(out)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    tiles = -(-M // 256) * -(-N // 256)
+    nk = -(-Kd // 32)
+    if slices is None:
+        slices = 1 if tiles >= 128 else max(1, min(512 // tiles, nk // 16, 64))
+    ws = None
+    if slices > 1 or accumulate:
+        assert out.is_contiguous()
+        ws = _wgrad_partials(slices * M * N, a.device)
+    _launch("g4r_gemm_tn_bf16", (_p(a), _p(b), _p(out), M, N, Kd, a.stride(0), b.stride(0), out.stride(0), _p(ws),
+                                 int(slices), int(bool(accumulate)), _stream(a),),
+            tag="gemm_tn" + (f" {M}x{N}x{Kd}/{slices}" if PROFILER.detail else ""), flops=2.0 * M * N * Kd,
+            nbytes=2.0 * Kd * (M + N) + 4.0 * M * N)
+    return out
+
+
 def linear_wgrad(dy, x, out_dtype=torch.float32, splits=None):
-    """dW [N, K] = dy^T [N, M] . x [M, K]: one NT GEMM over the (zero-padded) token axis."""
+    """dW [N, K] = dy^T [N, M] . x [M, K] (torch autograd's grad_weight of a Linear).  Operands whose widths and row strides
+    are multiples of 8: the TN kernel, straight from the row-major operands.  Otherwise (the 4-wide box embedding, an
+    unpadded vocabulary): transposed copies + one NT GEMM over the zero-padded token axis."""
+    if out_dtype == torch.float32 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.dim() == 2 and \
+            x.dim() == 2 and dy.size(1) % 8 == 0 and x.size(1) % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 \
+            and dy.stride(1) == 1 and x.stride(1) == 1 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 \
+            and os.environ.get("G4R_WGRAD_CM", "0") != "1":
+        return gemm_tn(dy, x)
     M = dy.size(0)
     m_pad = -(-M // 64) * 64
     dyt = transpose(dy, m_pad)
@@ -1365,7 +1400,7 @@ def _wgrad_partials(n_floats, device):
 class ConvWgradNHWC:
     """3x3 weight gradient from NHWC operands for the map geometries that share ONE weight (the levels of a fuse round, or a
     single conv): zero-bordered copies of each level's input and output gradient (buffers reused across steps, the borders
-    stay zero) and one launch of the TN kernel over all levels (csrc/conv_wgrad_tn.hip).  Channels: multiples of 256."""
+    stay zero) and one launch of the TN kernel over all levels (csrc/gemm_tn.hip).  Channels: multiples of 256."""
 
     def __init__(self, B, sizes, cin, cout, device):
         self.B, self.sizes, self.cin, self.cout = B, [(int(h), int(w)) for h, w in sizes], cin, cout

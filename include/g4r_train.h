@@ -117,7 +117,7 @@ int g4r_fuse_shuffle_bwd_gather_nhwc_bf16(float* d_src, const void* dinp_own, in
                                           int Hf, int Wf, const void* dinp_coarse, int Hc, int Wc, int self_top,
                                           int self_down, int B, int C, void* stream);
 
-/* 3x3 weight gradient read straight from NHWC operands (round 4; csrc/conv_wgrad_tn.hip).  The reference gets these from
+/* 3x3 weight gradient read straight from NHWC operands (round 4; csrc/gemm_tn.hip).  The reference gets these from
  * torch autograd for the convs of gpt4roi/models/layers.py:129-144,191-195,321-325.
  * g4r_nhwc_pad_bf16: src [B][H][W][C] -> the zero-bordered grid [B][H+2][W+2][C] starting at row `row0` of dst (interior
  * only; border and guard rows stay as the caller zeroed them).
@@ -129,6 +129,12 @@ int g4r_fuse_shuffle_bwd_gather_nhwc_bf16(float* d_src, const void* dinp_own, in
  * g4r_conv3x3_wgrad_nhwc_slices(same arguments) (< 0: shape not supported).  Cout, Cin multiples of 256;
  * accumulate != 0: dw += . */
 int g4r_nhwc_pad_bf16(const void* src, void* dst, int B, int H, int W, int C, long row0, void* stream);
+/* C [M][N] fp32 (+)= A^T B, A [K][lda] (element (k, m)), B [K][ldb] (element (k, n)) bf16: torch autograd's grad_weight of
+ * an nn.Linear, dW [N_out][K_in] = dY^T X, read from the row-major operands (no transposed copies; csrc/gemm_tn.hip).
+ * M, N, lda, ldb multiples of 8; K any.  slices = 1, accumulate = 0: direct store (ldc = row stride of C).  Otherwise the K
+ * axis is cut into `slices` ranges with fp32 partials [slices][M][N] and a reduce writes / adds to a dense C (ldc == N). */
+int g4r_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, float* partials,
+                     int slices, int accumulate, void* stream);
 int g4r_conv3x3_wgrad_nhwc_slices(int n_levels, const int* heights, const int* widths, int B, int Cin, int Cout,
                                   int slice_tiles);
 int g4r_conv3x3_wgrad_nhwc_bf16(const void* const* dy_pads, const void* const* x_pads, int n_levels, const int* heights,

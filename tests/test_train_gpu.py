@@ -189,6 +189,21 @@ def test_linear_gradients_through_nt_gemm():
     assert relerr(dx, xr.grad) < 1e-2 and relerr(dw, wr.grad) < 1e-2
 
 
+@pytest.mark.parametrize("Kd,M,N,slices", [(150, 192, 256, None), (1000, 520, 264, 1), (5000, 256, 1088, None),
+                                           (333, 24, 8, 3), (4096, 1024, 512, 7)])
+def test_gemm_tn_reads_row_major_operands(Kd, M, N, slices):
+    """C = a^T b over the rows of both operands (g4r_gemm_tn_bf16): edge tiles in M and N, a K that is no multiple of the K
+    tile, row-strided operands, the direct / sliced / accumulating forms."""
+    big_a, big_b = rnd(Kd, M + 16, seed=35), rnd(Kd, N + 8, seed=36)
+    a, b = big_a[:, 8:8 + M], big_b[:, :N]                          # row strides > widths
+    want = a.float().cpu().t() @ b.float().cpu()
+    got = K.gemm_tn(a, b, slices=slices)
+    assert relerr(got, want) < 2e-3, relerr(got, want)
+    acc = K.gemm_tn(a, b, out=got.clone(), accumulate=True, slices=slices)
+    assert relerr(acc, 2 * want) < 2e-3
+    assert torch.equal(K.gemm_tn(a, b, slices=slices), got)
+
+
 def test_adamw_matches_torch():
     n = 5000
     p0 = rnd(n, seed=34, dtype=torch.float32)
@@ -314,7 +329,7 @@ def test_fuse_shuffle_backward_gather_equals_scatter():
 @pytest.mark.parametrize("B,H,W,cin,cout", [(1, 14, 14, 64, 128), (2, 20, 12, 128, 64),
                                             (2, 20, 12, 256, 256), (1, 24, 24, 512, 256), (3, 7, 33, 256, 768)])
 def test_conv3x3_weight_and_input_gradients(B, H, W, cin, cout):
-    """Channel counts that are multiples of 256 take the NHWC (TN) kernel of csrc/conv_wgrad_tn.hip, the others the
+    """Channel counts that are multiples of 256 take the NHWC (TN) kernel of csrc/gemm_tn.hip, the others the
     channel-major NT path."""
     x, dy = rnd(B, H, W, cin, seed=80), rnd(B, H, W, cout, seed=81)
     w = rnd(cout, cin, 3, 3, scale=0.1, seed=82)
