@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256) void swiglu_il_bwd_kernel(const h16_t* __restr
 __global__ __launch_bounds__(256) void rope_qkv_bwd_kernel(const h16_t* __restrict__ dq, const h16_t* __restrict__ dk,
                                                            const h16_t* __restrict__ dv, const float* __restrict__ cs,
                                                            const float* __restrict__ sn, h16_t* __restrict__ dqkv,
-                                                           int T, int Hh, int D, int pos0, long ldq, long ldk, long ldv) {
+                                                           int T, int Hh, int D, int pos0, long ldq, long ldk, long ldv,
+                                                           int period) {
   const int half = D >> 1;
   const int hv = half >> 3;
   const long total = (long)T * Hh * hv;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void rope_qkv_bwd_kernel(const h16_t* __restri
     const int v = (int)(i % hv);
     const int h = (int)((i / hv) % Hh);
     const int t = (int)(i / ((long)hv * Hh));
-    const int pos = pos0 + t;
+    const int pos = pos0 + (period > 0 ? t % period : t);      // rows of several sequences stacked: positions restart
     const F8 c = ld8f(cs + (size_t)pos * half + v * 8);
     const F8 s = ld8f(sn + (size_t)pos * half + v * 8);
     const size_t off = (size_t)h * D + v * 8;
@@ -499,19 +500,33 @@ int g4r_swiglu_il_bwd_bf16(const void* gate_up, const void* dy, void* dgate_up, 
   return G4R_OK;
 }
 
-int g4r_rope_qkv_bwd_bf16(const void* dq, const void* dk, const void* dv, const float* cos_tab, const float* sin_tab,
-                          void* dqkv, int T, int heads, int head_dim, int pos0, long ldq, long ldk, long ldv,
-                          void* stream) {
-  G4R_REQUIRE(T >= 0 && heads > 0 && head_dim % 16 == 0 && pos0 >= 0, "rope_qkv_bwd: bad shape");
+static int rope_qkv_bwd_launch(const void* dq, const void* dk, const void* dv, const float* cos_tab, const float* sin_tab,
+                               void* dqkv, int T, int heads, int head_dim, int pos0, long ldq, long ldk, long ldv, int period,
+                               void* stream) {
+  G4R_REQUIRE(T >= 0 && heads > 0 && head_dim % 16 == 0 && pos0 >= 0 && period >= 0, "rope_qkv_bwd: bad shape");
   if (T == 0) return G4R_OK;
   G4R_REQUIRE(dq && dk && dv && cos_tab && sin_tab && dqkv, "rope_qkv_bwd: null pointer");
   G4R_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, "rope_qkv_bwd: bad stride");
   const long total = (long)T * heads * (head_dim / 16);
   hipLaunchKernelGGL(rope_qkv_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)dq,
                      (const h16_t*)dk, (const h16_t*)dv, cos_tab, sin_tab, (h16_t*)dqkv, T, heads, head_dim, pos0,
-                     ldq, ldk, ldv);
+                     ldq, ldk, ldv, period);
   G4R_CHECK_LAUNCH("rope_qkv_bwd");
   return G4R_OK;
+}
+
+int g4r_rope_qkv_bwd_bf16(const void* dq, const void* dk, const void* dv, const float* cos_tab, const float* sin_tab,
+                          void* dqkv, int T, int heads, int head_dim, int pos0, long ldq, long ldk, long ldv,
+                          void* stream) {
+  return rope_qkv_bwd_launch(dq, dk, dv, cos_tab, sin_tab, dqkv, T, heads, head_dim, pos0, ldq, ldk, ldv, 0, stream);
+}
+
+// The rows of a whole batch in one launch: `rows` = B * period stacked rows, row r sits at position pos0 + r % period.
+int g4r_rope_qkv_bwd_batch_bf16(const void* dq, const void* dk, const void* dv, const float* cos_tab, const float* sin_tab,
+                                void* dqkv, int rows, int period, int heads, int head_dim, int pos0, long ldq, long ldk,
+                                long ldv, void* stream) {
+  G4R_REQUIRE(period > 0 && rows % period == 0, "rope_qkv_bwd_batch: rows must be a multiple of the sequence length");
+  return rope_qkv_bwd_launch(dq, dk, dv, cos_tab, sin_tab, dqkv, rows, heads, head_dim, pos0, ldq, ldk, ldv, period, stream);
 }
 
 int g4r_cross_entropy_f32(const float* logits, const long* labels, void* dlogits, float* loss_sum,

@@ -35,6 +35,7 @@ _SIGS = {
     "g4r_swiglu_il_bf16": [P, P, c_int, c_int, P],
     "g4r_swiglu_il_bwd_bf16": [P, P, P, c_int, c_int, P],
     "g4r_rope_qkv_bwd_bf16": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, P],
+    "g4r_rope_qkv_bwd_batch_bf16": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, P],
     "g4r_cross_entropy_f32": [P, P, P, P, P, c_int, c_int, c_long, c_long, c_int, P],
     "g4r_transpose_bf16": [P, P, c_int, c_int, c_long, c_long, c_int, P],
     "g4r_colsum_bf16": [P, P, c_int, c_int, c_long, P],
@@ -1043,10 +1044,20 @@ def swiglu_il_bwd(gu, dy):
     return dgu
 
 
-def rope_qkv_bwd(dq, dk, dv, cos, sin, heads, head_dim, pos0=0, out=None):
-    """dq, dk, dv [T, heads*D] (row-strided ok) -> d(qkv) [T, 3*heads*D] (`out`: a dense [T, 3*heads*D] view to fill)."""
+def rope_qkv_bwd(dq, dk, dv, cos, sin, heads, head_dim, pos0=0, out=None, period=0):
+    """dq, dk, dv [T, heads*D] (row-strided ok) -> d(qkv) [T, 3*heads*D] (`out`: a dense [T, 3*heads*D] view to fill).
+    period > 0: the rows are B stacked sequences of `period` tokens each (positions restart): one launch for the batch."""
     _bf16(dq, dk, dv)
     T, HD = dq.shape
+    if period:
+        if out is None:
+            out = torch.empty((T, 3 * HD), dtype=torch.bfloat16, device=dq.device)
+        _bf16(out)
+        assert out.shape == (T, 3 * HD) and out.is_contiguous() and T % period == 0
+        _launch("g4r_rope_qkv_bwd_batch_bf16", (_p(dq), _p(dk), _p(dv), _p(cos), _p(sin), _p(out), T, int(period), heads,
+                                                head_dim, pos0, dq.stride(0), dk.stride(0), dv.stride(0), _stream(dq),),
+                tag="g4r_rope_qkv_bwd_bf16")
+        return out
     if out is None:
         out = torch.empty((T, 3 * HD), dtype=torch.bfloat16, device=dq.device)
     _bf16(out)

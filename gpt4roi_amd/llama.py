@@ -422,9 +422,9 @@ class LlamaDecoder:
             else:
                 dq, dk, dv = K.flash_attn_bwd(S['q'], self.kc[li, :B, :T], self.vc[li, :B, :T], S['a'], da, S['lse'], H,
                                               scale, True)
-            dqkv = torch.empty((B * T, 3 * C), dtype=torch.bfloat16, device=dq.device)
-            for b in range(B):                               # every sequence's rows written in place (no concatenation pass)
-                K.rope_qkv_bwd(dq[b], dk[b], dv[b], self.cos, self.sin, H, D, 0, out=dqkv[b * T:(b + 1) * T])
+            # the whole batch in one launch, every sequence's rows written in place (positions restart every T rows)
+            dqkv = K.rope_qkv_bwd(dq.view(B * T, C), dk.view(B * T, C), dv.view(B * T, C), self.cos, self.sin, H, D, 0,
+                                  period=T)
             dh = K.gemm(dqkv, L['wqkv_t'])
             if tw:
                 grads[f"{li}.wo"] = K.linear_wgrad(dx1, S['a'].view(B * T, C))

@@ -49,6 +49,10 @@ int g4r_swiglu_il_bwd_bf16(const void* gate_up, const void* dy, void* dgate_up, 
 int g4r_rope_qkv_bwd_bf16(const void* dq, const void* dk, const void* dv, const float* cos_tab, const float* sin_tab,
                           void* dqkv, int T, int heads, int head_dim, int pos0, long ldq, long ldk, long ldv,
                           void* stream);
+/* The same for the stacked rows of a whole batch in one launch: rows = B * period, row r at position pos0 + r % period. */
+int g4r_rope_qkv_bwd_batch_bf16(const void* dq, const void* dk, const void* dv, const float* cos_tab, const float* sin_tab,
+                                void* dqkv, int rows, int period, int heads, int head_dim, int pos0, long ldq, long ldk,
+                                long ldv, void* stream);
 
 /*
  * Token cross entropy of llava/model/llava.py:240-252 (labels already shifted by the caller; label < 0 =
