@@ -408,7 +408,7 @@ def test_batched_device_resident_decode_matches_host_loop():
     want = dec.greedy_batch(prompts, n_new)
     got = dec.decode_graph_batch(prompts, n_new)
     assert got == want
-    assert dec._bstate["graph"] is not None
+    assert dec._bstate[(B, False)]["graph"] is not None        # the state pool is keyed by (batch, ragged)
     again = dec.decode_graph_batch(prompts, n_new)
     assert again == want
     short = dec.decode_graph_batch(prompts, 4)
