@@ -191,17 +191,31 @@ class FullShardManager:
             u["pending"] = len(u["names"])
             u["gevent"] = None
 
-    def grad_ready(self, name, grad):
-        """Write `grad` into the unit's transient full gradient buffer; reduce-scatter the unit when it is complete.  Returns
-        True: the caller may drop its tensor."""
-        ui, fi, ei = self.where[name]
-        u = self.units[ui]
-        f = u["flats"][fi]
+    def _gfull(self, f):
         if f.gfull is None:
             f.gfull = self._take(torch.float32, f.padded)
             if f.padded != f.numel:
                 f.gfull[f.numel:].zero_()
-        f.views(f.gfull)[ei].copy_(grad.reshape(f.entries[ei][1]))
+        return f.gfull
+
+    def grad_slot(self, name):
+        """The view of the unit's transient full gradient buffer that receives `name`'s gradient, for producers that can
+        write their result in place (no copy in grad_ready); None for an unknown name."""
+        if name not in self.where:
+            return None
+        ui, fi, ei = self.where[name]
+        f = self.units[ui]["flats"][fi]
+        return f.views(self._gfull(f))[ei]
+
+    def grad_ready(self, name, grad):
+        """Write `grad` into the unit's transient full gradient buffer (unless it was produced there); reduce-scatter the
+        unit when it is complete.  Returns True: the caller may drop its tensor."""
+        ui, fi, ei = self.where[name]
+        u = self.units[ui]
+        f = u["flats"][fi]
+        dst = f.views(self._gfull(f))[ei]
+        if grad.data_ptr() != dst.data_ptr() or grad.dtype != dst.dtype:
+            dst.copy_(grad.reshape(f.entries[ei][1]))
         u["pending"] -= 1
         if u["pending"] == 0:
             self._reduce_unit(u)

@@ -84,10 +84,18 @@ class GradBucketReducer:
             b.work = None
             b.event = None
 
-    def ready(self, param, grad):
-        """Copy `grad` into its slot; launch the bucket's collective when the bucket is complete."""
+    def slot(self, param):
+        """The view of the flat bucket that receives `param`'s gradient: a producer that writes its result there (the
+        weight-gradient GEMMs take an output tensor) saves the copy in `ready` -- one read + one write of every gradient."""
         b, i = self.where[id(param)]
-        b.views[i].copy_(grad)
+        return b.views[i]
+
+    def ready(self, param, grad):
+        """Copy `grad` into its slot (unless it was produced there); launch the bucket's collective when the bucket is
+        complete."""
+        b, i = self.where[id(param)]
+        if grad.data_ptr() != b.views[i].data_ptr() or grad.dtype != b.views[i].dtype:
+            b.views[i].copy_(grad)
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)

@@ -1271,15 +1271,19 @@ def gemm_tn(a, b, out=None, accumulate=False, slices=None):
     return out
 
 
-def linear_wgrad(dy, x, out_dtype=torch.float32, splits=None):
+def linear_wgrad(dy, x, out_dtype=torch.float32, splits=None, out=None):
     """dW [N, K] = dy^T [N, M] . x [M, K] (torch autograd's grad_weight of a Linear).  Operands whose widths and row strides
     are multiples of 8: the TN kernel, straight from the row-major operands.  Otherwise (the 4-wide box embedding, an
-    unpadded vocabulary): transposed copies + one NT GEMM over the zero-padded token axis."""
+    unpadded vocabulary): transposed copies + one NT GEMM over the zero-padded token axis.
+    out: a dense fp32 [N, K] tensor to receive the gradient (a view of an exchange bucket: no copy afterwards)."""
     if out_dtype == torch.float32 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.dim() == 2 and \
             x.dim() == 2 and dy.size(1) % 8 == 0 and x.size(1) % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 \
             and dy.stride(1) == 1 and x.stride(1) == 1 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 \
-            and os.environ.get("G4R_WGRAD_CM", "0") != "1":
-        return gemm_tn(dy, x)
+            and os.environ.get("G4R_WGRAD_CM", "0") != "1" and (out is None or (out.dtype == torch.float32 and out.is_contiguous())):
+        return gemm_tn(dy, x, out=out)
+    if out is not None:
+        out.copy_(linear_wgrad(dy, x, out_dtype=out_dtype, splits=splits))
+        return out
     M = dy.size(0)
     m_pad = -(-M // 64) * 64
     dyt = transpose(dy, m_pad)

@@ -376,16 +376,22 @@ class LlamaDecoder:
         self.pos = T
         return logits, dict(B=B, T=T, saved=saved, x_final=x, xn=xn, checkpoint=checkpoint, rag=rag)
 
-    def backward(self, ctx, dlogits, on_grad=None):
+    def backward(self, ctx, dlogits, on_grad=None, grad_slot=None):
         """dlogits bf16 [B*T, v_pad] (zero in the pad columns) -> d(inputs_embeds) [B*T, C] bf16.
         With `train_weights`, self.grads[name] receives the fp32 weight gradients (layer weights in the
         kernel layout: fused qkv, interleaved gate|up); `on_grad(name, grad)` is called as soon as a layer's gradients
-        exist (last layer first), so a bucketed exchange can start while the earlier layers are still differentiating."""
+        exist (last layer first), so a bucketed exchange can start while the earlier layers are still differentiating;
+        `grad_slot(name)` (optional) returns the dense fp32 tensor the consumer wants that gradient written INTO (a view of
+        its flat exchange bucket) or None: the weight-gradient kernels then write there and no copy follows."""
         B, T = ctx["B"], ctx["T"]
         C, H, D = self.hidden, self.heads, self.head_dim
         scale = 1.0 / math.sqrt(D)
         tw = self.train_weights
         grads = {}
+
+        def wgrad(name, dy, x):
+            out = grad_slot(name) if grad_slot is not None else None
+            grads[name] = K.linear_wgrad(dy, x, out=out.view(dy.size(1), x.size(1)) if out is not None else None)
 
         def emit(*names):
             if on_grad is not None:
@@ -411,8 +417,8 @@ class LlamaDecoder:
             dgu = K.swiglu_il_bwd(S['gu'], df)
             dh2 = K.gemm(dgu, L['wgu_t'])
             if tw:
-                grads[f"{li}.wd"] = K.linear_wgrad(dx, S['f'])
-                grads[f"{li}.wgu"] = K.linear_wgrad(dgu, S['h2'])
+                wgrad(f"{li}.wd", dx, S['f'])
+                wgrad(f"{li}.wgu", dgu, S['h2'])
                 grads[f"{li}.n2"] = torch.zeros_like(L['n2'])
                 grads[f"{li}.n1"] = torch.zeros_like(L['n1'])
             dx1 = K.rmsnorm_bwd(S['x1'], L['n2'], dh2, dres=dx, dgamma=grads.get(f"{li}.n2"), eps=self.eps)
@@ -427,8 +433,8 @@ class LlamaDecoder:
                                   period=T)
             dh = K.gemm(dqkv, L['wqkv_t'])
             if tw:
-                grads[f"{li}.wo"] = K.linear_wgrad(dx1, S['a'].view(B * T, C))
-                grads[f"{li}.wqkv"] = K.linear_wgrad(dqkv, S['h'])
+                wgrad(f"{li}.wo", dx1, S['a'].view(B * T, C))
+                wgrad(f"{li}.wqkv", dqkv, S['h'])
             dx = K.rmsnorm_bwd(S['x'], L['n1'], dh, dres=dx1, dgamma=grads.get(f"{li}.n1"), eps=self.eps)
             if tw:
                 emit(f"{li}.n2", f"{li}.n1", f"{li}.wd", f"{li}.wgu", f"{li}.wo", f"{li}.wqkv")

@@ -114,9 +114,17 @@ class ShardedAdamW:
         for b in self.buckets:
             b.pending, b.event = len(b.entries), None
 
+    def slot(self, name):
+        """The bucket view that receives `name`'s gradient (see GradBucketReducer.slot), or None for an unknown name."""
+        if name not in self.where:
+            return None
+        b, i = self.where[name]
+        return b.gviews[i]
+
     def ready(self, name, grad):
         b, i = self.where[name]
-        b.gviews[i].copy_(grad.reshape(b.gviews[i].shape))
+        if grad.data_ptr() != b.gviews[i].data_ptr() or grad.dtype != b.gviews[i].dtype:
+            b.gviews[i].copy_(grad.reshape(b.gviews[i].shape))
         b.pending -= 1
         if b.pending == 0 and self.world > 1:
             self._async(lambda: self._reduce_scatter(b), b)

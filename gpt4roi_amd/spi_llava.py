@@ -283,13 +283,14 @@ class SPILlavaLlamaModel(nn.Module):
         return logits, dict(sctx=sctx, lctx=lctx, input_ids=input_ids, boxes=bboxes, image_features=image_features)
 
     @torch.no_grad()
-    def backward(self, ctx, dlogits, train_projector=False, on_grad=None):
+    def backward(self, ctx, dlogits, train_projector=False, on_grad=None, grad_slot=None):
         """dlogits bf16 [B*T, v_pad] -> {"spi_module.<key>": fp32 grad, ("mm_projector.weight"/".bias")} in the
         reference's state_dict layouts.  `on_grad(name, grad)` is called as each gradient is produced (head of the
         model first), which is what lets the bucketed exchange overlap with the rest of the backward."""
         cfg = self.config
         dec_cb = (lambda n, g: on_grad(f"llama.{n}", g)) if (on_grad is not None and self.llama.train_weights) else None
-        d_emb = self.llama.backward(ctx["lctx"], dlogits, on_grad=dec_cb)       # [B*T, C] bf16
+        dec_slot = (lambda n: grad_slot(f"llama.{n}")) if (grad_slot is not None and self.llama.train_weights) else None
+        d_emb = self.llama.backward(ctx["lctx"], dlogits, on_grad=dec_cb, grad_slot=dec_slot)       # [B*T, C] bf16
         self._d_emb = d_emb
         flat = ctx["input_ids"].reshape(-1)
         grads = {}

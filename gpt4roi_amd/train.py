@@ -97,7 +97,8 @@ class RegionTrainer:
             tensors = self._exchange_tensors()
             self.reducer.reset()
             on_grad = lambda name, g: self.reducer.ready(tensors[name], g.reshape(tensors[name].shape))  # noqa: E731
-        grads = m.backward(ctx, dlogits, train_projector=self.train_projector, on_grad=on_grad)
+            slot = lambda name: self.reducer.slot(tensors[name]) if name in tensors else None           # noqa: E731
+        grads = m.backward(ctx, dlogits, train_projector=self.train_projector, on_grad=on_grad, grad_slot=slot if live else None)
         self._d_emb = m._d_emb
         self._last_input_ids = input_ids
         grads = self._extra_grads(grads, on_grad)
@@ -272,7 +273,7 @@ class ShardedFullTrainer(FullTrainer):
         logits, ctx = m.forward_train(input_ids, images, bboxes, attention_mask=attention_mask)
         loss, dlogits = m.llama.loss_and_dlogits(logits, labels)
         self.sharded.reset()
-        grads = m.backward(ctx, dlogits, train_projector=True, on_grad=self.sharded.ready)
+        grads = m.backward(ctx, dlogits, train_projector=True, on_grad=self.sharded.ready, grad_slot=self.sharded.slot)
         self._d_emb = m._d_emb
         self._last_input_ids = input_ids
         self._extra_grads(grads, self.sharded.ready)
@@ -392,7 +393,7 @@ class FSDPFullTrainer(FullTrainer):
         logits, ctx = m.forward_train(input_ids, images, bboxes, attention_mask=attention_mask)
         loss, dlogits = dec.loss_and_dlogits(logits, labels)
         f.direction(-1, root=0)
-        grads = m.backward(ctx, dlogits, train_projector=True, on_grad=f.grad_ready)
+        grads = m.backward(ctx, dlogits, train_projector=True, on_grad=f.grad_ready, grad_slot=f.grad_slot)
         self._d_emb = m._d_emb
         self._last_input_ids = input_ids
         self._extra_grads(grads, f.grad_ready)

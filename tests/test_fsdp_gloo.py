@@ -85,7 +85,13 @@ def _worker(rank, world, port, q):
                 mgr.use(ui)
                 for n in reversed(mgr.units[ui]["names"]):
                     assert torch.equal(live[n], fwd[n])
-                    mgr.grad_ready(n, _grad(n, shapes[n], rank, step))
+                    g = _grad(n, shapes[n], rank, step)
+                    if (step + len(n)) % 2:                           # a producer that writes into the unit's buffer itself
+                        slot = mgr.grad_slot(n)
+                        assert slot.shape == g.shape and mgr.grad_slot("no such tensor") is None
+                        slot.copy_(g)
+                        g = slot
+                    mgr.grad_ready(n, g)
                 mgr.release(ui)
             if step == 0:
                 seen = {n: t.clone() for n, t in fwd.items()}

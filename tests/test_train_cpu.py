@@ -146,3 +146,33 @@ def test_collator_matches_reference_code(golden_dir):
     ragged = G.instances()
     ragged[1]["image"] = torch.zeros(3, 4, 4)
     assert isinstance(DataCollatorForDetDataset(0)(ragged)["images"], list) == bool(z["ragged_images_is_list"])
+
+
+def test_gradient_slots_save_the_copy_into_the_exchange_bucket():
+    """GradBucketReducer.slot(param) hands the producer the bucket view itself: a gradient written there is reported with
+    no copy (ready() recognises its own storage), any other tensor is copied as before; finish() returns the same views."""
+    from gpt4roi_amd.grad_reduce import GradBucketReducer
+    p1, p2 = torch.nn.Parameter(torch.zeros(4, 6)), torch.nn.Parameter(torch.zeros(10))
+    red = GradBucketReducer([p1, p2], bucket_bytes=1 << 20, comm_dtype=torch.float32)
+    red.reset()
+    s1 = red.slot(p1)
+    assert s1.shape == (4, 6) and s1.dtype == torch.float32
+    s1.copy_(torch.arange(24.).view(4, 6))               # the "kernel" writes its result into the bucket
+    calls = []
+    orig = torch.Tensor.copy_
+
+    def spy(self, *a, **k):
+        calls.append(self.data_ptr())
+        return orig(self, *a, **k)
+    torch.Tensor.copy_ = spy
+    try:
+        red.ready(p1, s1)                                 # produced in place: no copy
+        assert calls == []
+        g2 = torch.full((10,), 2.0)
+        red.ready(p2, g2)                                 # a foreign tensor: copied
+        assert calls == [red.slot(p2).data_ptr()]
+    finally:
+        torch.Tensor.copy_ = orig
+    out = red.finish()
+    assert torch.equal(out[id(p1)], torch.arange(24.).view(4, 6)) and torch.equal(out[id(p2)], torch.full((10,), 2.0))
+    assert out[id(p1)].data_ptr() == s1.data_ptr()
