@@ -96,3 +96,34 @@ def test_mmcv_shim_resolves_the_op_by_name():
             sys.modules.pop(k, None)
             if v is not None:
                 sys.modules[k] = v
+
+
+def test_conv_wgrad_slice_planner_on_the_host():
+    """g4r_conv3x3_wgrad_nhwc_slices is host code (no GPU): the slice count the workspace is sized by -- every level cut
+    into slices of about `slice_tiles` K tiles of 32 bordered pixels; unsupported shapes answer -1."""
+    import ctypes
+
+    from gpt4roi_amd import _lib
+    lib = _lib.lib()
+    f = lib.g4r_conv3x3_wgrad_nhwc_slices
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4
+
+    def slices(sizes, B, cin, cout, st):
+        h = (ctypes.c_int * len(sizes))(*[s[0] for s in sizes])
+        w = (ctypes.c_int * len(sizes))(*[s[1] for s in sizes])
+        return f(len(sizes), ctypes.cast(h, ctypes.c_void_p), ctypes.cast(w, ctypes.c_void_p), B, cin, cout, st)
+
+    def expect(sizes, B, st):
+        n = 0
+        for hh, ww in sizes:
+            nk = -(-(B * (hh + 2) * (ww + 2)) // 32)
+            n += max(1, -(-nk // st))
+        return n
+    pyr = [(192, 192), (96, 96), (48, 48), (24, 24)]
+    assert slices(pyr, 8, 1024, 1024, 589) == expect(pyr, 8, 589) == 24
+    assert slices([(14, 14)], 64, 1024, 1024, 64) == expect([(14, 14)], 64, 64)
+    assert slices([(7, 33)], 3, 256, 768, 8) == expect([(7, 33)], 3, 8)
+    assert slices(pyr, 8, 1000, 1024, 589) == -1            # channels must be multiples of 256
+    assert slices(pyr + [(12, 12)], 8, 1024, 1024, 589) == -1        # at most four levels
+    assert slices(pyr, 8, 1024, 1024, 4) == -1              # slices of at least 8 K tiles
