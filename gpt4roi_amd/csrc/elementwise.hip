@@ -604,6 +604,33 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const h16_t* __restrict__
 }
 
 // float32 -> bf16 and bf16 -> float32 casts (weights / feature hand-over)
+// torch conv weight [Co][Ci][3][3] fp32 -> a kernel layout in the 16-bit storage type, one pass (the region module's weights
+// change every training step: rounds 1-3 re-derived both layouts with torch permute / flip / cat / cast passes):
+//   transposed = 0: dst[co * ld + off + tap * Ci + ci] = w[co][ci][tap]          rows of the implicit-GEMM forward weight
+//   transposed = 1: dst[(ci) * ld + off + tap * Co + co] = w[co][ci][8 - tap]    rows of the data-gradient weight: the conv
+//                   with the 180-degree rotated, channel-transposed filter (what conv2d's backward applies to dY)
+__global__ __launch_bounds__(256) void conv3x3_weight_layout_kernel(const float* __restrict__ w, h16_t* __restrict__ dst,
+                                                                     int Co, int Ci, long ld, long off, int transposed) {
+  const long n = (long)Co * Ci;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    long co, ci;
+    if (transposed) { ci = i / Co; co = i - ci * Co; } else { co = i / Ci; ci = i - co * Ci; }   // fastest index = written dim
+    const float* src = w + (co * Ci + ci) * 9;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = src[t];
+    if (transposed) {
+      h16_t* o = dst + ci * ld + off + co;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) o[(long)t * Co] = f32_to_h16(v[8 - t]);
+    } else {
+      h16_t* o = dst + co * ld + off + ci;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) o[(long)t * Ci] = f32_to_h16(v[t]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, h16_t* __restrict__ y,
                                                             long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
@@ -836,6 +863,15 @@ int g4r_add_rows_bf16(const void* a, const void* b, void* y, long rows, int C, l
   hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, (hipStream_t)stream,
                      (const h16_t*)a, (const h16_t*)b, (h16_t*)y, rows, C, brows);
   G4R_CHECK_LAUNCH("add_rows");
+  return G4R_OK;
+}
+
+int g4r_conv3x3_weight_layout_bf16(const float* w, void* dst, int Co, int Ci, long ld, long off, int transposed, void* stream) {
+  G4R_REQUIRE(Co > 0 && Ci > 0 && off >= 0 && ld >= off + 9L * (transposed ? Co : Ci), "conv3x3_weight_layout: bad shape");
+  G4R_REQUIRE(w && dst, "conv3x3_weight_layout: null pointer");
+  hipLaunchKernelGGL(conv3x3_weight_layout_kernel, dim3(grid_for((long)Co * Ci)), dim3(256), 0, (hipStream_t)stream, w,
+                     (h16_t*)dst, Co, Ci, ld, off, transposed);
+  G4R_CHECK_LAUNCH("conv3x3_weight_layout");
   return G4R_OK;
 }
 

@@ -53,6 +53,7 @@ _SIGS = {
                                               c_int, P],
     "g4r_nhwc_pad_bf16": [P, P, c_int, c_int, c_int, c_int, c_long, P],
     "g4r_conv3x3_wgrad_nhwc_bf16": [P, P, c_int, P, P, c_int, c_int, c_int, c_int, P, P, c_int, P],
+    "g4r_conv3x3_weight_layout_bf16": [P, P, c_int, c_int, c_long, c_long, c_int, P],
     "g4r_gemm_tn_bf16": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P],
     "g4r_conv3x3_wgrad_nhwc_slices": [c_int, P, P, c_int, c_int, c_int, c_int],
     "g4r_nhwc_to_cm_padded_bf16": [P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_int, P],
@@ -575,8 +576,22 @@ def prep_conv3x3_weight(ws, dtype=torch.bfloat16):
     """list of torch conv weights [Cout, Cin, 3, 3] (one per group) -> [Cout, groups*9*Cin] in the 16-bit storage type."""
     if isinstance(ws, torch.Tensor):
         ws = [ws]
+    if _layout_kernel_ok(ws):
+        co, ci, G = ws[0].size(0), ws[0].size(1), len(ws)
+        out = torch.empty((co, G * 9 * ci), dtype=dtype, device=ws[0].device)
+        for g, w in enumerate(ws):
+            _launch("g4r_conv3x3_weight_layout_bf16", (_p(w), _p(out), co, ci, out.stride(0), g * 9 * ci, 0, _stream(w),),
+                    tag="g4r_conv3x3_weight_layout", dt=_h16(dtype))
+        return out
     parts = [w.permute(0, 2, 3, 1).reshape(w.size(0), 1, 9 * w.size(1)) for w in ws]
     return torch.cat(parts, 1).reshape(ws[0].size(0), -1).to(dtype).contiguous()
+
+
+def _layout_kernel_ok(ws):
+    """fp32 contiguous [Co, Ci, 3, 3] weights of one shape on the GPU: the one-pass layout kernel applies."""
+    w0 = ws[0]
+    return all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4 and w.shape == w0.shape
+               and w.shape[2:] == (3, 3) for w in ws)
 
 
 def flash_attn(q, k, v, heads, scale, causal=False, out=None, kv_len_dev=None, lse=None):
@@ -1395,6 +1410,13 @@ def conv3x3_dgrad_weight(ws):
     result [groups*Cin, 9*Cout]."""
     if isinstance(ws, torch.Tensor):
         ws = [ws]
+    if _layout_kernel_ok(ws):
+        co, ci, G = ws[0].size(0), ws[0].size(1), len(ws)
+        out = torch.empty((G * ci, 9 * co), dtype=torch.bfloat16, device=ws[0].device)
+        for g, w in enumerate(ws):
+            _launch("g4r_conv3x3_weight_layout_bf16", (_p(w), _p(out[g * ci:]), co, ci, out.stride(0), 0, 1, _stream(w),),
+                    tag="g4r_conv3x3_weight_layout")
+        return out
     wt = torch.cat([w.flip(2, 3).permute(1, 0, 2, 3) for w in ws], 0)
     return prep_conv3x3_weight(wt)
 

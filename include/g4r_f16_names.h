@@ -40,5 +40,6 @@
 #define g4r_splice_embed_bf16               g4r_splice_embed_f16
 #define g4r_add_rows_bf16                   g4r_add_rows_f16
 #define g4r_cast_f32_to_bf16                g4r_cast_f32_to_f16
+#define g4r_conv3x3_weight_layout_bf16      g4r_conv3x3_weight_layout_f16
 #define g4r_roi_align_mlvl_nhwc_bf16        g4r_roi_align_mlvl_nhwc_f16
 #endif

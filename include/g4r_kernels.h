@@ -244,6 +244,11 @@ int g4r_argmax_rows_f32(const float* logits, long ld, int rows, int N, long* out
 /* y = a + b[row % brows]  ("fuse_roi_feats + pos_embedd", layers.py:328). */
 int g4r_add_rows_bf16(const void* a, const void* b, void* y, long rows, int C, long brows, void* stream);
 int g4r_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
+/* torch conv weight [Co][Ci][3][3] fp32 -> the kernels' 16-bit layouts in one pass.  transposed = 0: the forward weight
+ * rows of g4r_conv3x3_nhwc_bf16, dst[co*ld + off + tap*Ci + ci] = w[co][ci][tap] (off = g*9*Ci for group g of a grouped
+ * conv); transposed = 1: the data-gradient weight, dst[ci*ld + off + tap*Co + co] = w[co][ci][8 - tap] (the 180-degree
+ * rotated, channel-transposed filter of conv2d's backward; `dst` = the row block of group g). */
+int g4r_conv3x3_weight_layout_bf16(const float* w, void* dst, int Co, int Ci, long ld, long off, int transposed, void* stream);
 
 /*
  * Image front end: uint8 HWC (RGB, or BGR with bgr = 1) -> fp32 CHW [3, out_h, out_w],

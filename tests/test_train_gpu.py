@@ -347,6 +347,22 @@ def test_conv3x3_weight_and_input_gradients(B, H, W, cin, cout):
     assert relerr(dx, xr.grad) < 1e-2
 
 
+@pytest.mark.parametrize("G,co,ci", [(1, 64, 48), (4, 32, 40), (1, 1024, 1024)])
+def test_conv_weight_layouts_in_one_pass(G, co, ci):
+    """g4r_conv3x3_weight_layout: fp32 torch conv weights -> the forward rows [Co, G*9*Ci] and the data-gradient rows
+    [G*Ci, 9*Co] (rotated, channel-transposed filter) == the torch permute / flip / cat / cast expressions, bit for bit."""
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.randn(co, ci, 3, 3, generator=g).to(DEV) for _ in range(G)]
+    for dt in (torch.bfloat16, torch.float16):
+        want = torch.cat([w.permute(0, 2, 3, 1).reshape(co, 1, 9 * ci) for w in ws], 1).reshape(co, -1).to(dt)
+        got = K.prep_conv3x3_weight(ws, dt)
+        assert got.dtype == dt and torch.equal(got, want)
+    wt = torch.cat([w.flip(2, 3).permute(1, 0, 2, 3) for w in ws], 0)
+    want = wt.permute(0, 2, 3, 1).reshape(G * ci, 9 * co).to(torch.bfloat16)
+    assert torch.equal(K.conv3x3_dgrad_weight(ws), want)
+    assert torch.equal(K.conv3x3_dgrad_weight([w.to(torch.bfloat16) for w in ws]), want)      # other dtypes: the torch path
+
+
 def test_conv3x3_weight_gradient_of_a_pyramid_in_one_launch():
     """ConvWgradNHWC over several map geometries that share the weight (the levels of a fuse round,
     gpt4roi/models/layers.py:218-236) == the sum of the per-level autograd gradients; slices of different levels end up in
