@@ -48,13 +48,14 @@ def parse():
     ap.add_argument("--llama-layers", type=int, default=32, help="debug only; anything but 32 marks the line invalid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="independent launch sequences in flight per GPU, one HIP stream each (1 = strictly serial)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent launch sequences in flight per GPU, one HIP stream each (1 = strictly serial; with 16 "
+                         "merged requests a second sequence no longer helps: profiles/r04_merge_sweep.txt)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit storage type of the whole path: bf16 (the reference's training dtype; the default) or fp16 (its "
                          "serving dtype, app.py:74-98) -- same MFMA rate, same bytes")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (fp16, 224^2, single request)")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=16,
                     help="batch-1 requests merged into ONE launch sequence per step (continuous batching: the weights are "
                          "streamed once for all of them); value counts every request's region tokens")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")

@@ -14,6 +14,8 @@ from gpt4roi_amd import kernels as K
     (767, 256, 4096, 14, None),        # the gate|up remainder: 64x64 ring-4 (+ 2 K slices in gemm())
     (577, 3072, 1024, 14, None), (577, 1024, 1024, 14, None), (577, 4096, 1024, 13, None), (577, 1024, 4096, 14, None),  # ViT, batch 1
     (4616, 3072, 1024, 24, None), (4616, 1024, 4096, 0, None),                                                           # ViT, batch 8
+    (12272, 12288, 4096, 24, None), (12272, 4096, 4096, 24, None), (12272, 22016, 4096, 24, 21760), (12272, 4096, 11008, 24, None),   # 16 merged requests (bench default): 192 x 256 ring tiles in whole waves
+    (9232, 3072, 1024, 24, None), (9232, 4096, 1024, 0, None), (9232, 1024, 4096, 28, None),                                          # ViT, batch 16
     (8, 12288, 4096, 14, None), (8, 4096, 4096, 14, None), (8, 22016, 4096, 13, None), (16, 4096, 11008, 14, None),      # batched decode
 ])
 def test_gemm_tile_dispatch(M, N, Kd, tile, main):

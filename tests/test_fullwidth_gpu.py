@@ -67,6 +67,12 @@ PROD_SHAPES = [
     (6136, 4096, 11008, None, torch.bfloat16, "8 merged: down_proj (+residual)"),
     (6136, 22016, 4096, "swiglu", torch.bfloat16, "8 merged: gate|up, 8 waves + thin tail"),
     (4616, 3072, 1024, None, torch.bfloat16, "ViT fused q|k|v at batch 8 (+bias)"),
+    # 16 merged requests (the bench default since the second sweep of round 4)
+    (12272, 12288, 4096, None, torch.bfloat16, "16 merged: fused q|k|v"),
+    (12272, 4096, 4096, None, torch.bfloat16, "16 merged: o_proj (+residual)"),
+    (12272, 22016, 4096, "swiglu", torch.bfloat16, "16 merged: gate|up"),
+    (12272, 4096, 11008, None, torch.bfloat16, "16 merged: down_proj (+residual)"),
+    (9232, 4096, 1024, "quick_gelu", torch.bfloat16, "ViT fc1 at batch 16 (+bias, QuickGELU)"),
 ]
 
 
