@@ -33,9 +33,14 @@ struct AttnBwdArgs {
   int causal;
 };
 
+// XOR swizzle of the 16-byte slots of a row-major tile row.  D = 128 (16 slots per 256-byte row): the two bit pairs of
+// row & 15 swapped -- 16 consecutive rows still take 16 different slot offsets (the ds_read_b128 fragment reads of 8 / 16
+// consecutive rows stay conflict-free, as with the plain row & 15 of rounds 1-3), AND four consecutive rows r0..r0+3 (r0 a
+// multiple of 4) differ in slot bits 2-3, which is what the transposing reads below need: a 16-lane group of
+// ds_read_b64_tr_b16 fetches 4 rows x 32 bytes, and with this swizzle those land in four different 64-byte bank groups.
 template <int D>
 __device__ __forceinline__ int row_swz(int row) {
-  return D == 128 ? (row & 15) : ((row >> 1) & 7);
+  return D == 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row >> 1) & 7);
 }
 
 // 64 rows x D of a [rows, H*D]-strided matrix -> LDS, row-major with the 16-byte slots of a row XOR-swizzled
@@ -134,14 +139,38 @@ __device__ __forceinline__ h16x8 frag_rows(const h16_t* tile, int row, int kk, i
                                           (((kk * 2 + hi) ^ row_swz<D>(row)) << 4));
 }
 
-// A operand from a transposed tile: row (= head-dim index), 8 of the 16 contraction indices of this MFMA
-// step in the permuted order the C-layout registers of the other operand already have.
-__device__ __forceinline__ h16x8 frag_transposed(const h16_t* tile, int row, int base) {
-  const h16_t* r = tile + row * T_LD + base;
-  const uint2v lo = *reinterpret_cast<const uint2v*>(r);
-  const uint2v hi2 = *reinterpret_cast<const uint2v*>(r + 8);
-  const uint4v w = {lo.x, lo.y, hi2.x, hi2.y};
-  return __builtin_bit_cast(h16x8, w);
+// A operand = the TRANSPOSE of a row-major tile (rows = the 64 streamed keys / queries, columns = head dim), read with
+// ds_read_b64_tr_b16 straight from the row-major image (round 4; rounds 1-3 wrote a second, transposed image of every tile
+// with 8-byte stores from packed registers).  The MFMA's A row is the head-dim index d = 32 * dblk + (lane & 31); its 8
+// contraction indices are tile rows base + 4 hi + {0..3} and base + 8 + 4 hi + {0..3} -- the order the C-layout registers of
+// the other operand (P / dS, packed by pack8) already have.  A 16-lane group fetches [4 rows][16 columns]: lane c of it
+// supplies the 8 bytes at row (c >> 2), columns 4 (c & 3)..+3 and receives column c of the four rows.
+template <int D>
+struct TrLane {
+  int off[2][D / 32];     // byte offset inside a tile (without the 16-row block) for the two reads, per 32-wide head-dim block
+  __device__ __forceinline__ void init(int lane) {
+    const int c = lane & 15, g = (lane >> 4) & 1, hi = lane >> 5, r4 = c >> 2;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int rowl = 4 * hi + r4 + 8 * rd;                  // row & 15: all the swizzle depends on
+      const int sw = row_swz<D>(rowl);
+#pragma unroll
+      for (int d = 0; d < D / 32; ++d) {
+        const int slot = d * 4 + g * 2 + ((c >> 1) & 1);
+        off[rd][d] = rowl * (D * 2) + ((slot ^ sw) << 4) + (c & 1) * 8;
+      }
+    }
+  }
+};
+
+template <int D>
+__device__ __forceinline__ h16x8 frag_tr(const h16_t* tile, const TrLane<D>& tl, int dblk, int base16) {
+  // base16: first row of the 16-row block (a multiple of 16)
+  const char* t = reinterpret_cast<const char*>(tile) + base16 * (D * 2);
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(t + tl.off[0][dblk]));
+  const short4v up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(t + tl.off[1][dblk]));
+  const short8 vv = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+  return __builtin_bit_cast(h16x8, vv);
 }
 
 __device__ __forceinline__ h16x8 pack8(const float* v) {
@@ -190,7 +219,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(AttnBwdArgs p) 
   constexpr int DB = D / 32;
   __shared__ __attribute__((aligned(16))) h16_t Ks[TB * D];
   __shared__ __attribute__((aligned(16))) h16_t Vs[TB * D];
-  __shared__ __attribute__((aligned(16))) h16_t Kt[D * T_LD];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, ql = lane & 31;
@@ -214,6 +242,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(AttnBwdArgs p) 
   }
   const float lse_i = p.lse[((size_t)b * p.H + h) * p.Tq + qr];
   const float delta_i = p.delta[((size_t)b * p.H + h) * p.Tq + qr];
+  TrLane<D> trl;
+  trl.init(lane);
   const float sc2 = p.scale * 1.4426950408889634f;
 
   float16v oacc[DB];
@@ -235,7 +265,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(AttnBwdArgs p) 
   for (int j0 = 0; j0 < kend; j0 += TB) {
     tile_store_rows<D, NT>(kreg, Ks, tid);
     tile_store_rows<D, NT>(vreg, Vs, tid);
-    tile_store_transposed<D, NT>(kreg, Kt, tid);
     __syncthreads();
     if (j0 + TB < kend) {                                   // the next tile's rows travel while this tile is multiplied
       tile_load<D, NT>(kreg, Kb, p.k_row, j0 + TB, p.Tk, tid);
@@ -274,10 +303,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(AttnBwdArgs p) 
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const h16x8 pf = pack8(ds + hf * 8);
-        const int kbase = kb * 32 + hf * 16 + 4 * hi;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
-          oacc[d] = G4R_MFMA_32X32X16(frag_transposed(Kt, d * 32 + ql, kbase), pf, oacc[d], 0, 0, 0);
+          oacc[d] = G4R_MFMA_32X32X16(frag_tr<D>(Ks, trl, d, kb * 32 + hf * 16), pf, oacc[d], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -304,13 +332,13 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnBwdArgs p)
   constexpr int KB = NW * 32;
   constexpr int KSTEPS = D / 16;
   constexpr int DB = D / 32;
-  extern __shared__ __attribute__((aligned(16))) char dkv_smem[];  // 67.5 KB at D = 128: dynamic
+  extern __shared__ __attribute__((aligned(16))) char dkv_smem[];  // 32.5 KB at D = 128
   h16_t* Qs = reinterpret_cast<h16_t*>(dkv_smem);
   h16_t* Gs = Qs + TB * D;        // dO rows
-  h16_t* Qt = Gs + TB * D;
-  h16_t* Gt = Qt + D * T_LD;      // dO transposed
-  float* lse_s = reinterpret_cast<float*>(Gt + D * T_LD);
+  float* lse_s = reinterpret_cast<float*>(Gs + TB * D);
   float* delta_s = lse_s + TB;
+  TrLane<D> trl;
+  trl.init(threadIdx.x & 63);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, ql = lane & 31;
@@ -363,8 +391,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnBwdArgs p)
   for (int i0 = q_begin; i0 < p.Tq; i0 += TB) {
     tile_store_rows<D, NT>(qreg, Qs, tid);
     tile_store_rows<D, NT>(greg, Gs, tid);
-    tile_store_transposed<D, NT>(qreg, Qt, tid);
-    tile_store_transposed<D, NT>(greg, Gt, tid);
     if (tid < TB) {
       lse_s[tid] = lse_r;
       delta_s[tid] = delta_r;
@@ -419,11 +445,11 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnBwdArgs p)
     auto grad_block = [&](int qb) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const int ibase = qb * 32 + hf * 16 + 4 * hi;
+        const int ibase = qb * 32 + hf * 16;
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
-          dvacc[d] = G4R_MFMA_32X32X16(frag_transposed(Gt, d * 32 + ql, ibase), pfr[qb][hf], dvacc[d], 0, 0, 0);
-          dkacc[d] = G4R_MFMA_32X32X16(frag_transposed(Qt, d * 32 + ql, ibase), sfr[qb][hf], dkacc[d], 0, 0, 0);
+          dvacc[d] = G4R_MFMA_32X32X16(frag_tr<D>(Gs, trl, d, ibase), pfr[qb][hf], dvacc[d], 0, 0, 0);
+          dkacc[d] = G4R_MFMA_32X32X16(frag_tr<D>(Qs, trl, d, ibase), sfr[qb][hf], dkacc[d], 0, 0, 0);
         }
       }
     };
@@ -465,7 +491,7 @@ int launch_bwd(const AttnBwdArgs& a, int B, hipStream_t stream) {
   hipLaunchKernelGGL((attn_bwd_dq_kernel<D, NW>), dim3(g4r_ceil_div(a.Tq, NW * 32), a.H, B), dim3(NW * 64), 0,
                      stream, a);
   G4R_CHECK_LAUNCH("attn_bwd_dq");
-  constexpr int DKV_LDS = (2 * TB * D + 2 * D * T_LD) * 2 + 2 * TB * 4;
+  constexpr int DKV_LDS = 2 * TB * D * 2 + 2 * TB * 4;
   static G4rPerDeviceOnce attr_set;
   if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D, NW>),
