@@ -7,10 +7,11 @@
 // tile ever needs a transpose:
 //   dQ     : "lane owns a query" (exactly the forward orientation).  S^T = K Q^T and dP^T = V dO^T land
 //            with one query per lane, so LSE and Delta are lane scalars; dQ^T += K^T dS^T uses the packed
-//            dS^T registers as the B operand and K staged TRANSPOSED in LDS as the A operand.
+//            dS^T registers as the B operand and K^T as the A operand, read TRANSPOSED (ds_read_b64_tr_b16) from the
+//            row-major K tile in LDS.
 //   dK, dV : "lane owns a key".  S = Q K^T and dP = dO V^T with the key block's K/V fragments resident in
-//            registers and the streamed query tile in LDS; dV^T += dO^T P and dK^T += Q^T dS use Q / dO
-//            staged transposed.  LSE / Delta of the 64 streamed queries sit in LDS (broadcast reads).
+//            registers and the streamed query tile in LDS; dV^T += dO^T P and dK^T += Q^T dS read Q / dO
+//            transposed from the same row-major tiles.  LSE / Delta of the 64 streamed queries sit in LDS.
 // P is recomputed from the forward's log2-domain LSE: P = 2^(s*scale*log2e - lse).  Delta = rowsum(dO*O)
 // comes from a small pre-pass.  Nothing is atomically accumulated: results are bit-reproducible.
 #include "g4r_common.h"
@@ -19,7 +20,6 @@ namespace {
 
 
 constexpr int TB = 64;     // rows of the streamed tile (keys for dQ, queries for dK/dV)
-constexpr int T_LD = 68;   // row stride of a transposed tile (136 B: conflict-free 8-byte reads)
 
 struct AttnBwdArgs {
   const h16_t *Q, *K, *V, *O, *dO;
@@ -59,37 +59,9 @@ __device__ __forceinline__ void stage_rows(h16_t* dst, const h16_t* src, long ro
   }
 }
 
-// the same 64 rows TRANSPOSED: dst[d][row], stride T_LD.  A thread takes 4 consecutive rows x 8 columns and
-// writes, for each column, the 4 rows as one 8-byte store.
-template <int D, int NT>
-__device__ __forceinline__ void stage_transposed(h16_t* dst, const h16_t* src, long row_stride, int r0,
-                                                 int rmax, int tid) {
-  constexpr int SLOTS = D / 8;
-#pragma unroll
-  for (int u = 0; u < 16 * SLOTS / NT; ++u) {
-    const int pu = u * NT + tid;
-    const int rq = pu % 16, vs = pu / 16;
-    unsigned w[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int r = r0 + rq * 4 + j;
-      if (r > rmax - 1) r = rmax - 1;
-      const uint4v v = *reinterpret_cast<const uint4v*>(src + (size_t)r * row_stride + vs * 8);
-      w[j][0] = v.x, w[j][1] = v.y, w[j][2] = v.z, w[j][3] = v.w;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint2v lo = {(w[0][e] & 0xffffu) | (w[1][e] << 16), (w[2][e] & 0xffffu) | (w[3][e] << 16)};
-      const uint2v hi2 = {(w[0][e] >> 16) | (w[1][e] & 0xffff0000u), (w[2][e] >> 16) | (w[3][e] & 0xffff0000u)};
-      *reinterpret_cast<uint2v*>(dst + (vs * 8 + 2 * e) * T_LD + rq * 4) = lo;
-      *reinterpret_cast<uint2v*>(dst + (vs * 8 + 2 * e + 1) * T_LD + rq * 4) = hi2;
-    }
-  }
-}
-
 // Round 4: ONE global pass per streamed tile and a register prefetch.  A thread holds 4 consecutive rows x one 16-byte slot
-// (the mapping the transposed write needs); from those 4 registers it writes BOTH LDS images -- the row-major swizzled one
-// (4 x 16-byte stores) and the transposed one (8 x 8-byte stores) -- so a tile is read from memory once instead of twice, and
+// and writes the row-major swizzled LDS image from them (4 x 16-byte stores; until the transposing reads below it also wrote a
+// transposed image, 8 x 8-byte stores from the same registers), and
 // `tile_load` for tile i+1 is issued before the MFMAs of tile i (the kernels run ONE workgroup per CU at 284-358 registers per
 // lane: without the prefetch nothing overlapped the load latency, and a 64-row tile took ~11 us against ~1 us of MFMAs).
 template <int D, int NT>
@@ -116,20 +88,6 @@ __device__ __forceinline__ void tile_store_rows(const TileRegs<D, NT>& t, h16_t*
   for (int j = 0; j < 4; ++j) {
     const int row = rq * 4 + j;
     *reinterpret_cast<uint4v*>(reinterpret_cast<char*>(dst) + row * (D * 2) + ((vs ^ row_swz<D>(row)) << 4)) = t.w[j];
-  }
-}
-
-template <int D, int NT>
-__device__ __forceinline__ void tile_store_transposed(const TileRegs<D, NT>& t, h16_t* dst, int tid) {
-  const int rq = tid % 16, vs = tid / 16;
-  const unsigned w[4][4] = {{t.w[0].x, t.w[0].y, t.w[0].z, t.w[0].w}, {t.w[1].x, t.w[1].y, t.w[1].z, t.w[1].w},
-                            {t.w[2].x, t.w[2].y, t.w[2].z, t.w[2].w}, {t.w[3].x, t.w[3].y, t.w[3].z, t.w[3].w}};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const uint2v lo = {(w[0][e] & 0xffffu) | (w[1][e] << 16), (w[2][e] & 0xffffu) | (w[3][e] << 16)};
-    const uint2v hi2 = {(w[0][e] >> 16) | (w[1][e] & 0xffff0000u), (w[2][e] >> 16) | (w[3][e] & 0xffff0000u)};
-    *reinterpret_cast<uint2v*>(dst + (vs * 8 + 2 * e) * T_LD + rq * 4) = lo;
-    *reinterpret_cast<uint2v*>(dst + (vs * 8 + 2 * e + 1) * T_LD + rq * 4) = hi2;
   }
 }
 
