@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgpt4roi_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

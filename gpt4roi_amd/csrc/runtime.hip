@@ -19,6 +19,6 @@ int g4r_note_error(int code, const char* what) {
 }
 
 extern "C" {
-int g4r_abi_version(void) { return 4; }
+int g4r_abi_version(void) { return 5; }   // 5 (round 4): + the f16 instantiation, ragged decode, TN GEMM / NHWC weight gradients, weight layouts
 const char* g4r_last_error(void) { return g_last_error; }
 }

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert len(names) >= 45
     for n in sorted(names):
         assert hasattr(lib, n), n
-    assert lib.g4r_abi_version() == 4
+    assert lib.g4r_abi_version() == 5
 
 
 def test_argument_validation_without_a_gpu(lib):
