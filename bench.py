@@ -106,9 +106,10 @@ def make_inputs(args, ids, device, seed, batch=None, image_size=None):
     return image, boxes, prompt
 
 
-def timed_replay(model, image, boxes, prompt, steps, warmup=2, streams=1):
+def timed_replay(model, image, boxes, prompt, steps, warmup=2, streams=1, attention_mask=None):
     """Seconds per launch sequence of `model` over (image, boxes, prompt), hipGraph replay on `streams` HIP streams
-    (one request context each), device-synchronised both sides.  Used by the extra legs (never by `value`)."""
+    (one request context each), device-synchronised both sides.  Used by the extra legs (never by `value`).
+    attention_mask: a prepared llama.RaggedLayout (requests of different prompt lengths merged; tools/ragged_merge.py)."""
     size = image.size(-1)
     ctxs = [model] + [model.clone_context() for _ in range(streams - 1)]
     sts = [torch.cuda.Stream(device=image.device) for _ in ctxs]
@@ -116,12 +117,12 @@ def timed_replay(model, image, boxes, prompt, steps, warmup=2, streams=1):
     graphs = []
     for c, st, rq in zip(ctxs, sts, reqs):
         with torch.cuda.stream(st):
-            c(input_ids=prompt, images=image, bboxes=rq)
-            c(input_ids=prompt, images=image, bboxes=rq)
+            c(input_ids=prompt, images=image, bboxes=rq, attention_mask=attention_mask)
+            c(input_ids=prompt, images=image, bboxes=rq, attention_mask=attention_mask)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=st):
-            keep = c(input_ids=prompt, images=image, bboxes=rq)
+            keep = c(input_ids=prompt, images=image, bboxes=rq, attention_mask=attention_mask)
         graphs.append((g, keep))
     torch.cuda.synchronize()
 

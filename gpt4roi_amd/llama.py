@@ -45,15 +45,19 @@ class RaggedLayout:
         inv = torch.full((B * T,), -1, dtype=torch.int32, device=dev)
         inv[keep] = torch.arange(self.nnz, dtype=torch.int32, device=dev)
         self.inv = inv                                                                   # padded row -> packed row (-1: pad)
+        self.pos0 = torch.tensor(self.lens + [T], dtype=torch.int32, device=dev)         # the ragged decode state after the prompt:
+        #                                                                                  B cache lengths + the RoPE position
         keep_h = keep.tolist()
         self.last = torch.tensor([keep_h[self.cu[i + 1] - 1] if self.lens[i] else -1 for i in range(B)], dtype=torch.int32,
                                  device=dev)                                             # padded row of each sequence's last token
 
     @staticmethod
     def of(mask, max_positions):
-        """None for `no mask` / all ones (the dense path), a layout otherwise."""
-        if mask is None:
-            return None
+        """None for `no mask` / all ones (the dense path), a layout otherwise.  A layout passes through: a serving loop
+        prepares it once per batch, outside the launch sequence, which then has no host <-> device traffic and can be captured
+        in a hipGraph (the constructor reads the mask on the host)."""
+        if mask is None or isinstance(mask, RaggedLayout):
+            return mask
         m = mask.to(torch.bool)
         if bool(m.all()):
             return None
@@ -179,7 +183,7 @@ class LlamaDecoder:
         if rag is not None:
             assert pos0 == 0 and T > 1 and (rag.B, rag.T) == (B, T), "a padding mask enters with the prompt (empty cache)"
             self.ragged = rag
-            self._rag_pos = torch.tensor(rag.lens + [T], dtype=torch.int32, device=inputs_embeds.device)
+            self._rag_pos = rag.pos0.clone()
         elif pos0 == 0:
             self.ragged = None
         elif self.ragged is not None:
