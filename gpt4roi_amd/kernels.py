@@ -1453,8 +1453,9 @@ class ConvWgradNHWC:
         self._h = (c_int * L)(*[h for h, _ in self.sizes])
         self._w = (c_int * L)(*[w for _, w in self.sizes])
         # slices of equal length over all levels, about 16 for the largest level: 144 workgroups (16 tiles x 9 taps at
-        # 1024 x 1024) per slice -> ~3000 work items of ~600 K tiles for the 336^2 pyramid at 8 images
-        self.slice_tiles = max(64, -(-max(nks) // 16))
+        # 1024 x 1024) per slice -> ~3000 work items of ~600 K tiles for the 336^2 pyramid at 8 images (measured: 12 slices of
+        # the largest level 6.20 ms per round, 16: 6.03, 24: 6.14)
+        self.slice_tiles = max(64, -(-max(nks) // int(os.environ.get("G4R_TN_LEVEL0_SLICES", 16))))      # (env: sweeps only)
         self.slices = _fn("g4r_conv3x3_wgrad_nhwc_slices")(L, ctypes.cast(self._h, P), ctypes.cast(self._w, P), B, cin, cout,
                                                             self.slice_tiles)
         assert self.slices > 0, "conv3x3_wgrad_nhwc: shape not supported"
