@@ -1925,6 +1925,299 @@ int launch_w4(GemmArgs& p, hipStream_t stream) {
   return G4R_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5 -- one-wave-per-SIMD kernel, second form ("w4k64", tile_cfg 34): 256 x 256 tile, FOUR waves (2 x 2), wave tile
+// 128 x 128 (16 accumulators of 32x32 = all 256 AGPRs), K tiles of 64 in TWO LDS buffers that are refilled as soon as they
+// are consumed.
+// Why (profiles/r05_vendor_ab.txt): a same-process A/B showed the vendor library at 1550 TF/s SUSTAINED on random operands
+// where the ring ping-pong kernel above does 1160-1235 -- the "power-cap ceiling" of round 4 was a ceiling of THAT kernel.
+// Its 8 waves x (128 x 64) read 192 KB of fragments per CU per 64 of K; 4 waves x (128 x 128) read 128 KB for the same
+// flops, every fragment read and every LDS-DMA piece can be hidden under the OWN wave's MFMAs (one wave per SIMD: 7 free
+// issue slots per 32-cycle MFMA), and there are two workgroup barriers per 64 MFMAs instead of four hand-offs.
+// Layout: a K tile is rows of 128 B (64 elements); a 1 KiB LDS-DMA piece = 8 rows x 128 B = WHOLE cache lines; the 16-byte
+// slot of k-chunk c of row r sits at slot c ^ ((r >> 1) & 7) (source-side swizzle, conflict-free for the lane groups of
+// ds_read_b128, MI355X_MICROARCH.md LDS table).  Per K tile a wave issues 8 + 8 pieces and 16 + 16 fragment reads.
+// Schedule of tile i (buffer X = i & 1; H0 / H1 = the fragments of k-steps 0,1 / 2,3, 64 + 64 VGPRs):
+//   A: 20 MFMA on H0           | 16 reads H1 <- X                                   | lgkmcnt(0), barrier  (X is consumed)
+//   B: 24 MFMA on H0 / H1      | 12 pieces of tile i+2 -> X                         | vmcnt(12), barrier   (tile i+1 landed)
+//   C: 20 MFMA on H1           | 16 reads H0 <- X^1 (tile i+1), last 4 pieces       |
+// so a tile's pieces have 1.3 tiles (~2700 cycles) to land.  AMODE 1 / 2 (implicit-GEMM convolution): the tap shift goes
+// into the per-lane offset, an out-of-image tap is an offset beyond the descriptor's extent (zeros), K tile = 64 channels
+// of one tap.
+// ---------------------------------------------------------------------------------------------
+template <int AMODE>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, NW = 4, BKT = 64, ROWB = 128, NP = 8;
+  constexpr int TM = 4, TN = 4;
+  constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;      // 32 KB + 32 KB per K tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];            // 2 * STAGE_BYTES = 128 KB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg, split;
+  g4r_workgroup_tile_slice(nwg, false, wg, split);
+  int tile_m, tile_n;
+  g4r_tile_coords(wg, p.tiles_m, p.tiles_n, p.n_fastest, p.group_m, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int t_begin = split * p.tiles_per_split;
+  int t_end = t_begin + p.tiles_per_split;
+  const int nt_total = p.K / BKT;
+  if (t_end > nt_total) t_end = nt_total;
+
+  // piece j of this wave covers rows 8 * (4 j + wave) + lane / 8; lane % 8 is the 16-byte slot it writes
+  int a_voff[NP], b_voff[NP];
+  unsigned a_ok[NP];
+  int a_pitch[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int row = (j * NW + wave) * 8 + (lane >> 3);
+    const int kslot = (lane & 7) ^ ((row >> 1) & 7);
+    int gm = m0 + row;
+    if (gm > p.M - 1) gm = p.M - 1;
+    a_voff[j] = (gm * p.lda + kslot * 8) * 2;
+    int gn = n0 + row;
+    if (gn > p.N - 1) gn = p.N - 1;
+    b_voff[j] = (gn * p.ldw + kslot * 8) * 2;
+    a_ok[j] = 0;
+    a_pitch[j] = p.Wd * p.lda;
+    if (AMODE >= 1) {
+      int h = p.H, w = p.Wd, local = gm;
+      if (AMODE == 2) {
+        int lv = 0;
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          if (q < p.n_lvl && gm >= p.lvl_start[q]) lv = q;
+        h = p.lvl_h[lv]; w = p.lvl_w[lv];
+        local = gm - p.lvl_start[lv];
+        a_pitch[j] = w * p.lda;
+      }
+      const int hw = h * w;
+      const int rem = local - (local / hw) * hw;
+      const int y = rem / w, x = rem - y * w;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) a_ok[j] |= 1u << tp;
+      }
+    }
+  }
+  // the NEXT K tile to stage (tiles are staged strictly in order): dense = a K offset; conv = (64-channel slice, group, tap),
+  // taps fastest, walked by a counter
+  int st_t = t_begin, st_ct = 0, st_g = 0, st_tap = 0;
+  if (AMODE >= 1) {
+    const int n_taps = 9 * p.groups;
+    st_ct = t_begin / n_taps;
+    const int rem = t_begin - st_ct * n_taps;
+    st_g = rem / 9;
+    st_tap = rem - st_g * 9;
+  }
+  struct TileSrc { int a_soff, w_soff, tap, dy, dx; };
+  auto next_tile = [&]() {
+    TileSrc ts;
+    ts.tap = ts.dy = ts.dx = 0;
+    ts.a_soff = ts.w_soff = st_t * BKT * 2;
+    ++st_t;
+    if (AMODE >= 1) {
+      const int c0 = st_ct * BKT;
+      ts.tap = st_tap;
+      ts.dy = st_tap / 3 - 1;
+      ts.dx = st_tap - (st_tap / 3) * 3 - 1;
+      ts.a_soff = (int)(((long)st_g * p.a_group_stride + c0) * 2);
+      ts.w_soff = ((st_g * 9 + st_tap) * p.Cin + c0) * 2;
+      if (++st_tap == 9) {
+        st_tap = 0;
+        if (++st_g == p.groups) { st_g = 0; ++st_ct; }
+      }
+    }
+    return ts;
+  };
+  // piece q of a K tile for this wave: q < 8 -> rows of A, else rows of W
+  auto piece = [&](int q, const TileSrc& ts, int buf) {
+    char* sa = smem + buf * STAGE_BYTES;
+    if (q < NP) {
+      int voff = a_voff[q];
+      if (AMODE == 1) voff += (ts.dy * p.Wd + ts.dx) * p.lda * 2;
+      if (AMODE == 2) voff += (ts.dy * a_pitch[q] + ts.dx * p.lda) * 2;
+      if (AMODE >= 1 && !((a_ok[q] >> ts.tap) & 1u)) voff = (int)0x80000000;      // beyond num_records: reads as zeros
+      g4r_buffer_piece(p.A, p.a_bytes, sa + (q * NW + wave) * 1024, voff, ts.a_soff);
+    } else {
+      g4r_buffer_piece(p.W, p.w_bytes, sa + A_BYTES + ((q - NP) * NW + wave) * 1024, b_voff[q - NP], ts.w_soff);
+    }
+  };
+  float16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frow = lane & 31, fsw = (frow >> 1) & 7, fhi = lane >> 5;
+  const int a_row_off = (wm * 128 + frow) * ROWB;
+  const int b_row_off = A_BYTES + (wn * 128 + frow) * ROWB;
+  h16x8 fa[4][TM], fw[4][TN];                  // [k-step][block]: k-steps 0,1 = H0, 2,3 = H1
+  auto ldfrag = [&](auto ks_tag, int buf) {
+    constexpr int ks = decltype(ks_tag)::value;
+    const char* sb = smem + buf * STAGE_BYTES;
+    const int slot = ((2 * ks + fhi) ^ fsw) << 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const h16x8*>(sb + a_row_off + i * 32 * ROWB + slot);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fw[ks][j] = *reinterpret_cast<const h16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
+  };
+  auto mma_rows = [&](auto ks_tag, auto i0_tag, auto i1_tag) {    // rows [i0, i1) of k-step ks
+    constexpr int ks = decltype(ks_tag)::value, i0 = decltype(i0_tag)::value, i1 = decltype(i1_tag)::value;
+#pragma unroll
+    for (int i = i0; i < i1; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = G4R_MFMA_32X32X16(fw[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
+
+  const int nt = t_end - t_begin;
+  if (nt > 0) {
+    {
+      const TileSrc ts = next_tile();
+#pragma unroll
+      for (int q = 0; q < 2 * NP; ++q) piece(q, ts, 0);
+    }
+    if (nt > 1) {
+      const TileSrc ts = next_tile();
+#pragma unroll
+      for (int q = 0; q < 2 * NP; ++q) piece(q, ts, 1);
+      __builtin_amdgcn_s_waitcnt(0x4f70);                     // vmcnt(16): tile 0 has landed
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0)
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ldfrag(I0{}, 0);
+    ldfrag(I1{}, 0);
+    // sched_group_barrier masks (LLVM SchedGroupMask): 0x8 MFMA, 0x10 VMEM, 0x100 DS read
+    auto body = [&](int i, auto steady_tag) {
+      constexpr bool STEADY = decltype(steady_tag)::value;      // tiles i+1, i+2 exist: no branches in the body
+      const int buf = i & 1;
+      // ---- A: k-step 0 + the first row of k-step 1 | H1 <- X, one read per MFMA ----
+      ldfrag(I2{}, buf);
+      ldfrag(I3{}, buf);
+      mma_rows(I0{}, I0{}, I4{});
+      mma_rows(I1{}, I0{}, I1{});
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): every fragment of X is in registers (the builtin,
+      asm volatile("" ::: "memory");                           //   not inline asm: the compiler's counter model sees it)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                            // ... in every wave: X may be overwritten
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- B: rest of k-step 1 + three rows of k-step 2 | pieces 0-11 of tile i+2 -> X, one per two MFMAs ----
+      TileSrc ts2 = {};
+      const bool more = STEADY || i + 2 < nt;
+      if (more) {
+        ts2 = next_tile();
+#pragma unroll
+        for (int q = 0; q < 12; ++q) piece(q, ts2, buf);
+      }
+      mma_rows(I1{}, I1{}, I4{});
+      mma_rows(I2{}, I0{}, I3{});
+      if (STEADY) {
+#pragma unroll
+        for (int n = 0; n < 12; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 2, 1);
+          __builtin_amdgcn_sched_group_barrier(0x10, 1, 1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) __builtin_amdgcn_s_waitcnt(0x0f7c);            // vmcnt(12): tile i+1 has landed (only this tile's 12 in flight)
+      else __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- C: last row of k-step 2 + k-step 3 | H0 <- X^1 (tile i+1), one read per MFMA; the last 4 pieces ----
+      if (STEADY || i + 1 < nt) {
+        ldfrag(I0{}, buf ^ 1);
+        ldfrag(I1{}, buf ^ 1);
+      }
+      if (more) {
+#pragma unroll
+        for (int q = 12; q < 16; ++q) piece(q, ts2, buf);
+      }
+      mma_rows(I2{}, I3{}, I4{});
+      mma_rows(I3{}, I0{}, I4{});
+      if (STEADY) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 2);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 2);
+          __builtin_amdgcn_sched_group_barrier(0x10, 1, 2);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int i = 0;
+    for (; i + 2 < nt; ++i) body(i, std::true_type{});
+    for (; i < nt; ++i) body(i, std::false_type{});
+  }
+  __syncthreads();   // the operand buffers are idle: stage the epilogue through them
+  gemm_epilogue_lds<TM, TN>(p, acc, smem + wave * EpiLds<TN>::WAVE_BYTES, m0 + wm * 128, n0 + wn * 128, lane, split);
+}
+
+template <int AMODE>
+int launch_w4k64(GemmArgs& p, hipStream_t stream) {
+  {
+    // extents for the buffer descriptors: the last byte a clamped row / in-image tap can touch
+    size_t ab = (size_t)p.M * p.lda * 2, wb = (size_t)p.N * p.ldw * 2;
+    if (AMODE == 1) ab = ((size_t)(p.groups - 1) * p.a_group_stride + (size_t)p.M * p.lda) * 2;
+    if (ab >= 0x7fffffffu || wb >= 0x7fffffffu) return g4r_note_error(G4R_ERR_UNSUPPORTED, "gemm_w4k64: operands of 2 GiB and more (use tile 24)");
+    p.a_bytes = (unsigned)ab;
+    p.w_bytes = (unsigned)wb;
+  }
+  if (p.K % 64 != 0 || (AMODE >= 1 && p.Cin % 64 != 0)) return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm_w4k64: K (Cin) must be a multiple of 64");
+  {
+    const int nt = p.K / 64;
+    int splits = p.splits < 1 ? 1 : p.splits;
+    if (splits > nt) splits = nt;
+    p.tiles_per_split = g4r_ceil_div(nt, splits);
+    p.splits = g4r_ceil_div(nt, p.tiles_per_split);
+  }
+  p.tiles_m = g4r_ceil_div(p.M, 256);
+  p.tiles_n = g4r_ceil_div(p.N, 256);
+  const size_t ring = 2 * (256 + 256) * 64 * 2, epi = 4 * (size_t)EpiLds<4>::WAVE_BYTES;
+  const size_t lds = ring > epi ? ring : epi;
+  auto kern = gemm_bf16_w4k64_kernel<AMODE>;
+  static G4rPerDeviceOnce attr_set;
+  if (attr_set.first()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_w4k64: hipFuncSetAttribute");
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(256), lds, stream, p);
+  G4R_CHECK_LAUNCH("gemm_bf16_w4k64");
+  if (p.splits > 1 && !p.defer_reduce) {
+    long total = (long)p.M * p.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    G4R_CHECK_LAUNCH("splitk_reduce");
+  }
+  return G4R_OK;
+}
+
 template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true, int SCHED = 0>
 int launch_pp32(GemmArgs& p, hipStream_t stream) {
   if (BUF) {
@@ -2038,7 +2331,7 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
   // grouped tile order for dense launches with many row tiles (ring ping-pong kernel): tools modes 31 / 32 / 33 force a group of
   // 8 / 4 / 16 row tiles, 30 forces the plain order
   p.group_m = 0;
-  if (AMODE == 0 && (tile_cfg == 24 || tile_cfg == 28)) {
+  if (AMODE == 0 && (tile_cfg == 24 || tile_cfg == 28 || tile_cfg == 34)) {
     const int tm = g4r_ceil_div(p.M, tile_cfg == 28 ? 192 : 256);
     if (tm >= 12) p.group_m = 8;
     if (g_gemm_dbg == 30) p.group_m = 0;
@@ -2074,6 +2367,7 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 43: if constexpr (AMODE == 0) return launch_tile<64, 128, 1, 4, AMODE, true, 3>(p, stream); else break;
     case 44: if constexpr (AMODE == 0) return launch_tile<64, 64, 2, 2, AMODE, true, 4>(p, stream); else break;
     case 47: if constexpr (AMODE == 0) return launch_tile<128, 128, 2, 4, AMODE, true, 4>(p, stream); else break;
+    case 34: return launch_w4k64<AMODE>(p, stream);                              // 256x256, 4 waves x (128x128), K 64 x 2 buffers refilled as consumed (round 5)
     case 26: return launch_w4<AMODE>(p, stream);                                 // 256x256, 4 waves x (128x128): one wave per SIMD, K 32 ring of 4
     case 22: return launch_pp<AMODE>(p, stream);                                 // 256x256 ping-pong (4 barriers / K tile)
     case 24:                                                                     // 256x256 ping-pong, K 32 ring of 4
@@ -2284,6 +2578,7 @@ int g4r_conv3x3_mlvl_nhwc_bf16(const void* X, const void* W, void* Y, const floa
   p.n_fastest = 1; p.dbg = g_gemm_dbg; p.splits = 1;
   if (g_gemm_dbg == 41) p.group_m = -2;     // tools: an XCD's wave = 16 pixel tiles x 2 weight panels (instead of 8 x 4)
   if (g_gemm_dbg == 42) p.group_m = -1;     // tools: 32 pixel tiles x 1 weight panel
+  if (g_gemm_dbg == 34) return launch_w4k64<2>(p, (hipStream_t)stream);      // tools: A/B arm (one wave per SIMD, K 64)
   return launch_pp32<2, false, 256, 256, true, 1>(p, (hipStream_t)stream);
 }
 

@@ -139,7 +139,8 @@ class _Profiler:
 PROFILER = _Profiler()
 TILE_NAMES = {0: "128x128", 1: "256x128", 2: "128x128reg", 4: "64x128", 5: "128x128s3", 6: "128x128s4",
               7: "128x128w8s4", 8: "256x128s3", 9: "256x256", 10: "128x128w8", 11: "128x64", 12: "64x128s4", 13: "64x128s3", 14: "64x64s4",
-              15: "128x64s4", 22: "256x256pp", 24: "256x256pp32", 26: "256x256w4", 27: "128x384pp32", 28: "192x256pp32"}
+              15: "128x64s4", 22: "256x256pp", 24: "256x256pp32", 26: "256x256w4", 27: "128x384pp32", 28: "192x256pp32",
+              34: "256x256w4k64"}
 
 
 def _sym(name, dt):
