@@ -1926,6 +1926,241 @@ int launch_w4(GemmArgs& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Epilogue of the one-wave-per-SIMD kernel (round 5): wave tile 128 x 128, FOUR waves.  In-kernel stamps of the first form
+// (tools/wg_timeline.py, profiles/r05_wg_timeline.txt) put the K loop at 2221 cycles per 64 of K (MFMA floor 2048) and the
+// shared epilogue above at 24.5 k cycles per tile -- 14 % of a K = 4096 tile: with half the waves of the ring kernel every
+// wave runs twice the number of its serial read-back iterations (LDS read -> mode branches -> one store each).
+// Here the mode is a TEMPLATE parameter of the kernel (the launcher picks it), so every instantiation carries one
+// straight-line epilogue whose LDS reads and global accesses the compiler batches:
+//   W4_P16  16-bit park, ONE pass (plain / bias / activation): the values are final BEFORE they are parked, so the wave parks
+//           16-bit values (128 rows x 256 B) and reads them back as whole 16-byte runs of a row;
+//   W4_SWIGLU  the (gate, up) column pairs sit in one lane: 64 outputs per row, parked as 16-bit;
+//   W4_ROPE    the fused RoPE + KV-cache append of q|k|v: the projection is parked at the rounding point the unfused path had,
+//              the wave's 128 columns are ONE head, so the rotation partner is column d +- 64 of the same parked row;
+//   W4_WIDE    fp32 park, two passes of 64 rows (residual, fp32 output, K-slice partials): arithmetic after the park;
+//   W4_GENERIC gemm_epilogue_lds (ragged N, unaligned rows).
+// Same arithmetic and order as gemm_epilogue_lds (bias -> activation -> residual -> one rounding): bit-identical results.
+// A wave whose 128 columns are not all inside N, or whose tile crosses row M, takes the guarded forms.
+// ---------------------------------------------------------------------------------------------
+enum { W4_GENERIC = 0, W4_P16 = 1, W4_SWIGLU = 2, W4_ROPE = 3, W4_WIDE = 4 };
+struct W4Epi {
+  static constexpr int RS16 = 256 + 16;         // 128 x 16-bit row + 16 B (rows stay 16-byte aligned for the b128 read-back)
+  static constexpr int RSW = 128 + 16;          // SwiGLU: 64 x 16-bit outputs per row
+  static constexpr int RS32 = 512 + 16;         // 128 x fp32 row + 16 B (EpiLds<4>::RS)
+  static constexpr int WAVE_BYTES = 128 * RS16;  // >= 64 * RS32
+};
+static_assert(64 * W4Epi::RS32 <= W4Epi::WAVE_BYTES && 128 * W4Epi::RSW <= W4Epi::WAVE_BYTES && W4Epi::WAVE_BYTES >= EpiLds<4>::WAVE_BYTES,
+              "every mode fits the wave's slice");
+
+// One accumulator register -> VGPR, in program order.  Without it the compiler copies all 256 AGPRs to VGPRs at the head of
+// the epilogue (v_accvgpr_read x 256 -> 548 bytes of scratch per lane); the volatile asm keeps every value in its AGPR until
+// the park loop reaches it.
+__device__ __forceinline__ float w4_acc(const float16v& c, int r) {
+  float v;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(c[r]));
+  return v;
+}
+
+// read-back of a parked 16-bit tile: NR rows of RB bytes (LPR lanes x 16 B per row), whole rows of the output
+template <int NR, int RS, int LPR, bool GUARD>
+__device__ __forceinline__ void w4_copy_rows(const char* wave_lds, h16_t* dst0, long ldc, int lane, int rows_left) {
+  constexpr int RPI = 64 / LPR;
+  const int rrow = lane / LPR, rchunk = lane % LPR;
+  const char* src = wave_lds + rrow * RS + rchunk * 16;
+  h16_t* dst = dst0 + (long)rrow * ldc + rchunk * 8;
+#pragma unroll
+  for (int b = 0; b < NR / RPI; b += 8) {
+    uint4v d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d[u] = *reinterpret_cast<const uint4v*>(src + (b + u) * RPI * RS);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (!GUARD || (b + u) * RPI + rrow < rows_left) *reinterpret_cast<uint4v*>(dst + (long)(b + u) * RPI * ldc) = d[u];
+  }
+}
+
+template <int MODE, bool PROBE>
+__device__ __forceinline__ void w4_epilogue(const GemmArgs& p, float16v (&acc)[4][4], char* wave_lds, int m_wave0, int n_wave0,
+                                            int lane, int split, long long& park_t) {
+  if (MODE == W4_GENERIC || n_wave0 + 128 > p.N) {         // (wave-uniform; W4_ROPE never sees a ragged tile: heads * 128 % 256 == 0)
+    if (MODE != W4_ROPE) gemm_epilogue_lds<4, 4>(p, acc, wave_lds, m_wave0, n_wave0, lane, split);
+    return;
+  }
+  if (m_wave0 >= p.M) return;                               // the whole wave tile is below the last row (wave-uniform)
+  const int wr = lane & 31, wh = lane >> 5;
+  const int rows_left = p.M - m_wave0;
+  const bool full = rows_left >= 128;
+  if (MODE == W4_SWIGLU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float16v& c = acc[i][j];
+          const float g0 = w4_acc(c, q * 4), u0 = w4_acc(c, q * 4 + 1), g1 = w4_acc(c, q * 4 + 2), u1 = w4_acc(c, q * 4 + 3);
+          const float s0 = h16lo(pack_h16x2(g0 / (1.f + __expf(-g0)), 0.f));
+          const float s1 = h16lo(pack_h16x2(g1 / (1.f + __expf(-g1)), 0.f));
+          *reinterpret_cast<uint32_t*>(wave_lds + (i * 32 + wr) * W4Epi::RSW + (j * 16 + q * 4 + wh * 2) * 2) = pack_h16x2(s0 * u0, s1 * u1);
+        }
+    if (PROBE) park_t = __builtin_amdgcn_s_memtime();
+    h16_t* dst0 = reinterpret_cast<h16_t*>(p.C) + (size_t)m_wave0 * p.ldc + (n_wave0 >> 1);
+    if (full) w4_copy_rows<128, W4Epi::RSW, 8, false>(wave_lds, dst0, p.ldc, lane, rows_left);
+    else w4_copy_rows<128, W4Epi::RSW, 8, true>(wave_lds, dst0, p.ldc, lane, rows_left);
+    return;
+  }
+  if (MODE == W4_P16 || MODE == W4_ROPE) {
+    // ---- 16-bit park: bias / activation applied in the accumulator layout (RoPE: the projection rounded as the unfused path did) ----
+    const bool has_bias = MODE == W4_P16 && p.bias != nullptr;
+    auto park16 = [&](auto act_tag) {                     // the activation is a compile-time constant of each copy
+      constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4v b = {0.f, 0.f, 0.f, 0.f};
+          if (has_bias) b = *reinterpret_cast<const float4v*>(p.bias + n_wave0 + j * 32 + q * 8 + wh * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float16v& c = acc[i][j];
+            float v[4] = {w4_acc(c, q * 4) + b.x, w4_acc(c, q * 4 + 1) + b.y, w4_acc(c, q * 4 + 2) + b.z, w4_acc(c, q * 4 + 3) + b.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float x = v[k];
+              v[k] = ACT == 0 ? x : (ACT == 1 ? fmaxf(x, 0.f) : (ACT == 2 ? x / (1.f + __expf(-1.702f * x)) : x / (1.f + __expf(-x))));
+            }
+            *reinterpret_cast<uint2v*>(wave_lds + (i * 32 + wr) * W4Epi::RS16 + (j * 32 + q * 8 + wh * 4) * 2) =
+                uint2v{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3])};
+          }
+        }
+    };
+    const int act = MODE == W4_P16 ? p.act : 0;
+    if (act == 0) park16(std::integral_constant<int, 0>{});
+    else if (act == 1) park16(std::integral_constant<int, 1>{});
+    else if (act == 2) park16(std::integral_constant<int, 2>{});
+    else park16(std::integral_constant<int, 3>{});
+    if (PROBE) park_t = __builtin_amdgcn_s_memtime();
+    if (MODE == W4_P16) {
+      h16_t* dst0 = reinterpret_cast<h16_t*>(p.C) + (size_t)m_wave0 * p.ldc + n_wave0;
+      if (full) w4_copy_rows<128, W4Epi::RS16, 16, false>(wave_lds, dst0, p.ldc, lane, rows_left);
+      else w4_copy_rows<128, W4Epi::RS16, 16, true>(wave_lds, dst0, p.ldc, lane, rows_left);
+      return;
+    }
+    // fused RoPE + KV-cache append (gemm_epilogue_lds, act 5, states the arithmetic)
+    const int rrow = lane >> 4, rchunk = lane & 15;      // 4 rows x 256 B per wave instruction
+    const int part = n_wave0 / p.rope_HD;                // 0 q, 1 k, 2 v
+    const int col0 = n_wave0 - part * p.rope_HD + rchunk * 8;
+    const bool second = rchunk >= 8;
+    const int d0 = (rchunk & 7) * 8;                     // position of this run inside its half of the head
+#pragma unroll 4
+    for (int it = 0; it < 32; ++it) {
+      const int r = it * 4 + rrow;
+      int m = m_wave0 + r;
+      const bool live = m < p.M;
+      if (!live) m = p.M - 1;                            // (reads stay in range; the store is masked)
+      const uint4v own = *reinterpret_cast<const uint4v*>(wave_lds + r * W4Epi::RS16 + rchunk * 16);
+      const uint4v mate = *reinterpret_cast<const uint4v*>(wave_lds + r * W4Epi::RS16 + (rchunk ^ 8) * 16);
+      const int b = m / p.rope_T, t = m - b * p.rope_T;
+      const int pos = p.rope_pos0 + t;
+      uint4v o = own;
+      if (part < 2) {
+        const float* cp = p.rope_cos + (size_t)pos * 64 + d0;
+        const float* sp = p.rope_sin + (size_t)pos * 64 + d0;
+        const float4v c0 = *reinterpret_cast<const float4v*>(cp), c1 = *reinterpret_cast<const float4v*>(cp + 4);
+        const float4v s0 = *reinterpret_cast<const float4v*>(sp), s1 = *reinterpret_cast<const float4v*>(sp + 4);
+        const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const uint32_t ow[4] = {own.x, own.y, own.z, own.w}, mw[4] = {mate.x, mate.y, mate.z, mate.w};
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a0 = h16lo(ow[k]), a1 = h16hi(ow[k]), b0 = h16lo(mw[k]), b1 = h16hi(mw[k]);
+          v[2 * k] = second ? __builtin_fmaf(a0, cs[2 * k], b0 * sn[2 * k]) : __builtin_fmaf(a0, cs[2 * k], -(b0 * sn[2 * k]));
+          v[2 * k + 1] = second ? __builtin_fmaf(a1, cs[2 * k + 1], b1 * sn[2 * k + 1])
+                                : __builtin_fmaf(a1, cs[2 * k + 1], -(b1 * sn[2 * k + 1]));
+        }
+        o = uint4v{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7])};
+      }
+      h16_t* dst = part == 0 ? p.rope_q + (size_t)m * p.rope_HD + col0
+                              : (part == 1 ? p.rope_k : p.rope_v) + (size_t)b * p.rope_kbatch + (size_t)pos * p.rope_krow + col0;
+      if (live) *reinterpret_cast<uint4v*>(dst) = o;
+    }
+    return;
+  }
+  // ---- W4_WIDE: fp32 park, two passes of 64 rows: residual / fp32 output / K-slice partials ----
+  const int rrow = lane >> 4, rcol = (lane & 15) * 8;
+  float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p.bias != nullptr && p.splits == 1) {
+    const float4v b0 = *reinterpret_cast<const float4v*>(p.bias + n_wave0 + rcol), b1 = *reinterpret_cast<const float4v*>(p.bias + n_wave0 + rcol + 4);
+    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  }
+  const int n = n_wave0 + rcol;
+  auto readback = [&](int mh, auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;        // -1: K-slice partials
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int r = it * 4 + rrow;
+      int m = mh + r;
+      const bool live = m < p.M;
+      if (!live) m = p.M - 1;                            // (reads stay in range; the stores are masked)
+      const float4v a0 = *reinterpret_cast<const float4v*>(wave_lds + r * W4Epi::RS32 + rcol * 4);
+      const float4v a1 = *reinterpret_cast<const float4v*>(wave_lds + r * W4Epi::RS32 + rcol * 4 + 16);
+      if (ACT < 0) {
+        float* dst = p.ws + ((size_t)split * p.M + m) * p.N + n;
+        if (live) {
+          *reinterpret_cast<float4v*>(dst) = a0;
+          *reinterpret_cast<float4v*>(dst + 4) = a1;
+        }
+        continue;
+      }
+      float v[8] = {a0.x + bias8[0], a0.y + bias8[1], a0.z + bias8[2], a0.w + bias8[3],
+                    a1.x + bias8[4], a1.y + bias8[5], a1.z + bias8[6], a1.w + bias8[7]};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float x = v[k];
+        v[k] = ACT <= 0 ? x : (ACT == 1 ? fmaxf(x, 0.f) : (ACT == 2 ? x / (1.f + __expf(-1.702f * x)) : x / (1.f + __expf(-x))));
+      }
+      if (p.residual) {
+        const uint4v rr = *reinterpret_cast<const uint4v*>(p.residual + (size_t)m * p.ldr + n);
+        v[0] += h16lo(rr.x); v[1] += h16hi(rr.x); v[2] += h16lo(rr.y); v[3] += h16hi(rr.y);
+        v[4] += h16lo(rr.z); v[5] += h16hi(rr.z); v[6] += h16lo(rr.w); v[7] += h16hi(rr.w);
+      }
+      if (p.out_f32) {
+        float* dst = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+        if (live) {
+          *reinterpret_cast<float4v*>(dst) = float4v{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<float4v*>(dst + 4) = float4v{v[4], v[5], v[6], v[7]};
+        }
+      } else if (live) {
+        *reinterpret_cast<uint4v*>(reinterpret_cast<h16_t*>(p.C) + (size_t)m * p.ldc + n) =
+            uint4v{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]), pack_h16x2(v[6], v[7])};
+      }
+    }
+  };
+  const int act = p.splits > 1 ? -1 : p.act;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float16v& c = acc[half * 2 + i2][j];
+          *reinterpret_cast<float4v*>(wave_lds + (i2 * 32 + wr) * W4Epi::RS32 + (j * 32 + q * 8 + wh * 4) * 4) =
+              float4v{c[q * 4], c[q * 4 + 1], c[q * 4 + 2], c[q * 4 + 3]};       // (ds_write_b128 takes its data straight from AGPRs)
+        }
+    if (PROBE && half == 0) park_t = __builtin_amdgcn_s_memtime();
+    const int mh = m_wave0 + half * 64;
+    if (act < 0) readback(mh, std::integral_constant<int, -1>{});
+    else if (act == 0) readback(mh, std::integral_constant<int, 0>{});
+    else if (act == 1) readback(mh, std::integral_constant<int, 1>{});
+    else if (act == 2) readback(mh, std::integral_constant<int, 2>{});
+    else readback(mh, std::integral_constant<int, 3>{});
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Round 5 -- one-wave-per-SIMD kernel, second form ("w4k64", tile_cfg 34): 256 x 256 tile, FOUR waves (2 x 2), wave tile
 // 128 x 128 (16 accumulators of 32x32 = all 256 AGPRs), K tiles of 64 in TWO LDS buffers that are refilled as soon as they
 // are consumed.
@@ -1945,7 +2180,7 @@ int launch_w4(GemmArgs& p, hipStream_t stream) {
 // into the per-lane offset, an out-of-image tap is an offset beyond the descriptor's extent (zeros), K tile = 64 channels
 // of one tap.
 // ---------------------------------------------------------------------------------------------
-template <int AMODE>
+template <int AMODE, bool PROBE, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, NW = 4, BKT = 64, ROWB = 128, NP = 8;
   constexpr int TM = 4, TN = 4;
@@ -1965,6 +2200,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64_kernel(GemmArgs p) {
   int t_end = t_begin + p.tiles_per_split;
   const int nt_total = p.K / BKT;
   if (t_end > nt_total) t_end = nt_total;
+  // PROBE (tools/wg_timeline.py, tile 35): wave 0 of every workgroup records entry / loop begin / loop end / exit (s_memtime),
+  // its XCC id and the 100 MHz wall clock at ws + 16 + 8 * blockIdx.x (int64) -- the convention of the ring kernel's probe
+  long long* wg_stamps = reinterpret_cast<long long*>(p.ws) + 16 + 8 * (long)blockIdx.x;
+  const bool wg_probe = PROBE && blockIdx.y == 0 && wave == 0 && lane == 0;
+  if (PROBE) { if (wg_probe) { wg_stamps[0] = __builtin_amdgcn_s_memtime(); wg_stamps[4] = __builtin_amdgcn_s_getreg(6164); wg_stamps[5] = wall_clock64(); } }
 
   // piece j of this wave covers rows 8 * (4 j + wave) + lane / 8; lane % 8 is the 16-byte slot it writes
   int a_voff[NP], b_voff[NP];
@@ -2169,15 +2409,35 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64_kernel(GemmArgs p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     };
+    if (PROBE) { if (wg_probe) wg_stamps[1] = __builtin_amdgcn_s_memtime(); }
     int i = 0;
     for (; i + 2 < nt; ++i) body(i, std::true_type{});
     for (; i < nt; ++i) body(i, std::false_type{});
+    if (PROBE) { if (wg_probe) wg_stamps[2] = __builtin_amdgcn_s_memtime(); }
   }
   __syncthreads();   // the operand buffers are idle: stage the epilogue through them
-  gemm_epilogue_lds<TM, TN>(p, acc, smem + wave * EpiLds<TN>::WAVE_BYTES, m0 + wm * 128, n0 + wn * 128, lane, split);
+  long long park_t = 0;
+  w4_epilogue<EPI, PROBE>(p, acc, smem + wave * W4Epi::WAVE_BYTES, m0 + wm * 128, n0 + wn * 128, lane, split, park_t);
+  if (PROBE) { if (wg_probe) { wg_stamps[3] = __builtin_amdgcn_s_memtime(); wg_stamps[6] = wall_clock64(); wg_stamps[7] = park_t; } }
 }
 
-template <int AMODE>
+template <int AMODE, bool PROBE, int EPI>
+int launch_w4k64_epi(GemmArgs& p, hipStream_t stream) {
+  const size_t ring = 2 * (256 + 256) * 64 * 2, epi = 4 * (size_t)W4Epi::WAVE_BYTES;
+  const size_t lds = ring > epi ? ring : epi;
+  auto kern = gemm_bf16_w4k64_kernel<AMODE, PROBE, EPI>;
+  static G4rPerDeviceOnce attr_set;
+  if (attr_set.first()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_w4k64: hipFuncSetAttribute");
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(256), lds, stream, p);
+  G4R_CHECK_LAUNCH("gemm_bf16_w4k64");
+  return G4R_OK;
+}
+
+template <int AMODE, bool PROBE = false>
 int launch_w4k64(GemmArgs& p, hipStream_t stream) {
   {
     // extents for the buffer descriptors: the last byte a clamped row / in-image tap can touch
@@ -2197,17 +2457,32 @@ int launch_w4k64(GemmArgs& p, hipStream_t stream) {
   }
   p.tiles_m = g4r_ceil_div(p.M, 256);
   p.tiles_n = g4r_ceil_div(p.N, 256);
-  const size_t ring = 2 * (256 + 256) * 64 * 2, epi = 4 * (size_t)EpiLds<4>::WAVE_BYTES;
-  const size_t lds = ring > epi ? ring : epi;
-  auto kern = gemm_bf16_w4k64_kernel<AMODE>;
-  static G4rPerDeviceOnce attr_set;
-  if (attr_set.first()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_w4k64: hipFuncSetAttribute");
+  // the epilogue mode (W4Epi): the straight-line forms need 16-byte rows on every operand they touch
+  const bool wide = p.splits > 1 || p.out_f32 || p.residual != nullptr;
+  int mode = W4_GENERIC;
+  if ((p.N & 7) == 0) {
+    if (p.act == 5) mode = W4_ROPE;
+    else if (p.splits > 1) mode = W4_WIDE;
+    else if ((p.ldc & 7) == 0 && (p.residual == nullptr || (p.ldr & 7) == 0) && (p.act != 4 || ((p.ldc & 7) == 0 && !wide)))
+      mode = wide ? W4_WIDE : (p.act == 4 ? W4_SWIGLU : W4_P16);
   }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(256), lds, stream, p);
-  G4R_CHECK_LAUNCH("gemm_bf16_w4k64");
+  if (p.act == 5 && mode != W4_ROPE) return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm_w4k64: the fused RoPE epilogue needs N % 8 == 0");
+  int rc = G4R_OK;
+  if (AMODE != 0) {                       // the convolutions: bias / ReLU only
+    rc = (mode == W4_P16) ? launch_w4k64_epi<AMODE, false, W4_P16>(p, stream)
+                          : (mode == W4_WIDE ? launch_w4k64_epi<AMODE, false, W4_WIDE>(p, stream) : launch_w4k64_epi<AMODE, false, W4_GENERIC>(p, stream));
+  } else if (PROBE) {
+    rc = mode == W4_P16 ? launch_w4k64_epi<0, PROBE, W4_P16>(p, stream) : launch_w4k64_epi<0, PROBE, W4_WIDE>(p, stream);
+  } else {
+    switch (mode) {
+      case W4_P16: rc = launch_w4k64_epi<0, false, W4_P16>(p, stream); break;
+      case W4_SWIGLU: rc = launch_w4k64_epi<0, false, W4_SWIGLU>(p, stream); break;
+      case W4_ROPE: rc = launch_w4k64_epi<0, false, W4_ROPE>(p, stream); break;
+      case W4_WIDE: rc = launch_w4k64_epi<0, false, W4_WIDE>(p, stream); break;
+      default: rc = launch_w4k64_epi<0, false, W4_GENERIC>(p, stream); break;
+    }
+  }
+  if (rc != G4R_OK) return rc;
   if (p.splits > 1 && !p.defer_reduce) {
     long total = (long)p.M * p.N;
     int blocks = (int)((total + 255) / 256);
@@ -2331,7 +2606,7 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
   // grouped tile order for dense launches with many row tiles (ring ping-pong kernel): tools modes 31 / 32 / 33 force a group of
   // 8 / 4 / 16 row tiles, 30 forces the plain order
   p.group_m = 0;
-  if (AMODE == 0 && (tile_cfg == 24 || tile_cfg == 28 || tile_cfg == 34)) {
+  if (AMODE == 0 && (tile_cfg == 24 || tile_cfg == 28 || tile_cfg == 34 || tile_cfg == 35)) {
     const int tm = g4r_ceil_div(p.M, tile_cfg == 28 ? 192 : 256);
     if (tm >= 12) p.group_m = 8;
     if (g_gemm_dbg == 30) p.group_m = 0;
@@ -2368,6 +2643,7 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 44: if constexpr (AMODE == 0) return launch_tile<64, 64, 2, 2, AMODE, true, 4>(p, stream); else break;
     case 47: if constexpr (AMODE == 0) return launch_tile<128, 128, 2, 4, AMODE, true, 4>(p, stream); else break;
     case 34: return launch_w4k64<AMODE>(p, stream);                              // 256x256, 4 waves x (128x128), K 64 x 2 buffers refilled as consumed (round 5)
+    case 35: if constexpr (AMODE == 0) return launch_w4k64<AMODE, true>(p, stream); else break;   // same + s_memtime stamps (tools only)
     case 26: return launch_w4<AMODE>(p, stream);                                 // 256x256, 4 waves x (128x128): one wave per SIMD, K 32 ring of 4
     case 22: return launch_pp<AMODE>(p, stream);                                 // 256x256 ping-pong (4 barriers / K tile)
     case 24:                                                                     // 256x256 ping-pong, K 32 ring of 4
@@ -2445,7 +2721,7 @@ int g4r_gemm_qkv_rope_bf16(const void* A, const void* W, int B, int T, int K, in
   G4R_REQUIRE(A && W && q_out && k_cache && v_cache && cos_tab && sin_tab, "gemm_qkv_rope: null pointer");
   G4R_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (cache_row % 8) == 0 && (cache_batch % 8) == 0, "gemm_qkv_rope: 16-byte rows");
   if (tile_cfg == 0) tile_cfg = 28;
-  G4R_REQUIRE(tile_cfg == 24 || tile_cfg == 28, "gemm_qkv_rope: ring ping-pong tiles only (24 / 28)");
+  G4R_REQUIRE(tile_cfg == 24 || tile_cfg == 28 || tile_cfg == 34, "gemm_qkv_rope: 256-wide tiles only (24 / 28 / 34)");
   GemmArgs p = {};
   p.A = (const h16_t*)A; p.W = (const h16_t*)W; p.C = q_out;
   p.M = B * T; p.N = 3 * heads * head_dim; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = heads * head_dim;

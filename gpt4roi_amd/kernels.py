@@ -396,7 +396,7 @@ def gemm_qkv_rope(h, wqkv, B, T, heads, head_dim, q_out, k_cache, v_cache, cos, 
     HD = heads * head_dim
     if tile_cfg is None:
         tile_cfg = pick_tile(M, 3 * HD, Kd)
-    if head_dim != 128 or HD % 256 != 0 or tile_cfg not in (24, 28) or M != B * T:
+    if head_dim != 128 or HD % 256 != 0 or tile_cfg not in (24, 28, 34) or M != B * T:
         return None
     assert wqkv.shape == (3 * HD, Kd) and q_out.is_contiguous() and cos.size(1) == 64 and cos.is_contiguous() and sin.is_contiguous()
     assert k_cache.stride(2) == 1 and v_cache.stride() == k_cache.stride() and pos0 + T <= k_cache.size(1)

@@ -56,6 +56,38 @@ report("K slices x4 (767x4096x11008)", K.gemm(a, w, splits=4, tile_cfg=34), None
 a, w = R(300, 384), R(520, 384)
 report("K slices x3 (300x520x384)", K.gemm(a, w, splits=3, tile_cfg=34), None, a.float() @ w.float().t(), exact=False)
 
+# ---- fused q|k|v projection + RoPE + KV-cache append (epilogue mode 5) ----
+for (B, T, heads) in [(1, 767, 32), (3, 300, 4)]:
+    HD = heads * 128
+    h, wqkv = R(B * T, 512), R(3 * HD, 512)
+    ang = torch.rand(1024, 64, device=dev, generator=g) * 6.28
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    outs = {}
+    for t in (24, 34):
+        q = torch.zeros(B, T, HD, dtype=torch.bfloat16, device=dev)
+        kc = torch.zeros(B, 1024, HD, dtype=torch.bfloat16, device=dev)
+        vc = torch.zeros(B, 1024, HD, dtype=torch.bfloat16, device=dev)
+        assert K.gemm_qkv_rope(h, wqkv, B, T, heads, 128, q, kc, vc, cos, sin, 5, tile_cfg=t) is not None
+        outs[t] = torch.cat([q.flatten(), kc.flatten(), vc.flatten()])
+    e = rel(outs[34], outs[24])
+    nz = (outs[34] != 0).float().mean().item()
+    ok = e == 0.0 and nz > 0.1
+    bad += not ok
+    print(json.dumps({"case": f"qkv+rope B{B} T{T} heads{heads}", "vs_tile24": e, "nonzero": round(nz, 3), "ok": ok}), flush=True)
+# ---- ragged N (generic fallback of the new epilogue), bias on the 16-bit park ----
+a, w = R(700, 256), R(1000, 256)
+bias = torch.randn(1000, device=dev, generator=g)
+report("ragged N=1000 + bias + relu", K.gemm(a, w, bias=bias, act="relu", tile_cfg=34), K.gemm(a, w, bias=bias, act="relu", tile_cfg=24),
+       (a.float() @ w.float().t() + bias).relu())
+a, w = R(700, 256), R(1024, 256)
+bias = torch.randn(1024, device=dev, generator=g)
+for act in (None, "relu", "quick_gelu", "silu"):
+    r32 = a.float() @ w.float().t() + bias
+    r32 = {None: r32, "relu": r32.relu(), "quick_gelu": r32 * torch.sigmoid(1.702 * r32), "silu": torch.nn.functional.silu(r32)}[act]
+    report(f"16-bit park bias+{act}", K.gemm(a, w, bias=bias, act=act, tile_cfg=34), K.gemm(a, w, bias=bias, act=act, tile_cfg=24), r32)
+report("fp32 out + bias", K.gemm(a, w, bias=bias, out_dtype=torch.float32, tile_cfg=34), K.gemm(a, w, bias=bias, out_dtype=torch.float32, tile_cfg=24),
+       a.float() @ w.float().t() + bias, tol=1e-5)
+
 # ---- 3x3 convolution (implicit GEMM) ----
 for (B, H, W, Ci, Co, G) in [(1, 48, 48, 128, 256, 1), (2, 24, 20, 64, 320, 1), (1, 14, 14, 128, 256, 4)]:
     x = R(G, B, H, W, Ci) if G > 1 else R(B, H, W, Ci)
