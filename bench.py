@@ -433,7 +433,9 @@ def main():
         except Exception:
             pass
         # kernel names as the counter pass records them, matched by prefix (template tails change between rounds)
-        PMC_PREFIX = {"gemm_bf16_nt<256x256pp32>": "void gemm_bf16_pp32_kernel<0, false, 256, 256",
+        PMC_PREFIX = {"gemm_bf16_nt<256x256w4k64>": "void gemm_bf16_w4k64_kernel<0, false",       # (all epilogue modes of the symbol family)
+                      "conv3x3_igemm<256x256w4k64>": "void gemm_bf16_w4k64_kernel<2, false",
+                      "gemm_bf16_nt<256x256pp32>": "void gemm_bf16_pp32_kernel<0, false, 256, 256",
                       "gemm_bf16_nt<192x256pp32>": "void gemm_bf16_pp32_kernel<0, false, 192, 256",
                       "conv3x3_igemm<256x256pp32>": "void gemm_bf16_pp32_kernel<2, false, 256, 256",   # the one-launch-per-round form
                       "gemm_bf16_nt<128x128w8s4>": "void gemm_bf16_nt_kernel<128, 128, 2, 4, 0, true, 4, 64, 0>",
@@ -456,11 +458,12 @@ def main():
         if rec.get("mfma_util") is not None:
             roofline["pmc"] = {"mfma_util": rec["mfma_util"], "clock_GHz": rec["clock_GHz"],
                                "source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), clock = GRBM_GUI_ACTIVE / 8 / duration"}
-        cv = agg.get("conv3x3_igemm<256x256pp32>")
+        conv_tag = max((t_ for t_ in agg if t_.startswith("conv3x3_igemm<256x256")), key=lambda t_: agg[t_]["ms"], default=None)
+        cv = agg.get(conv_tag)
         if cv and cv.get("flops"):
-            crec = pmc_rec("conv3x3_igemm<256x256pp32>")
+            crec = pmc_rec(conv_tag)
             tf = cv["flops"] / (cv["ms"] * 1e-3) / 1e12
-            roofline["conv"] = {"kernel": "conv3x3_igemm<256x256pp32>", "bound": "mfma", "achieved": round(tf, 1),
+            roofline["conv"] = {"kernel": conv_tag, "bound": "mfma", "achieved": round(tf, 1),
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
                                 "avg_launch_us": round(1e3 * cv["ms"] / cv["calls"], 2),
                                 "algorithmic_bytes_per_launch": int(cv["bytes"] / cv["calls"]),

@@ -2854,7 +2854,9 @@ int g4r_conv3x3_mlvl_nhwc_bf16(const void* X, const void* W, void* Y, const floa
   p.n_fastest = 1; p.dbg = g_gemm_dbg; p.splits = 1;
   if (g_gemm_dbg == 41) p.group_m = -2;     // tools: an XCD's wave = 16 pixel tiles x 2 weight panels (instead of 8 x 4)
   if (g_gemm_dbg == 42) p.group_m = -1;     // tools: 32 pixel tiles x 1 weight panel
-  if (g_gemm_dbg == 34) return launch_w4k64<2>(p, (hipStream_t)stream);      // tools: A/B arm (one wave per SIMD, K 64)
+  // round 5: the one-wave-per-SIMD K 64 kernel (1383-1393 vs 1286-1292 TF/s, profiles/r05_w4k64_epilogue.txt); debug mode 60 = the
+  // ring ping-pong kernel (tools: A/B arm), also the fallback for maps of 2 GiB and more
+  if (g_gemm_dbg != 60 && (size_t)rows * Cin * 2 < 0x7fffffffu) return launch_w4k64<2>(p, (hipStream_t)stream);
   return launch_pp32<2, false, 256, 256, true, 1>(p, (hipStream_t)stream);
 }
 

@@ -141,6 +141,12 @@ TILE_NAMES = {0: "128x128", 1: "256x128", 2: "128x128reg", 4: "64x128", 5: "128x
               7: "128x128w8s4", 8: "256x128s3", 9: "256x256", 10: "128x128w8", 11: "128x64", 12: "64x128s4", 13: "64x128s3", 14: "64x64s4",
               15: "128x64s4", 22: "256x256pp", 24: "256x256pp32", 26: "256x256w4", 27: "128x384pp32", 28: "192x256pp32",
               34: "256x256w4k64"}
+# the production 256 x 256 tile: 34 = one wave per SIMD, K tiles of 64, straight-line epilogues (round 5: 1.38-1.41 PF/s on the
+# merged LLaMA shapes, +14 % over the ring ping-pong tile, profiles/r05_w4k64_epilogue.txt); G4R_BIG_TILE=24 = the ring
+# ping-pong tile of rounds 2-4 (A/B runs)
+BIG_TILE = int(os.environ.get("G4R_BIG_TILE", "34"))
+if BIG_TILE != 34:
+    _lib.lib().g4r_gemm_debug_mode(60)          # the one-launch-per-round conv follows (debug mode 60 = its ring ping-pong arm)
 
 
 def _sym(name, dt):
@@ -241,7 +247,8 @@ def pick_tile(M, N, K=0):
         t24 = -(-M // 256) * -(-N // 256)
         t28 = -(-M // 192) * -(-N // 256)
         if max(t24, t28) >= 192:                    # narrow outputs (ViT fc2 at batch 8: 100 tiles) stay on the smaller tiles below
-            return 28 if -(-t28 // 256) * 0.92 < -(-t24 // 256) else 24
+            # (a 192 x 256 wave takes 0.92 of a ring ping-pong 256 x 256 wave, 1.05 of a one-wave-per-SIMD one)
+            return 28 if -(-t28 // 256) * (1.05 if BIG_TILE == 34 else 0.92) < -(-t24 // 256) else BIG_TILE
     t256 = -(-M // 256) * -(-N // 256)
     if K >= 1024 and K % 64 == 0 and (-(-M // 256) * 256) <= 1.1 * M:     # K = 1024: ViT at batch 8 (4616x3072x1024: 715 vs 552 TF/s)
         eff = t256 / (-(-t256 // 256) * 256)
@@ -251,7 +258,7 @@ def pick_tile(M, N, K=0):
             t192 = -(-M // 192) * -(-N // 256)
             if t256 <= 256 and eff < 0.75 and t256 < t192 <= 256 and (-(-M // 192) * 192) <= 1.1 * M:
                 return 28
-            return 24
+            return BIG_TILE
     t128 = -(-M // 128) * -(-N // 128)
     if t128 >= 192:
         # o_proj 767x4096x4096 (192 tiles): 8-wave ring 45.7 us vs 65.9 on the two-stage tile; with more than one tile per CU
@@ -286,7 +293,7 @@ def pick_conv_tile(M, Cout, K):
         t256 = -(-M // 256) * -(-Cout // 256)
         return 24, max(1, min(5, 256 // t256))
     if M >= 8192:
-        return 24, 1
+        return BIG_TILE, 1
     blocks = -(-M // 64) * -(-Cout // 128)
     splits = max(1, min(8, round(384 / blocks), K // 1024))
     return 4, splits
@@ -328,7 +335,7 @@ def partial_wave_plan(M, N, K):
         return None
     t256 = -(-M // 256) * -(-N // 256)
     if 64 < t256 <= 128:
-        return 24, 256 // t256
+        return BIG_TILE, 256 // t256
     return None
 
 
@@ -425,21 +432,21 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=None, spl
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
     thin_tail = False
-    if tile_cfg is None and splits == 1 and M >= 1024 and pick_tile(M, N, K) == 24 and out.dtype != torch.float32:
+    if tile_cfg is None and splits == 1 and M >= 1024 and pick_tile(M, N, K) == BIG_TILE and out.dtype != torch.float32:
         # several whole waves of 256 x 256 tiles plus a THIN last one (batch-4 gate|up 3068 x 22016: 1032 tiles = 4 waves + 8
         # tiles): the last columns go to a second launch as K slices instead of costing a fifth wave
         t256 = -(-M // 256) * -(-N // 256)
         thin_tail = t256 > 256 and 0 < t256 % 256 <= 48
-    if tile_cfg is None and splits == 1 and (pick_tile(M, N, K) not in (24, 28) or thin_tail):
+    if tile_cfg is None and splits == 1 and (pick_tile(M, N, K) not in (24, 28, 34) or thin_tail):
         n_main = wave_split(M, N, K)
         if n_main is not None:
             o_main = n_main // 2 if act == "swiglu" else n_main
             gemm(a, w[:n_main], bias[:n_main] if bias is not None else None,
-                 residual[:, :n_main] if residual is not None else None, act, out[:, :o_main], tile_cfg=24)
+                 residual[:, :n_main] if residual is not None else None, act, out[:, :o_main], tile_cfg=BIG_TILE)
             rem_tiles = -(-M // 256) * -(-(N - n_main) // 256)
             if thin_tail and rem_tiles <= 64:
                 gemm(a, w[n_main:], bias[n_main:] if bias is not None else None,
-                     residual[:, n_main:] if residual is not None else None, act, out[:, o_main:], tile_cfg=24,
+                     residual[:, n_main:] if residual is not None else None, act, out[:, o_main:], tile_cfg=BIG_TILE,
                      splits=max(2, min(16, 256 // rem_tiles, K // 256)))
             else:
                 gemm(a, w[n_main:], bias[n_main:] if bias is not None else None,
@@ -568,7 +575,7 @@ def conv3x3_mlvl(x, w, bias=None, act=None, out=None):
     _launch("g4r_conv3x3_mlvl_nhwc_bf16", (
         _p(x.flat), _p(w), _p(out.flat), _p(bias), _p(zeros_line(x.flat.device)), len(x.sizes), x._hw[0], x._hw[1], x.B,
         x.C, Cout, ACT[act], _stream(x.flat),),
-        tag="conv3x3_igemm<256x256pp32>", flops=2.0 * M * Cout * 9 * x.C,
+        tag=f"conv3x3_igemm<{TILE_NAMES[BIG_TILE] if BIG_TILE == 34 else '256x256pp32'}>", flops=2.0 * M * Cout * 9 * x.C,
         nbytes=2.0 * (M * x.C + Cout * 9 * x.C + M * Cout), dt=dt)
     return out
 

@@ -1,0 +1,139 @@
+"""GPU: the round-5 production GEMM tile (tile_cfg 34: 256 x 256, one wave per SIMD, K tiles of 64, epilogue mode chosen at
+launch) against (a) the ring ping-pong tile of rounds 2-4 -- bit-identical on dense problems: same MFMA, same K order, same
+rounding points -- and (b) plain fp32 torch arithmetic.  Both storage types (bf16 / fp16 instantiation).  The arithmetic is the
+one the reference delegates to cuBLAS / cuDNN through nn.Linear / nn.Conv2d (gpt4roi/models/layers.py:129-144, 257-270;
+llava/model/llava.py:52) and, for the fused epilogue, HF's apply_rotary_pos_emb + KV-cache append."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from gpt4roi_amd import kernels as K
+    from gpt4roi_amd._lib import lib
+
+DEV = "cuda"
+DTYPES = [torch.bfloat16, torch.float16]
+
+
+def rnd(*shape, scale=0.5, seed=0, dtype=torch.bfloat16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-9)).item()
+
+
+TOL = {torch.bfloat16: 6e-3, torch.float16: 1e-3}
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,Kd", [(300, 520, 128), (1000, 300, 64), (256, 256, 192), (513, 4096, 1024), (2049, 6216, 320),
+                                     (767, 1024, 4096), (3068, 4096, 4096)])
+def test_dense_bit_identical_to_the_ring_tile_and_close_to_fp32(M, N, Kd, dtype):
+    """ragged M and N (clamped rows, the generic epilogue on the ragged column tile), one / two / three / many K tiles"""
+    a, w = rnd(M, Kd, seed=1, dtype=dtype), rnd(N, Kd, seed=2, dtype=dtype)
+    got = K.gemm(a, w, tile_cfg=34)
+    assert torch.equal(got, K.gemm(a, w, tile_cfg=24))
+    assert rel(got, a.float() @ w.float().t()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [None, "relu", "quick_gelu", "silu"])
+@pytest.mark.parametrize("residual", [False, True])
+def test_epilogue_modes_bias_activation_residual(act, residual, dtype):
+    """16-bit park (no residual) and fp32 park (residual), every activation; M crosses the last row tile"""
+    a, w = rnd(900, 512, seed=3, dtype=dtype), rnd(768, 512, seed=4, dtype=dtype)
+    bias = rnd(768, seed=5, dtype=torch.float32)
+    res = rnd(900, 768, seed=6, dtype=dtype) if residual else None
+    got = K.gemm(a, w, bias=bias, residual=res, act=act, tile_cfg=34)
+    assert torch.equal(got, K.gemm(a, w, bias=bias, residual=res, act=act, tile_cfg=24))
+    r = a.float() @ w.float().t() + bias
+    r = {None: r, "relu": r.relu(), "quick_gelu": r * torch.sigmoid(1.702 * r), "silu": F.silu(r)}[act]
+    if residual:
+        r = r + res.float()
+    assert rel(got, r) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fp32_output_swiglu_and_k_slices(dtype):
+    a, w = rnd(700, 384, seed=7, dtype=dtype), rnd(1024, 384, seed=8, dtype=dtype)
+    bias = rnd(1024, seed=9, dtype=torch.float32)
+    f32 = K.gemm(a, w, bias=bias, out_dtype=torch.float32, tile_cfg=34)
+    assert torch.equal(f32, K.gemm(a, w, bias=bias, out_dtype=torch.float32, tile_cfg=24))
+    assert rel(f32, a.float() @ w.float().t() + bias) < 1e-5
+    sw = K.gemm(a, w, act="swiglu", tile_cfg=34)
+    assert sw.shape == (700, 512) and torch.equal(sw, K.gemm(a, w, act="swiglu", tile_cfg=24))
+    y = a.float() @ w.float().t()
+    assert rel(sw, F.silu(y[:, 0::2]) * y[:, 1::2]) < 3 * TOL[dtype]
+    for splits in (2, 3, 6):                                     # K slices: fp32 partials + the reduce launch
+        assert rel(K.gemm(a, w, splits=splits, tile_cfg=34), y) < TOL[dtype]
+    a2, w2 = rnd(767, 11008, seed=10, dtype=dtype), rnd(512, 11008, seed=11, scale=0.1, dtype=dtype)
+    assert rel(K.gemm(a2, w2, splits=4, tile_cfg=34), a2.float() @ w2.float().t()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T,heads", [(1, 767, 32), (3, 300, 4)])
+def test_fused_qkv_rope_epilogue_bit_identical_to_the_ring_tile(B, T, heads, dtype):
+    """epilogue mode W4_ROPE: q rotated, k rotated into the cache rows pos0 + t, v into the cache; untouched cache rows stay 0"""
+    HD = heads * 128
+    h, wqkv = rnd(B * T, 512, seed=12, dtype=dtype), rnd(3 * HD, 512, seed=13, dtype=dtype)
+    ang = torch.rand(1024, 64, generator=torch.Generator().manual_seed(14)) * 6.28
+    cos, sin = ang.cos().contiguous().to(DEV), ang.sin().contiguous().to(DEV)
+    outs = {}
+    for t in (24, 34):
+        q = torch.zeros(B, T, HD, dtype=dtype, device=DEV)
+        kc = torch.zeros(B, 1024, HD, dtype=dtype, device=DEV)
+        vc = torch.zeros(B, 1024, HD, dtype=dtype, device=DEV)
+        assert K.gemm_qkv_rope(h, wqkv, B, T, heads, 128, q, kc, vc, cos, sin, 5, tile_cfg=t) is not None
+        outs[t] = (q, kc, vc)
+    for x, y in zip(outs[24], outs[34]):
+        assert torch.equal(x, y)
+    q, kc, vc = outs[34]
+    assert (kc[:, :5] == 0).all() and (kc[:, 5 + T:] == 0).all() and (q != 0).float().mean() > 0.9
+    # against the plain statement: projection rounded to 16 bit, rotate_half in fp32
+    y = (h.float() @ wqkv.float().t()).to(dtype).float().view(B, T, 3, heads, 128)
+    c, s = cos[5:5 + T][None, :, None, :], sin[5:5 + T][None, :, None, :]
+
+    def rot(x):
+        x1, x2 = x[..., :64], x[..., 64:]
+        return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], -1)
+    assert rel(q.view(B, T, heads, 128), rot(y[:, :, 0])) < 2 * TOL[dtype]
+    assert rel(kc[:, 5:5 + T].view(B, T, heads, 128), rot(y[:, :, 1])) < 2 * TOL[dtype]
+    assert torch.equal(vc[:, 5:5 + T].view(B, T, heads, 128).float(), y[:, :, 2])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Ci,Co,G", [(1, 48, 48, 128, 256, 1), (2, 24, 20, 64, 320, 1), (1, 14, 14, 128, 256, 4)])
+def test_implicit_gemm_conv_vs_fp32_conv2d(B, H, W, Ci, Co, G, dtype):
+    """AMODE 1: taps as per-lane offsets, out-of-image taps as offsets beyond the buffer descriptor (zeros), groups summed in
+    one accumulator; K walks 64-channel slices, so the ring tile (32-channel slices) differs in the last bit only"""
+    x = rnd(G, B, H, W, Ci, seed=15, dtype=dtype) if G > 1 else rnd(B, H, W, Ci, seed=15, dtype=dtype)
+    ws = [rnd(Co, Ci, 3, 3, scale=0.05, seed=16 + g, dtype=torch.float32) for g in range(G)]
+    wk = K.prep_conv3x3_weight(ws, dtype=dtype)
+    bias = rnd(Co, seed=20, dtype=torch.float32)
+    xs = x if G > 1 else x[None]
+    ref = sum(F.conv2d(xs[g].float().permute(0, 3, 1, 2), ws[g].to(dtype).float(), padding=1) for g in range(G))
+    ref = (ref + bias[None, :, None, None]).relu().permute(0, 2, 3, 1)
+    got = K.conv3x3(x, wk, bias=bias, act="relu", groups=G, tile_cfg=34)
+    assert rel(got, ref) < TOL[dtype]
+    assert rel(got, K.conv3x3(x, wk, bias=bias, act="relu", groups=G, tile_cfg=24)) < TOL[dtype]
+
+
+def test_conv_over_all_levels_one_wave_per_simd_vs_ring_kernel():
+    """AMODE 2 (all pyramid levels in one launch): the production kernel against its ring ping-pong arm (debug mode 60)"""
+    mm = K.MlvlMaps(2, [(16, 16), (8, 8), (4, 4), (2, 2)], 128, DEV)
+    mm.flat.copy_(rnd(*mm.flat.shape, seed=21))
+    wc = rnd(256, 128, 3, 3, scale=0.05, seed=22, dtype=torch.float32)
+    wk = K.prep_conv3x3_weight(wc)
+    got = K.conv3x3_mlvl(mm, wk).flat.clone()
+    lib().g4r_gemm_debug_mode(60)
+    try:
+        ring = K.conv3x3_mlvl(mm, wk).flat.clone()
+    finally:
+        lib().g4r_gemm_debug_mode(0)
+    ref = torch.cat([F.conv2d(m.float().permute(0, 3, 1, 2), wc.to(torch.bfloat16).float(), padding=1).permute(0, 2, 3, 1).reshape(-1, 256)
+                     for m in mm.levels])
+    assert rel(got, ref) < TOL[torch.bfloat16] and rel(got, ring) < TOL[torch.bfloat16]

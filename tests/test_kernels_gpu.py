@@ -740,7 +740,7 @@ def test_conv3x3_over_all_pyramid_levels_in_one_launch(B, C, sizes):
     y = K.conv3x3_mlvl(x, w)
     assert [tuple(m.shape) for m in y.levels] == [(B, h, ww, C) for h, ww in sizes]
     for xl, yl in zip(x.levels, y.levels):
-        one = K.conv3x3(xl, w, tile_cfg=24, splits=1)
+        one = K.conv3x3(xl, w, tile_cfg=K.BIG_TILE, splits=1)       # the same kernel and K order (64-channel slices of a tap)
         assert torch.equal(yl, one)
         if C <= 128:
             ref = F.conv2d(xl.float().permute(0, 3, 1, 2), w4.float(), padding=1).permute(0, 2, 3, 1)
@@ -749,7 +749,7 @@ def test_conv3x3_over_all_pyramid_levels_in_one_launch(B, C, sizes):
     bias = rnd(C, seed=33, dtype=torch.float32)
     y2 = K.conv3x3_mlvl(x, w, bias=bias, act="relu")
     for xl, yl in zip(x.levels, y2.levels):
-        assert torch.equal(yl, K.conv3x3(xl, w, bias=bias, act="relu", tile_cfg=24, splits=1))
+        assert torch.equal(yl, K.conv3x3(xl, w, bias=bias, act="relu", tile_cfg=K.BIG_TILE, splits=1))
 
 
 @pytest.mark.parametrize("B,H,D,kv", [(3, 32, 128, 300), (8, 32, 128, 21), (2, 16, 64, 577)])

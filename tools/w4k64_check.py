@@ -103,10 +103,10 @@ mm = K.MlvlMaps(2, sizes, 128, dev)
 mm.flat.copy_(R(*mm.flat.shape))
 wc = torch.randn(256, 128, 3, 3, device=dev, generator=g) * 0.05
 wk = K.prep_conv3x3_weight(wc)
+lib().g4r_gemm_debug_mode(60)          # the ring ping-pong kernel (A/B arm)
 ref = K.conv3x3_mlvl(mm, wk).flat.clone()
-lib().g4r_gemm_debug_mode(34)
-got = K.conv3x3_mlvl(mm, wk).flat.clone()
 lib().g4r_gemm_debug_mode(0)
+got = K.conv3x3_mlvl(mm, wk).flat.clone()
 r32 = torch.cat([torch.nn.functional.conv2d(mm.levels[l].float().permute(0, 3, 1, 2), wc.to(torch.bfloat16).float(), padding=1)
                  .permute(0, 2, 3, 1).reshape(-1, 256) for l in range(4)])
 report("conv all levels in one launch", got, ref, r32, exact=False)
@@ -152,11 +152,11 @@ for B in (1, 4):
     wk = R(1024, 9 * 1024)
     out = K.MlvlMaps(B, mm.sizes, 1024, dev)
     row = {"conv_mlvl_batch": B}
-    for mode in (0, 34):
+    for mode in (60, 0):
         lib().g4r_gemm_debug_mode(mode)
         fn = lambda: K.conv3x3_mlvl(mm, wk, out=out)            # noqa: E731
         fn(); torch.cuda.synchronize()
         us = burst(fn, n=4)
-        row["pp32" if mode == 0 else "w4k64"] = [round(us, 1), round(2.0 * mm.flat.size(0) * 1024 * 9216 / us / 1e6, 1)]
+        row["pp32" if mode == 60 else "w4k64"] = [round(us, 1), round(2.0 * mm.flat.size(0) * 1024 * 9216 / us / 1e6, 1)]
     lib().g4r_gemm_debug_mode(0)
     print(json.dumps(row), flush=True)
