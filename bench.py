@@ -2,13 +2,15 @@
 """bench.py -- region-tokens/s of the region-feature path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: either launched as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py
+    --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or as the plain command above -- bench.py then starts
+    the N ranks itself through the same launcher (one process per GPU, RCCL over xGMI) and rank 0 prints the line.
 
 Workload (BASELINE.json configs[1], the one the metric is quoted on): batch-1 requests of ONE 336x336 image with 32 RoIs
 each: CLIP ViT-L/14 (23 of 24 blocks) -> 4-level pyramid + 5 fuse rounds -> multi-level
 RoIAlign -> pconvs / flatten_linear / pos-embed / updims -> mm_projector -> splice + <bbox>
 injection -> LLaMA-7B prefill forward with logits for every position.  A "step" is ONE launch sequence over
-`--batch` such requests merged (continuous batching, default 8: the weights are streamed once for all of them and the
+`--batch` such requests merged (continuous batching, default 16: the weights are streamed once for all of them and the
 LLaMA GEMMs get M = 8 x 767 rows, i.e. whole waves of tiles on the 256 CUs; profiles/r04_merge_sweep.txt: 1 x 1 1652, 1 x 2 1856,
 4 x 2 2011, 8 x 2 2096 region-tokens/s on one box); `value` counts every request's 32 region
 tokens.  `--batch 1 --streams 1` is the strictly serial batch-1 latency, reported beside the headline as `single_request`.
@@ -51,9 +53,11 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="independent launch sequences in flight per GPU, one HIP stream each (1 = strictly serial; with 16 "
                          "merged requests a second sequence no longer helps: profiles/r04_merge_sweep.txt)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
-                    help="16-bit storage type of the whole path: bf16 (the reference's training dtype; the default) or fp16 (its "
-                         "serving dtype, app.py:74-98) -- same MFMA rate, same bytes")
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"],
+                    help="16-bit storage type of the whole path.  fp16 (the default) is what the reference SERVES configs[1] in "
+                         "(app.py:74-98, boxes :271, image :296) and the storage type whose greedy ids equal HF fp32's on every "
+                         "tested draw (64 of 64 new tokens, profiles/r05_greedy_parity.json); bf16 is its training dtype -- "
+                         "same MFMA rate, same bytes, reported under extras")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (fp16, 224^2, single request)")
     ap.add_argument("--batch", type=int, default=16,
                     help="batch-1 requests merged into ONE launch sequence per step (continuous batching: the weights are "
@@ -302,13 +306,38 @@ def train_leg(args, model, ids, device, rank, world, dist, agg_device):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks through torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) and return their exit code.  The reference's launch line is the same launcher:
+    train_stage1.sh:11 `torchrun --nproc_per_node=4`."""
+    import socket
+    import subprocess
+    if "G4R_FORCE_DEVICE" not in os.environ:                 # (test hook: several ranks on one GPU over gloo)
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the path has no CPU fallback")
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}")
     # test hooks (not used by the driver): run >1 rank on a 1-GPU box over gloo to exercise this code path
     backend = os.environ.get("G4R_DIST_BACKEND", "nccl")                  # "nccl" is RCCL on ROCm
     if "G4R_FORCE_DEVICE" in os.environ:
@@ -568,32 +597,52 @@ def main():
             extras["error"] = repr(ex)
     train = None
     n_ctx, graph_ok = len(ctxs), all(g is not None for g in graphs)
-    if args.train_steps > 0 and args.dtype == "bf16":          # the reference trains in bf16 (train_stage1.sh:19)
+    # the OTHER storage type of the same configuration (extras) and the training leg.  The reference trains in bf16
+    # (train_stage1.sh:19) and serves in fp16 (app.py:74-98): with the fp16 headline the bf16 model built for the extras leg is
+    # the one the training leg runs on (every rank builds it when the training leg is on).
+    other_name = "bf16" if args.dtype == "fp16" else "fp16"
+    other_dtype = torch.bfloat16 if other_name == "bf16" else torch.float16
+    want_other_leg = rank == 0 and extras is not None and world == 1
+    want_train = args.train_steps > 0
+    del graphs, ctxs, reqs                               # release the captured inference pools
+    graph_error = last.get("graph_error")
+    last.clear()
+    last["graph_error"] = graph_error
+    torch.cuda.empty_cache()
+    m_train = model if args.dtype == "bf16" else None
+    if want_train and m_train is not None:
         try:
-            del graphs, ctxs, reqs                       # release the captured inference pools before training
-            graph_error = last.get("graph_error")
-            last.clear()
-            last["graph_error"] = graph_error
-            torch.cuda.empty_cache()
-            train = train_leg(args, model, ids, device, rank, world, dist, device if backend == "nccl" else "cpu")
+            train = train_leg(args, m_train, ids, device, rank, world, dist, device if backend == "nccl" else "cpu")
         except Exception as ex:                                      # never lose the headline: every rank carries on to the
             train = {"error": repr(ex)}                              # end and exits 0 (no collective follows this leg); a
             #                                                          rank left waiting in one gets the group's timeout here
-
-    if rank == 0 and extras is not None and args.dtype == "bf16" and world == 1:
+    if want_other_leg or (want_train and m_train is None):
         try:
-            del model
+            del model, m_train
             torch.cuda.empty_cache()
-            m16, ids16 = build_model(args, device, seed=100 + rank, dtype=torch.float16)
-            i3, b3, p3 = make_inputs(args, ids16, device, seed=rank)
-            t3 = timed_replay(m16, i3, b3, p3, steps=max(4, args.steps // 2), streams=max(1, args.streams))
-            extras["fp16"] = {"ms_per_step": round(1e3 * t3, 3), "region_tokens_per_s": round(args.rois * i3.size(0) / t3, 1),
-                              "what": "the headline configuration with fp16 storage (the reference's serving dtype, app.py:74-98): "
-                                      "the -DG4R_F16 instantiation of the same kernels"}
-            del m16, i3, b3, p3
-            torch.cuda.empty_cache()
+            m2, ids2 = build_model(args, device, seed=100 + rank, dtype=other_dtype)
+            if want_other_leg:
+                i3, b3, p3 = make_inputs(args, ids2, device, seed=rank)
+                t3 = timed_replay(m2, i3, b3, p3, steps=max(4, args.steps // 2), streams=max(1, args.streams))
+                extras[other_name] = {"ms_per_step": round(1e3 * t3, 3), "region_tokens_per_s": round(args.rois * i3.size(0) / t3, 1),
+                                      "what": f"the headline configuration with {other_name} storage (bf16 = the reference's training "
+                                              "dtype, train_stage1.sh:19; fp16 = its serving dtype, app.py:74-98): the other "
+                                              "instantiation of the same kernels"}
+                del i3, b3, p3
+                torch.cuda.empty_cache()
         except Exception as ex:
-            extras["fp16"] = {"error": repr(ex)}
+            m2 = None
+            if extras is not None:
+                extras[other_name] = {"error": repr(ex)}
+        if want_train and other_name == "bf16":
+            try:
+                if m2 is None:
+                    raise RuntimeError("the bf16 model of the training leg could not be built")
+                train = train_leg(args, m2, ids2, device, rank, world, dist, device if backend == "nccl" else "cpu")
+            except Exception as ex:
+                train = {"error": repr(ex)}
+        m2 = None
+        torch.cuda.empty_cache()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -601,15 +650,47 @@ def main():
         except Exception as ex:                                      # never lose the GPU number
             cpu = {"error": repr(ex)}
 
+    greedy = None
+    if rank == 0:
+        # exact-id statistics of the committed GPU test for this storage type: written by
+        # tests/test_fullwidth_gpu.py on the GPU box, merged into profiles/rNN_greedy_parity.json
+        try:
+            import glob
+            import re as _re
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_greedy_parity.json")),
+                           key=lambda f: int(_re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+            if cands:
+                runs = json.load(open(cands[-1]))["runs"]
+
+                def summary(dt):
+                    rs = [r for r in runs if r["dtype"] == dt]
+                    if not rs:
+                        return None
+                    n = rs[0]["new_tokens"]
+                    return {"seeds": [r["seed"] for r in rs], "new_tokens": n,
+                            "exact": all(r["whole_path_generate_exact_len"] == n and r["teacher_forced_identical"] == n for r in rs),
+                            "whole_path_exact_len": [r["whole_path_generate_exact_len"] for r in rs],
+                            "decoder_free_running_exact_len": [r["free_running_exact_len"] for r in rs],
+                            "teacher_forced_identical": [r["teacher_forced_identical"] for r in rs],
+                            "first_divergence": [r["whole_path_first_divergence"] for r in rs if r["whole_path_first_divergence"]] or None}
+                greedy = {"source": os.path.relpath(cands[-1], ROOT), "against": runs[0]["against"],
+                          args.dtype: summary(args.dtype), ("bf16" if args.dtype == "fp16" else "fp16"): summary("bf16" if args.dtype == "fp16" else "fp16")}
+        except Exception as ex:
+            greedy = {"error": repr(ex)}
     if rank == 0:
         P = args.image_size // 14
         total_regions = args.rois * args.batch * args.steps * world
         line = {
-            "metric": "region-tokens/sec (336^2 img, 32 RoIs, CLIP ViT-L/14 + region module + LLaMA-7B fwd)",
+            "metric": f"region-tokens/sec (336^2 img, 32 RoIs, CLIP ViT-L/14 + region module + LLaMA-7B fwd; {args.batch} batch-1 requests "
+                      "merged per launch sequence, value_batch1 = one request at a time)",
             "value": round(total_regions / dt, 2), "unit": "region-tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "value_per_gpu": round(total_regions / dt / world, 2),
+            "ranks": world, "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+            # configs[1] is a batch-1 request; `value` is the throughput of a server that merges `requests_per_step` of them into
+            # one launch sequence (the weights stream once for all); the strictly serial batch-1 figure of the same run:
+            "value_batch1": (extras or {}).get("single_request", {}).get("region_tokens_per_s"),
             "in_flight_requests_per_gpu": n_ctx, "hipMalloc_calls_in_timed_region": device_allocs_in_timed_region,
             "hipgraph": graph_ok, "hipgraph_error": last.get("graph_error"),
             "requests_per_step": args.batch,
@@ -622,6 +703,8 @@ def main():
                        "parallelism": f"replicas x{world} (no data-path collective); {n_ctx} launch sequences of {args.batch} "
                                       f"requests in flight per GPU on separate HIP streams",
                        "valid": args.llama_layers == 32 and args.image_size == 336 and args.rois == 32},
+            "greedy_exact": (greedy or {}).get(args.dtype, {}).get("exact") if isinstance((greedy or {}).get(args.dtype), dict) else None,
+            "greedy_parity": greedy,
             "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "train": train, "extras": extras, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)

@@ -454,7 +454,7 @@ int launch_bwd(const AttnBwdArgs& a, int B, hipStream_t stream) {
   if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
-    if (e != hipSuccess) return g4r_note_hip_error(e, "attn_bwd_dkv: hipFuncSetAttribute");
+    if (e != hipSuccess) { attr_set.failed(); return g4r_note_hip_error(e, "attn_bwd_dkv: hipFuncSetAttribute"); }
   }
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, NW>), dim3(g4r_ceil_div(a.Tk, NW * 32), a.H, B), dim3(NW * 64), DKV_LDS,
                      stream, a);

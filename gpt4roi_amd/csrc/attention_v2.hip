@@ -462,7 +462,7 @@ int launch_attn2(const Attn2Args& a, int B, hipStream_t st) {
   static G4rPerDeviceOnce attr_set;
   if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return g4r_note_hip_error(e, "flash_attn_fwd2: hipFuncSetAttribute");
+    if (e != hipSuccess) { attr_set.failed(); return g4r_note_hip_error(e, "flash_attn_fwd2: hipFuncSetAttribute"); }
   }
   dim3 grid(g4r_ceil_div(a.Tq, NWG * 32), a.H, B);
   hipLaunchKernelGGL(kfn, grid, dim3(NWG * NG * 64), LDS, st, a);

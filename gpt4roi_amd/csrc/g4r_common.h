@@ -77,6 +77,8 @@ __device__ __forceinline__ float h16hi(uint32_t w) { return __uint_as_float(w & 
 // hipFuncSetAttribute(hipFuncAttributeMaxDynamicSharedMemorySize) applies to the CURRENT device only: launchers remember it
 // per (kernel, device), not in one process-wide flag (a second GPU or a device reset would otherwise launch the
 // > 64 KB LDS kernels without it).  A benign race between host threads sets the attribute twice.
+// A failing hipFuncSetAttribute must NOT leave the device marked: the launcher calls failed() on its error path,
+// so the next call retries the attribute instead of launching a > 64 KB dynamic-LDS kernel without the raised limit.
 struct G4rPerDeviceOnce {
   bool done[64] = {};
   bool first() {
@@ -85,6 +87,10 @@ struct G4rPerDeviceOnce {
     if (done[d]) return false;
     done[d] = true;
     return true;
+  }
+  void failed() {
+    int d = 0;
+    if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) done[d] = false;
   }
 };
 

@@ -1911,7 +1911,7 @@ int launch_w4(GemmArgs& p, hipStream_t stream) {
   if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_w4: hipFuncSetAttribute");
+    if (e != hipSuccess) { attr_set.failed(); return g4r_note_hip_error(e, "gemm_w4: hipFuncSetAttribute"); }
   }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(256), lds, stream, p);
   G4R_CHECK_LAUNCH("gemm_bf16_w4");
@@ -2430,7 +2430,7 @@ int launch_w4k64_epi(GemmArgs& p, hipStream_t stream) {
   if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_w4k64: hipFuncSetAttribute");
+    if (e != hipSuccess) { attr_set.failed(); return g4r_note_hip_error(e, "gemm_w4k64: hipFuncSetAttribute"); }
   }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(256), lds, stream, p);
   G4R_CHECK_LAUNCH("gemm_bf16_w4k64");
@@ -2520,7 +2520,7 @@ int launch_pp32(GemmArgs& p, hipStream_t stream) {
   if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_pp32: hipFuncSetAttribute");
+    if (e != hipSuccess) { attr_set.failed(); return g4r_note_hip_error(e, "gemm_pp32: hipFuncSetAttribute"); }
   }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(512), lds, stream, p);
   G4R_CHECK_LAUNCH("gemm_bf16_pp32");
@@ -2552,7 +2552,7 @@ int launch_pp(GemmArgs& p, hipStream_t stream) {
   if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return g4r_note_hip_error(e, "gemm_pp: hipFuncSetAttribute");
+    if (e != hipSuccess) { attr_set.failed(); return g4r_note_hip_error(e, "gemm_pp: hipFuncSetAttribute"); }
   }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(512), lds, stream, p);
   G4R_CHECK_LAUNCH("gemm_bf16_pp");
@@ -2584,7 +2584,7 @@ int launch_tile(GemmArgs& p, hipStream_t stream) {
   if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return g4r_note_hip_error(e, "gemm: hipFuncSetAttribute");
+    if (e != hipSuccess) { attr_set.failed(); return g4r_note_hip_error(e, "gemm: hipFuncSetAttribute"); }
   }
   dim3 grid(p.tiles_m * p.tiles_n, p.splits);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);

@@ -367,9 +367,10 @@ static void tn_balance(TnArgs& a) {
 
 static int tn_launch(TnArgs& a, void* stream) {
   const int lds = 4 * 32768;
-  if (g_tn_lds.first())
-    G4R_REQUIRE(hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) ==
-                    hipSuccess, "gemm_tn: cannot raise the dynamic LDS limit");
+  if (g_tn_lds.first()) {
+    const hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { g_tn_lds.failed(); return g4r_note_hip_error(e, "gemm_tn: hipFuncSetAttribute"); }
+  }
   int longest = 0;
   for (int x = 0; x < 8; ++x)
     if (a.xcd_first[x + 1] - a.xcd_first[x] > longest) longest = a.xcd_first[x + 1] - a.xcd_first[x];

@@ -230,7 +230,7 @@ extern "C" int g4r_sample_advance_f32(const float* logits, int N, float temperat
   if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_advance_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    if (e != hipSuccess) return g4r_note_hip_error(e, "sample_advance: hipFuncSetAttribute");
+    if (e != hipSuccess) { attr_set.failed(); return g4r_note_hip_error(e, "sample_advance: hipFuncSetAttribute"); }
   }
   hipLaunchKernelGGL(sample_advance_kernel, dim3(1), dim3(SNT), lds, (hipStream_t)stream, logits, N, in_lds,
                      1.0f / temperature, top_k, top_p, seed, tok, out_ids, step, pos, max_steps, u_out);

@@ -284,6 +284,28 @@ class FullShardManager:
         full = sum(f.numel * (esz[f.dtype] + 4 + 8 + (4 if f.dtype == torch.bfloat16 else 0)) for f in flats)
         return own, full, self.peak_transient
 
+    # ---- this rank's shards, for checkpoints (torch FSDP's sharded state dict: resumable on the same (rank, world) layout) ----
+    def shard_state(self):
+        units = []
+        for u in self.units:
+            units.append([dict(names=[n for n, _ in fl.entries], dtype=str(fl.dtype), param_shard=fl.param_shard.clone(),
+                               master=fl.master.clone(), exp_avg=fl.exp_avg.clone(), exp_avg_sq=fl.exp_avg_sq.clone())
+                          for fl in u["flats"]])
+        return {"rank": self.rank, "world": self.world, "units": units}
+
+    def load_shard_state(self, sd):
+        assert sd["world"] == self.world and sd["rank"] == self.rank, "the sharded state is per (rank, world)"
+        assert len(sd["units"]) == len(self.units)
+        for u, su in zip(self.units, sd["units"]):
+            assert len(u["flats"]) == len(su)
+            for fl, s in zip(u["flats"], su):
+                assert [n for n, _ in fl.entries] == s["names"] and str(fl.dtype) == s["dtype"]
+                fl.param_shard.copy_(s["param_shard"])
+                if fl.master is not fl.param_shard:
+                    fl.master.copy_(s["master"])
+                fl.exp_avg.copy_(s["exp_avg"])                 # (after the first step these ARE the fused optimizer's moments)
+                fl.exp_avg_sq.copy_(s["exp_avg_sq"])
+
     def full_state(self, ui):
         """name -> full tensor of unit ui (gathers it; for checkpoints / tests).  The caller must release(ui)."""
         self.direction(1)

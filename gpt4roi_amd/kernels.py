@@ -1302,7 +1302,10 @@ def linear_wgrad(dy, x, out_dtype=torch.float32, splits=None, out=None):
     if out_dtype == torch.float32 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.dim() == 2 and \
             x.dim() == 2 and dy.size(1) % 8 == 0 and x.size(1) % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 \
             and dy.stride(1) == 1 and x.stride(1) == 1 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 \
-            and os.environ.get("G4R_WGRAD_CM", "0") != "1" and (out is None or (out.dtype == torch.float32 and out.is_contiguous())):
+            and os.environ.get("G4R_WGRAD_CM", "0") != "1" and (out is None or (out.dtype == torch.float32 and out.is_contiguous())) \
+            and dy.size(0) * dy.stride(0) * 2 < 2 ** 31 - 1 and x.size(0) * x.stride(0) * 2 < 2 ** 31 - 1:
+        # (operands of 2 GiB and more -- dgu [tokens, 22016] above ~48.7 k tokens -- exceed the TN kernel's 32-bit buffer
+        #  offsets: they take the transposed-copy path below instead of raising)
         return gemm_tn(dy, x, out=out)
     if out is not None:
         out.copy_(linear_wgrad(dy, x, out_dtype=out_dtype, splits=splits))

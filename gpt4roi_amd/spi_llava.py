@@ -80,6 +80,7 @@ class _RegionPathFn(torch.autograd.Function):
             logits, pctx = model.forward_train(input_ids, images, bboxes, attention_mask=attention_mask)
         ctx.model, ctx.pctx, ctx.names = model, pctx, names
         ctx.shape = (input_ids.size(0), input_ids.size(1))
+        ctx.input_ids = input_ids
         return logits.view(input_ids.size(0), input_ids.size(1), -1)
 
     @staticmethod
@@ -90,6 +91,8 @@ class _RegionPathFn(torch.autograd.Function):
             dl = torch.zeros((B * T, dec.v_pad), dtype=torch.bfloat16, device=dlogits.device)
             dl[:, :dec.vocab] = dlogits.reshape(B * T, dec.vocab)
             grads = model.backward(ctx.pctx, dl, train_projector=any(n.startswith("mm_projector.") for n in ctx.names))
+            if any(n.startswith("llama.") for n in ctx.names):       # stage 2: the decoder's own weights (and embedding rows)
+                grads.update(model.decoder_param_grads(ctx.input_ids))
         ctx.pctx = None
         return (None, None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
@@ -110,6 +113,42 @@ class _ShiftedCrossEntropyFn(torch.autograd.Function):
     def backward(ctx, g):
         B, T, V = ctx.shape
         return (ctx.dl[:, :V].float() * g).view(B, T, V), None, None
+
+
+class _DecoderLayerMasters(nn.Module):
+    pass
+
+
+class _DecoderMasters(nn.Module):
+    """The decoder's weights as fp32 nn.Parameters over its KERNEL-layout tensors (fused q|k|v rows, interleaved gate / up rows:
+    `LlamaDecoder.trainable_tensors`) -- what makes stage 2 drivable through the reference's own caller
+    (gpt4roi/train/train.py:698-712: HF Trainer.training_step = model(**batch).loss.backward() + a torch optimizer over
+    `model.parameters()`; stage 1 freezes them by name, train.py:685-697; train_stage2.sh leaves them trainable).  The bf16
+    tensors the kernels read are roundings of these masters, re-derived when an optimizer step bumps a version counter
+    (`SPILlavaLlamaModel._maybe_prepare`); the fp32 norm weights ARE the parameters' storage."""
+
+    def __init__(self, dec):
+        super().__init__()
+        live = dec.trainable_tensors()
+
+        def P(t):
+            return nn.Parameter(t if t.dtype == torch.float32 else t.float())
+        self.embed_tokens, self.norm, self.lm_head = P(live["embed_tokens"]), P(live["norm"]), P(live["lm_head"])
+        self.layers = nn.ModuleList()
+        for i in range(len(dec.layers)):
+            m = _DecoderLayerMasters()
+            for nm in ("wqkv", "wo", "wgu", "wd", "n1", "n2"):
+                setattr(m, nm, P(live[f"{i}.{nm}"]))
+            self.layers.append(m)
+
+    def named_kernel_tensors(self):
+        """(name as LlamaDecoder.trainable_tensors() spells it, parameter), in that order"""
+        yield "embed_tokens", self.embed_tokens
+        for i, m in enumerate(self.layers):
+            for nm in ("wqkv", "wo", "wgu", "wd", "n1", "n2"):
+                yield f"{i}.{nm}", getattr(m, nm)
+        yield "norm", self.norm
+        yield "lm_head", self.lm_head
 
 
 class SPILlavaLlamaModel(nn.Module):
@@ -133,6 +172,8 @@ class SPILlavaLlamaModel(nn.Module):
         self._stamp = None
         self.last_status = None
         self.gradient_checkpointing = False
+        self.llama_master = None                    # stage 2 through autograd: enable_decoder_training()
+        self._llama_stamp = None
 
     # ---- kernel-ready copies of the nn.Parameters, refreshed when a parameter changed -------------------------
     def _param_stamp(self):
@@ -153,6 +194,46 @@ class SPILlavaLlamaModel(nn.Module):
         """An optimizer step (or load_state_dict) bumps the parameters' version counters: re-derive the bf16 copies."""
         if self._proj is None or self._stamp != self._param_stamp():
             self.prepare()
+        if self.llama_master is not None:
+            st = tuple((p.data_ptr(), p._version) for _, p in self.llama_master.named_kernel_tensors())
+            if st != self._llama_stamp:
+                self.sync_decoder_from_masters()
+
+    # ---- stage 2 under autograd ----------------------------------------------------------------------------------------------
+    def enable_decoder_training(self):
+        """Expose the decoder's weights as fp32 nn.Parameters (`llama_master.*` in named_parameters(), requires_grad=True: the
+        state the reference's model is in when train_stage2.sh starts; the stage-1 freeze loop of train.py:685-697 turns them
+        off again by name).  27 GB of masters for the 7 B model, on top of which a torch optimizer keeps its own state."""
+        if self.llama_master is None:
+            self.llama.prepare_training(train_weights=True)
+            self.llama_master = _DecoderMasters(self.llama)
+            self.sync_decoder_from_masters()
+        return self.llama_master
+
+    @torch.no_grad()
+    def sync_decoder_from_masters(self):
+        """bf16 kernel tensors <- fp32 masters (one rounding, as FullTrainer's fused AdamW writes them), W^T refreshed"""
+        live = self.llama.trainable_tensors()
+        for k, prm in self.llama_master.named_kernel_tensors():
+            t = live[k]
+            if t.data_ptr() != prm.data_ptr():
+                t.copy_(prm.data)
+        self.llama.refresh_transposes()
+        self._llama_stamp = tuple((p.data_ptr(), p._version) for _, p in self.llama_master.named_kernel_tensors())
+
+    @torch.no_grad()
+    def decoder_param_grads(self, input_ids):
+        """After backward(): 'llama.<kernel tensor>' -> fp32 gradient of every decoder weight (LlamaDecoder.backward left them
+        in `llama.grads`) + the embedding rows: every position that took embed[id] in the splice (not <im_patch>, not <bbox>)."""
+        dec, cfg = self.llama, self.config
+        out = {f"llama.{k}": g for k, g in dec.grads.items()}
+        flat = input_ids.reshape(-1)
+        idx = torch.where((flat == cfg.im_patch_token) | (flat == cfg.bbox_token), torch.full_like(flat, -1), flat)
+        ge = torch.zeros(dec.embed.shape, dtype=torch.float32, device=dec.embed.device)
+        K.scatter_add_rows(self._d_emb, idx.to(torch.int32).contiguous(), ge)
+        out["llama.embed_tokens"] = ge
+        dec.grads = {}
+        return out
 
     def initialize_vision_modules(self, vision_tower, mm_vision_select_layer=-2, pretrain_mm_mlp_adapter=None,
                                   tune_mm_mlp_adapter=False):
@@ -326,6 +407,8 @@ class SPILlavaLlamaModel(nn.Module):
         """name -> nn.Parameter for the stage-1 trainables that currently require grad (train.py:685-696)."""
         out = {f"spi_module.{k}": p for k, p in self.spi_module.named_parameters() if p.requires_grad}
         out.update({f"mm_projector.{k}": p for k, p in self.mm_projector.named_parameters() if p.requires_grad})
+        if self.llama_master is not None:          # stage 2: the decoder's masters (enable_decoder_training)
+            out.update({f"llama.{k}": p for k, p in self.llama_master.named_kernel_tensors() if p.requires_grad})
         return out
 
     def forward(self, input_ids: torch.LongTensor = None, attention_mask: Optional[torch.Tensor] = None,
@@ -337,6 +420,8 @@ class SPILlavaLlamaModel(nn.Module):
             named = self.trainable_named()
             if named:
                 names = tuple(named)
+                if self.llama_master is not None:   # weight gradients only when a decoder parameter asks for one
+                    self.llama.train_weights = any(n.startswith("llama.") for n in names)
                 return _RegionPathFn.apply(self, input_ids, images, bboxes, attention_mask, names, *named.values())
         with torch.no_grad():
             if inputs_embeds is None:
@@ -388,6 +473,14 @@ class SPILlavaMPTForCausalLM(nn.Module):
 
     def gradient_checkpointing_disable(self):
         self.model.gradient_checkpointing = False
+
+    def enable_decoder_training(self):
+        """Stage 2 (train_stage2.sh) through the reference's own caller: after this call `named_parameters()` lists the LLaMA
+        weights (`model.llama_master.*`, fp32, requires_grad) beside the region module and the projector, `model(**batch).loss
+        .backward()` fills their `.grad` with the hand-written backward's weight gradients, and any torch optimizer steps them;
+        the stage-1 freeze loop (train.py:685-697: requires_grad = 'spi_module' in name) turns them off by name.  Call it once,
+        after `resize_token_embeddings` / `initialize_vision_tokenizer` (the masters are built from the final tables)."""
+        return self.model.enable_decoder_training()
 
     def resize_token_embeddings(self, new_num_tokens):
         """HF `resize_token_embeddings`: grow (or cut) the embedding table and lm_head; new rows are zero until
@@ -469,6 +562,8 @@ class SPILlavaMPTForCausalLM(nn.Module):
     def state_dict(self, *args, **kwargs):
         """The HF-keyed state dict the reference checkpoints carry (`model.layers.*`, `lm_head.weight`,
         `model.spi_module.*`, `model.mm_projector.*`; no vision tower: llava.py:48 keeps it in a Python list)."""
+        if self.model.llama_master is not None:
+            self.model._maybe_prepare()            # the kernel tensors follow the masters an optimizer may just have stepped
         sd = self.model.llama.export_hf_state_dict()
         sd.update({f"model.spi_module.{k}": v.detach() for k, v in self.model.spi_module.state_dict().items()})
         sd.update({f"model.mm_projector.{k}": v.detach() for k, v in self.model.mm_projector.state_dict().items()})

@@ -421,3 +421,91 @@ class FSDPFullTrainer(FullTrainer):
                 out[n] = v.detach().clone()
             self.fsdp.release(ui)
         return out
+
+    # ---- checkpoints: what the reference's stage 2 ends with is an HF-named FULL state dict
+    #      (safe_save_model_for_hf_trainer, gpt4roi/train/train.py:86-95) plus a resumable optimizer; under FSDP the optimizer
+    #      state is saved per rank (torch FSDP's sharded state dict) ----
+    def state_dict(self):
+        """THIS rank's shards: per unit and dtype the parameter shard, its fp32 master and the Adam moments, + the step count.
+        Resuming needs the same (rank, world) layout, as FSDP's sharded state dict does."""
+        return {"step": self.steps, **self.fsdp.shard_state()}
+
+    def load_state_dict(self, sd):
+        self.fsdp.load_shard_state(sd)
+        self.steps = self.fsdp.steps = int(sd["step"])
+        if self.fsdp._fused is not None:
+            self.fsdp._fused.steps = self.steps
+
+    def summon_full_params(self):
+        """Context manager: every unit gathered and bound, the kernel-ready copies of the region module / projector re-derived
+        -- the model can then run `generate` / evaluation or be exported between two steps (torch FSDP's
+        `summon_full_params`).  Costs the full 13.5 GB of bf16 weights for its duration; everything is released on exit."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            f, dec = self.fsdp, self.model.llama
+            f.direction(1)
+            keep, f.prefetch = f.prefetch, 0
+            hook, dec.unit_hook = dec.unit_hook, None          # (the per-layer gather / release of a training step stays out of it)
+            try:
+                for ui in range(len(f.units)):
+                    f.use(ui)
+                self.model.prepare()
+                dec.refresh_transposes()                       # lazy: lm_head^T only
+                yield self.model
+            finally:
+                dec.lm_head_t = None
+                for ui in range(len(f.units)):
+                    f.release(ui)
+                f.prefetch = keep
+                dec.unit_hook = hook
+        return ctx()
+
+    def export_hf_state_dict(self):
+        """The reference-format checkpoint content: HF-named FULL tensors of the decoder (q|k|v and gate/up de-fused) + the
+        region module and projector under their reference keys.  Gathers one unit at a time."""
+        f, dec = self.fsdp, self.model.llama
+        C = dec.hidden
+        out = {}
+        root = f.full_state(0)
+        for n, v in root.items():
+            if n == "llama.embed_tokens":
+                out["model.embed_tokens.weight"] = v.detach().clone()
+            elif n == "llama.norm":
+                out["model.norm.weight"] = v.detach().clone()
+            elif n == "llama.lm_head":
+                out["lm_head.weight"] = v.detach().clone()
+            else:
+                out["model." + n] = v.detach().clone()           # spi_module.* / mm_projector.* (self.params keys)
+        f.release(0)
+        for li in range(len(dec.layers)):
+            t = f.full_state(1 + li)
+            g = lambda nm: t[f"llama.{li}.{nm}"]                 # noqa: E731
+            p = f"model.layers.{li}."
+            out[p + "self_attn.q_proj.weight"] = g("wqkv")[:C].detach().clone()
+            out[p + "self_attn.k_proj.weight"] = g("wqkv")[C:2 * C].detach().clone()
+            out[p + "self_attn.v_proj.weight"] = g("wqkv")[2 * C:].detach().clone()
+            out[p + "self_attn.o_proj.weight"] = g("wo").detach().clone()
+            out[p + "mlp.gate_proj.weight"] = g("wgu")[0::2].detach().clone()
+            out[p + "mlp.up_proj.weight"] = g("wgu")[1::2].detach().clone()
+            out[p + "mlp.down_proj.weight"] = g("wd").detach().clone()
+            out[p + "input_layernorm.weight"] = g("n1").detach().clone()
+            out[p + "post_attention_layernorm.weight"] = g("n2").detach().clone()
+            f.release(1 + li)
+        return out
+
+    def save_pretrained(self, path, safe_serialization=True, max_shard_bytes=5 << 30):
+        """HF-layout directory of the FULL model (every rank gathers; rank 0 writes) -- what train.py:86-95 leaves behind."""
+        import json as _json
+        import os as _os
+
+        from . import checkpoint as ckpt
+        sd = self.export_hf_state_dict()
+        if self.fsdp.rank == 0:
+            _os.makedirs(path, exist_ok=True)
+            ckpt.save_hf_state_dict(sd, path, safe_serialization, max_shard_bytes)
+            with open(_os.path.join(path, "config.json"), "w") as fh:
+                _json.dump(ckpt.model_config(type("_Wrapped", (), {"model": self.model})()), fh, indent=2)
+        if dist.is_initialized() and self.fsdp.world > 1:
+            dist.barrier(group=self.fsdp.group)

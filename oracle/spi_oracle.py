@@ -64,19 +64,21 @@ class _RoIAlignOracleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rois, output_size, spatial_scale, sampling_ratio, pool_mode, aligned):
         assert pool_mode == 'avg'
-        out, _, _ = roi_oracle.forward(x.detach().float().numpy(), rois.detach().float().numpy(), output_size,
+        # (x may live on an accelerator when the surrounding torch ops of the oracle are run there: the node itself is always
+        #  the C oracle on the host)
+        out, _, _ = roi_oracle.forward(x.detach().float().cpu().numpy(), rois.detach().float().cpu().numpy(), output_size,
                                        np.float32(spatial_scale), sampling_ratio, pool_mode, aligned)
         ctx.save_for_backward(rois)
         ctx.cfg = (tuple(x.shape), output_size, spatial_scale, sampling_ratio, pool_mode, aligned)
-        return torch.from_numpy(out)
+        return torch.from_numpy(out).to(x.device)
 
     @staticmethod
     def backward(ctx, grad_out):
         (rois,) = ctx.saved_tensors
         shape, output_size, spatial_scale, sampling_ratio, pool_mode, aligned = ctx.cfg
-        gin = roi_oracle.backward(grad_out.contiguous().float().numpy(), rois.detach().float().numpy(), shape,
+        gin = roi_oracle.backward(grad_out.contiguous().float().cpu().numpy(), rois.detach().float().cpu().numpy(), shape,
                                   output_size, np.float32(spatial_scale), sampling_ratio, pool_mode, aligned)
-        return torch.from_numpy(gin), None, None, None, None, None, None
+        return torch.from_numpy(gin).to(grad_out.device), None, None, None, None, None, None
 
 
 class RoIAlignOracle(nn.Module):
@@ -94,10 +96,10 @@ class RoIAlignOracle(nn.Module):
         if x.requires_grad:
             return _RoIAlignOracleFn.apply(x, rois, self.output_size, self.spatial_scale, self.sampling_ratio,
                                            self.pool_mode, self.aligned)
-        out, _, _ = roi_oracle.forward(x.detach().float().numpy(), rois.detach().float().numpy(),
+        out, _, _ = roi_oracle.forward(x.detach().float().cpu().numpy(), rois.detach().float().cpu().numpy(),
                                        self.output_size, np.float32(self.spatial_scale), self.sampling_ratio,
                                        self.pool_mode, self.aligned)
-        return torch.from_numpy(out)
+        return torch.from_numpy(out).to(x.device)
 
 
 class BaseRoIExtractorOracle(nn.Module):
@@ -135,7 +137,7 @@ class MLVLFuseOracle(nn.Module):
     def forward(self, inputs, emulate=False):
         xs = []
         for lvl, feat in enumerate(inputs):
-            feat = torch.cat([feat, _r(self.coords(feat.shape), emulate)], 1)
+            feat = torch.cat([feat, _r(self.coords(feat.shape).to(feat.device), emulate)], 1)
             conv = self.input_conv[lvl]
             y = F.conv2d(_r(feat, emulate), _r(conv.weight, emulate), _r(conv.bias, emulate))
             xs.append(_r(y, emulate))

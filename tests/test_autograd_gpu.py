@@ -177,3 +177,59 @@ def test_malformed_training_batch_raises_like_the_reference():
     assert abs(float(out.loss.detach()) - float(plain.detach())) > 0                   # three keys fewer for every later row of sample 0
     out.loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in a.spi_module.parameters() if p.requires_grad)
+
+
+def test_stage2_training_through_autograd_equals_full_trainer():
+    """stage 2 (train_stage2.sh: everything but the vision tower trains) through the REFERENCE's caller
+    (gpt4roi/train/train.py:698-712, HF Trainer.training_step): `enable_decoder_training()` exposes the LLaMA weights as fp32
+    nn.Parameters, then it is model.train(); loss = model(**batch).loss; loss.backward(); clip_grad_norm_;
+    torch.optim.AdamW(model.parameters()).step() -- step for step against train.FullTrainer on an identical second model:
+    same loss every step, same weights after three steps.  And the stage-1 freeze loop of train.py:685-697 switches the
+    decoder off again by parameter NAME."""
+    from gpt4roi_amd.train import FullTrainer
+    lr = 5e-5
+    a, ids, prompt, img, boxes, labels = _mini(seed=4)
+    b, *_ = _mini(seed=4)
+    b.mm_projector.load_state_dict(a.mm_projector.state_dict())
+    lm = SPILlavaMPTForCausalLM(a)
+    lm.enable_decoder_training()
+    names = [n for n, _ in lm.named_parameters()]
+    assert any(n.startswith("model.llama_master.layers.0.wqkv") for n in names) and "model.llama_master.lm_head" in names
+    assert all(p.requires_grad and p.dtype == torch.float32 for n, p in lm.named_parameters() if "llama_master" in n)
+    params = [p for p in lm.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    tr = FullTrainer(b, lr=lr, max_grad_norm=1.0)
+    lm.train()
+    la, lb = [], []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        out = lm(input_ids=prompt, labels=labels, images=img, bboxes=boxes)
+        out.loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        la.append(out.loss.item())
+        lb.append(tr.step(prompt, img, boxes, labels).item())
+    print("losses through autograd:", la, "FullTrainer:", lb)
+    for x, y in zip(la, lb):
+        assert abs(x - y) < 2e-3 * abs(y), (la, lb)                # (atomics order in a few backward kernels)
+    assert la[-1] < la[0]
+    a._maybe_prepare()                                              # kernel tensors <- the masters the last step moved
+    wa, wb = a.llama.export_hf_state_dict(), b.llama.export_hf_state_dict()
+    for k in wa:
+        d = (wa[k].float() - wb[k].float()).abs().max().item()
+        assert d <= 2 ** -7 * wb[k].float().abs().max().item() + 1e-6, (k, d)
+    for (k, pa), (_, pb) in zip(a.spi_module.named_parameters(), b.spi_module.named_parameters()):
+        d = (pa - pb).abs()
+        assert d.max().item() <= 2 * 3 * lr and d.mean().item() <= 0.05 * 3 * lr, k
+    # state_dict() (what safe_save_model_for_hf_trainer writes) carries the stepped weights under the reference's names
+    sd = lm.state_dict()
+    assert torch.equal(sd["model.layers.0.self_attn.o_proj.weight"], wa["model.layers.0.self_attn.o_proj.weight"])
+    # stage 1 on the same model: the reference's freeze loop, by name
+    for n, p in lm.named_parameters():
+        p.requires_grad = "spi_module" in n
+    lm.zero_grad(set_to_none=True)
+    lm(input_ids=prompt, labels=labels, images=img, bboxes=boxes).loss.backward()
+    assert all(p.grad is None for n, p in lm.named_parameters() if "llama_master" in n or "mm_projector" in n)
+    assert all(p.grad is not None for n, p in lm.named_parameters() if "spi_module" in n)
+    assert a.llama.train_weights is False

@@ -1,6 +1,6 @@
 """CPU: the tile / split dispatch of the production shapes (pure host logic in gpt4roi_amd/kernels.py).  Every decision below
 was taken from an A/B measurement on MI355X (profiles/r02_gemm_tiles.md, r02_gemm_small_m.txt, r02_conv_k_order.jsonl,
-DESIGN.md section 3); this test pins them so that a heuristic edit for one shape cannot silently move another."""
+r05_w4k64_epilogue.txt: tile 34 replaces the ring ping-pong tile 24 on the 256 x 256 shapes); this test pins them so that a heuristic edit for one shape cannot silently move another."""
 import pytest
 
 from gpt4roi_amd import kernels as K
@@ -13,9 +13,9 @@ from gpt4roi_amd import kernels as K
     (767, 4096, 4096, 7, None),        # o_proj: 128x128 x 8 waves, ring of 4
     (767, 256, 4096, 14, None),        # the gate|up remainder: 64x64 ring-4 (+ 2 K slices in gemm())
     (577, 3072, 1024, 14, None), (577, 1024, 1024, 14, None), (577, 4096, 1024, 13, None), (577, 1024, 4096, 14, None),  # ViT, batch 1
-    (4616, 3072, 1024, 24, None), (4616, 1024, 4096, 0, None),                                                           # ViT, batch 8
-    (12272, 12288, 4096, 24, None), (12272, 4096, 4096, 24, None), (12272, 22016, 4096, 24, 21760), (12272, 4096, 11008, 24, None),   # 16 merged requests (bench default): 192 x 256 ring tiles in whole waves
-    (9232, 3072, 1024, 24, None), (9232, 4096, 1024, 0, None), (9232, 1024, 4096, 28, None),                                          # ViT, batch 16
+    (4616, 3072, 1024, 34, None), (4616, 1024, 4096, 0, None),                                                           # ViT, batch 8
+    (12272, 12288, 4096, 34, None), (12272, 4096, 4096, 34, None), (12272, 22016, 4096, 34, 21760), (12272, 4096, 11008, 34, None),   # 16 merged requests (bench default): the one-wave-per-SIMD 256 x 256 tile (round 5) in whole waves
+    (9232, 3072, 1024, 34, None), (9232, 4096, 1024, 0, None), (9232, 1024, 4096, 34, None),                                          # ViT, batch 16
     (8, 12288, 4096, 14, None), (8, 4096, 4096, 14, None), (8, 22016, 4096, 13, None), (16, 4096, 11008, 14, None),      # batched decode
 ])
 def test_gemm_tile_dispatch(M, N, Kd, tile, main):
@@ -24,7 +24,7 @@ def test_gemm_tile_dispatch(M, N, Kd, tile, main):
 
 
 @pytest.mark.parametrize("M,N,Kd,want", [
-    (5592, 1280, 11008, (24, 2)), (5592, 1280, 22016, (24, 2)), (5592, 1280, 12288, (24, 2)),   # training-batch column remainders
+    (5592, 1280, 11008, (34, 2)), (5592, 1280, 22016, (34, 2)), (5592, 1280, 12288, (34, 2)),   # training-batch column remainders
     (5592, 1280, 4096, None),          # K = 4096: the two-stage tile is as fast
     (767, 4096, 11008, None),          # down_proj at batch 1: long_k_plan's shape (48 tiles), not this one
     (767, 10246, 4096, None),          # lm_head remainder
@@ -35,7 +35,7 @@ def test_partial_wave_plan(M, N, Kd, want):
 
 
 @pytest.mark.parametrize("M,Cout,Kd,want", [
-    (36864, 1024, 9216, (24, 1)),      # a 192^2 level on its own (the fuse rounds use conv3x3_mlvl: one launch for all levels)
+    (36864, 1024, 9216, (34, 1)),      # a 192^2 level on its own (the fuse rounds use conv3x3_mlvl: one launch for all levels)
     (2304, 1024, 9216, (4, 1)),
     (6272, 1024, 36864, (24, 2)),      # pconv, 32 RoIs: 100 tiles x 2 K slices on the ring kernel
     (15288, 1024, 36864, (24, 1)),     # pconv, training batch (78 RoIs)

@@ -156,3 +156,72 @@ def test_full_shard_two_ranks_matches_unsharded():
         assert (fin0[n].float() - w.float()).abs().max().item() <= tol + 1e-7, n
     own, unsharded, transient = mem0
     assert abs(own - unsharded / 2) <= 64 and transient > 0        # half the persistent state per rank (+ padding)
+
+
+def _one_step(mgr, live, shapes, rank, step):
+    mgr.begin_step()
+    mgr.direction(+1)
+    for ui in range(3):
+        mgr.use(ui)
+        mgr.release(ui)
+    mgr.direction(-1)
+    for ui in reversed(range(3)):
+        mgr.use(ui)
+        for n in reversed(mgr.units[ui]["names"]):
+            mgr.grad_ready(n, _grad(n, shapes[n], rank, step))
+        mgr.release(ui)
+    return float(mgr.step(LR, CLIP))
+
+
+def _resume_worker(rank, world, port, q):
+    """two steps -> shard_state() -> a FRESH manager (built from the INITIAL tensors) -> load_shard_state() -> two more steps,
+    against four uninterrupted steps: identical slices on every rank (the sharded trainer must resume)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import copy
+        shapes = {n: tuple(t.shape) for u in _units() for n, t in u}
+
+        def make():
+            live = {}
+            return FullShardManager(_units(), lambda n, t: live.__setitem__(n, t), betas=BETAS, eps=EPS, prefetch=1,
+                                    update_fn=torch_update), live
+        a, live_a = make()
+        for step in range(2):
+            _one_step(a, live_a, shapes, rank, step)
+        sd = copy.deepcopy(a.shard_state())
+        steps_at_save = a.steps
+        for step in range(2, 4):
+            _one_step(a, live_a, shapes, rank, step)
+        b, live_b = make()
+        b.load_shard_state(sd)
+        b.steps = steps_at_save
+        for step in range(2, 4):
+            _one_step(b, live_b, shapes, rank, step)
+        same = all(torch.equal(fa.param_shard, fb.param_shard) and torch.equal(fa.master, fb.master)
+                   and torch.equal(fa.exp_avg, fb.exp_avg) and torch.equal(fa.exp_avg_sq, fb.exp_avg_sq)
+                   for ua, ub in zip(a.units, b.units) for fa, fb in zip(ua["flats"], ub["flats"]))
+        wrong_layout = False
+        try:
+            b.load_shard_state(dict(sd, rank=1 - rank))
+        except AssertionError:
+            wrong_layout = True
+        q.put(_mp.plain((rank, same, wrong_layout, sd["world"], len(sd["units"]))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_full_shard_state_saves_and_resumes_on_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_resume_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((_mp.tensors(q.get(timeout=120)) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, same, wrong_layout, world, n_units in res:
+        assert same, f"rank {rank}: the resumed run left the uninterrupted one"
+        assert wrong_layout and world == 2 and n_units == 3

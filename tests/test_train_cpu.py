@@ -42,8 +42,8 @@ def test_cosine_schedule_matches_hf_trainer():
 def test_tile_planners():
     from gpt4roi_amd import kernels as K
     # the ring ping-pong tile only where whole waves of 256x256 tiles come out; never for skinny or short-K problems
-    assert K.pick_tile(767, 12288, 4096) == 28 and K.pick_tile(4096, 4096, 4096) == 24   # ring ping-pong: 192- / 256-row tiles
-    assert K.pick_tile(767, 22016, 4096) != 24 and K.pick_tile(577, 4096, 1024) != 24 and K.pick_tile(1, 4096, 4096) != 24
+    assert K.pick_tile(767, 12288, 4096) == 28 and K.pick_tile(4096, 4096, 4096) == K.BIG_TILE   # 192-row ring tile / the 256-row production tile
+    assert all(K.pick_tile(*shp) not in (24, 34) for shp in [(767, 22016, 4096), (577, 4096, 1024), (1, 4096, 4096)])
     assert K.wave_split(767, 22016, 4096) == 85 * 256      # 3 x 85 = 255 tiles = one wave; tail of 256 columns
     assert K.wave_split(767, 32006, 4096) == 85 * 256
     assert K.wave_split(767, 12288, 4096) is None          # fewer than one wave: no main part
@@ -54,7 +54,7 @@ def test_tile_planners():
             assert 0 < n < N and n % 256 == 0 and (-(-M // 256) * (n // 256)) % 256 <= -(-M // 256) * 256 - 1
             assert (-(-M // 256) * (n // 256)) <= (-(-M // 256) * -(-N // 256))
     tile, splits = K.pick_conv_tile(192 * 192, 1024, 9216)
-    assert (tile, splits) == (24, 1)
+    assert (tile, splits) == (K.BIG_TILE, 1)
     tile, splits = K.pick_conv_tile(24 * 24, 1024, 9216)
     assert tile == 4 and splits > 1
 
