@@ -68,6 +68,12 @@ def parse():
                          "region module + projector trainable, gradient exchange over RCCL when N > 1); 0 = skip")
     ap.add_argument("--train-batch", type=int, default=8)
     ap.add_argument("--decode-batch", type=int, default=8, help="extra: batched greedy decode of this many sequences (<= 1 skips it)")
+    ap.add_argument("--mixed-tokens", type=int, default=512,
+                    help="extra: SURVEY.md 8d config 5 on one GPU (224^2 crop, 64 RoIs, --decode-batch requests together): greedy "
+                         "tokens generated per request after the prefill; 0 = skip")
+    ap.add_argument("--stage2-steps", type=int, default=2,
+                    help="extra: timed stage-2 training steps (SURVEY.md 8d config 4 per GPU: LLaMA-7B unfrozen, fp32 masters + "
+                         "fused AdamW, --train-batch images); N = 1 only; 0 = skip")
     ap.add_argument("--decode-tokens", type=int, default=32,
                     help="extra (not part of `value`): greedy KV-cache decode steps timed after the prefill")
     return ap.parse_args()
@@ -306,6 +312,38 @@ def train_leg(args, model, ids, device, rank, world, dist, agg_device):
     return out
 
 
+def stage2_leg(args, model, ids, device):
+    """Stage-2 step (train_stage2.sh / SURVEY.md 8d config 4, the per-GPU part): everything but the vision tower trains --
+    forward + hand-written backward of every stage incl. all LLaMA weight gradients + clip + fused AdamW on fp32 masters.
+    One rank (the exchange of the 6.7 B gradients is covered by the gloo tests and needs the 8-GPU node)."""
+    from gpt4roi_amd import synthetic as syn
+    from gpt4roi_amd.train import FullTrainer
+    B, P = args.train_batch, args.image_size // 14
+    g = torch.Generator().manual_seed(6000)
+    n_i = torch.randint(1, 16, (B,), generator=g).tolist()
+    images = torch.randn(B, 3, args.image_size, args.image_size, generator=g).to(device)
+    boxes = [syn.boxes(n, g).to(device) for n in n_i]
+    prompt = torch.stack([syn.prompt_ids(ids, P, n, g, question_len=20 + 4 * (15 - n)) for n in n_i]).to(device)
+    labels = prompt.clone()
+    labels[:, :42 + P * P] = -100
+    labels[labels >= 32000] = -100
+    torch.cuda.reset_peak_memory_stats(device)
+    torch.cuda.empty_cache()
+    tr = FullTrainer(model, lr=2e-5)
+    losses = [tr.step(prompt, images, boxes, labels).item() for _ in range(2)]      # warm-up: allocations, plans, the allocator's pools
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.stage2_steps):
+        losses.append(tr.step(prompt, images, boxes, labels).item())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.stage2_steps
+    return {"what": "stage-2 step (SURVEY.md 8d config 4, one GPU's share): forward + backward with every LLaMA-7B weight gradient "
+                    "+ clip + fused AdamW on fp32 masters", "batch_per_gpu": B, "tokens_per_sequence": int(prompt.size(1)),
+            "steps": args.stage2_steps, "ms_per_step": round(1e3 * dt, 2), "images_per_s": round(B / dt, 2),
+            "tokens_per_s": round(B * prompt.size(1) / dt, 1), "peak_mem_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
+            "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)]}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks through torch.distributed.run (one
     process per GPU, rendezvous on 127.0.0.1) and return their exit code.  The reference's launch line is the same launcher:
@@ -471,13 +509,19 @@ def main():
                       "roi_align_mlvl_nhwc": "void roi_align_mlvl_nhwc_kernel<unsigned short, true>"}
 
         def pmc_rec(tag):
+            """launch-weighted mean over every counter-pass row of the tag's kernel symbol family (the epilogue modes of the
+            one-wave-per-SIMD kernel are template instances of one symbol)"""
             pre = PMC_PREFIX.get(tag)
-            if not pre:
+            rows = [v for k, v in pmc.items() if pre and k.startswith(pre)]
+            if not rows:
                 return {}
-            for k, v in pmc.items():
-                if k.startswith(pre):
-                    return v
-            return {}
+            n = sum(r.get("launches", 1) for r in rows)
+            out = {"launches": n, "symbols": len(rows)}
+            for key in ("avg_us", "clock_GHz", "mfma_util", "hbm_read_bytes", "hbm_write_bytes"):
+                if all(r.get(key) is not None for r in rows):
+                    val = sum(r[key] * r.get("launches", 1) for r in rows) / n
+                    out[key] = int(val) if key.endswith("bytes") else round(val, 4)
+            return out
         rec = pmc_rec(dom)
         if "hbm_read_bytes" in rec:
             roofline["traffic"] = rec["hbm_read_bytes"] + rec.get("hbm_write_bytes", 0)
@@ -595,6 +639,41 @@ def main():
             del i1, b1, p1, i2, b2, p2
         except Exception as ex:
             extras["error"] = repr(ex)
+        if args.mixed_tokens > 0:
+            # (d) SURVEY.md 8d config 5 on ONE GPU: multi-region VCR-shape requests (224^2 crop, 64 RoIs), B of them served
+            # together: batched vision + region module + prefill, then `mixed_tokens` greedy tokens each, one hipGraph replay per
+            # decode step for the whole batch (tools/mixed_bench.py is the stand-alone form)
+            try:
+                from types import SimpleNamespace as _NS
+                Bm, n_new = max(1, args.decode_batch), args.mixed_tokens
+                a5 = _NS(**{**vars(args), "rois": 64})
+                i5, b5, p5 = make_inputs(a5, ids, device, seed=9002, batch=Bm, image_size=224)
+                boxes5 = model.prepare_boxes(b5, 224)
+
+                def request(n):
+                    emb5 = model.embed_inputs(p5, i5, boxes5)
+                    return model.llama.decode_graph_batch(emb5, n)
+                request(8)                                          # warm-up + decode-graph capture
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                request(2)
+                torch.cuda.synchronize()
+                t_pre = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                outs5 = request(n_new)
+                torch.cuda.synchronize()
+                t_full = time.perf_counter() - t0
+                extras["mixed_prefill_decode"] = {
+                    "what": f"SURVEY.md 8d config 5 on one GPU: {Bm} requests of a 224^2 crop + 64 RoIs served together, prompt "
+                            f"{int(p5.size(1))} tokens + {n_new} greedy tokens each (vision + region module + prefill, then one "
+                            "hipGraph replay per decode step for the batch)",
+                    "batch": Bm, "prefill_ms": round(1e3 * t_pre, 2), "batch_ms": round(1e3 * t_full, 2),
+                    "decode_ms_per_step": round(1e3 * (t_full - t_pre) / max(1, n_new - 2), 3),
+                    "generated_tokens_per_s": round(Bm * n_new / t_full, 1), "region_tokens_per_s": round(Bm * 64 / t_full, 1),
+                    "requests_per_s": round(Bm / t_full, 3), "tokens_out": [len(o) for o in outs5][:2]}
+                del i5, b5, p5, boxes5, outs5
+            except Exception as ex:
+                extras["mixed_prefill_decode"] = {"error": repr(ex)}
     train = None
     n_ctx, graph_ok = len(ctxs), all(g is not None for g in graphs)
     # the OTHER storage type of the same configuration (extras) and the training leg.  The reference trains in bf16
@@ -610,12 +689,18 @@ def main():
     last["graph_error"] = graph_error
     torch.cuda.empty_cache()
     m_train = model if args.dtype == "bf16" else None
+    want_stage2 = want_other_leg and args.stage2_steps > 0
     if want_train and m_train is not None:
         try:
             train = train_leg(args, m_train, ids, device, rank, world, dist, device if backend == "nccl" else "cpu")
         except Exception as ex:                                      # never lose the headline: every rank carries on to the
             train = {"error": repr(ex)}                              # end and exits 0 (no collective follows this leg); a
             #                                                          rank left waiting in one gets the group's timeout here
+        if want_stage2:
+            try:
+                extras["stage2_step"] = stage2_leg(args, m_train, ids, device)
+            except Exception as ex:
+                extras["stage2_step"] = {"error": repr(ex)}
     if want_other_leg or (want_train and m_train is None):
         try:
             del model, m_train
@@ -641,6 +726,11 @@ def main():
                 train = train_leg(args, m2, ids2, device, rank, world, dist, device if backend == "nccl" else "cpu")
             except Exception as ex:
                 train = {"error": repr(ex)}
+        if want_stage2 and other_name == "bf16" and m2 is not None:
+            try:
+                extras["stage2_step"] = stage2_leg(args, m2, ids2, device)
+            except Exception as ex:
+                extras["stage2_step"] = {"error": repr(ex)}
         m2 = None
         torch.cuda.empty_cache()
     cpu = None

@@ -252,11 +252,14 @@ def pick_tile(M, N, K=0):
     t256 = -(-M // 256) * -(-N // 256)
     if K >= 1024 and K % 64 == 0 and (-(-M // 256) * 256) <= 1.1 * M:     # K = 1024: ViT at batch 8 (4616x3072x1024: 715 vs 552 TF/s)
         eff = t256 / (-(-t256 // 256) * 256)
-        if (t256 <= 256 and eff >= 0.55) or eff >= 0.85:
+        # (round 5, profiles/r05_vit_gemm_sweep.txt: the one-wave-per-SIMD tile also wins at 0.77 of its last wave -- ViT fc1 at
+        #  batch 16, 9232 x 4096 x 1024: 108 us vs 122-128 on the 128 x 128 tile; at 0.59 -- batch 8 -- they are equal)
+        if (t256 <= 256 and eff >= 0.55) or eff >= (0.75 if BIG_TILE == 34 else 0.85):
             # one partial wave: 192-row tiles when they give more of the 256 CUs a (smaller) tile -- LLaMA fused qkv
             # 767x12288x4096: 4 x 48 = 192 workgroups of 0.75 the work, 101.6 vs 114.6 us (profiles/r02_gemm_tiles.md)
             t192 = -(-M // 192) * -(-N // 256)
-            if t256 <= 256 and eff < 0.75 and t256 < t192 <= 256 and (-(-M // 192) * 192) <= 1.1 * M:
+            # (round 5: the one-wave-per-SIMD tile beats the 192-row ring tile there too -- 82.6 vs 95.5 us, profiles/r05_m767_sweep.txt)
+            if BIG_TILE != 34 and t256 <= 256 and eff < 0.75 and t256 < t192 <= 256 and (-(-M // 192) * 192) <= 1.1 * M:
                 return 28
             return BIG_TILE
     t128 = -(-M // 128) * -(-N // 128)
@@ -290,8 +293,10 @@ def pick_conv_tile(M, Cout, K):
         # kernel so that tiles x slices stays within one wave of the 256 CUs.  (The one-wave-per-SIMD kernel wins the dense
         # proxy of this shape, 452 vs 492 us, but loses the real implicit conv -- 841 us: a lone wave per SIMD has nobody to
         # hide the per-piece halo / bounds arithmetic behind.)
+        # Round 5: the K-64 one-wave-per-SIMD kernel has no VALU address work left in its loop and wins the real pconv as well
+        # (32 RoIs x 2 slices 417 vs 459 us; 78 RoIs 887 vs 976; 512 RoIs 6154 vs 6887: profiles/r05_m767_sweep.txt).
         t256 = -(-M // 256) * -(-Cout // 256)
-        return 24, max(1, min(5, 256 // t256))
+        return BIG_TILE, max(1, min(5, 256 // t256))
     if M >= 8192:
         return BIG_TILE, 1
     blocks = -(-M // 64) * -(-Cout // 128)
@@ -321,7 +326,8 @@ def long_k_plan(M, N, K):
     """(tile_cfg, K slices) for the long-K / few-tiles shape of the LLaMA down_proj (767 x 4096 x 11008: 48 tiles of 256 x 256),
     or None: the 192 x 256 ring ping-pong tile x 4 K-slices = 64 x 4 = 256 workgroups."""
     if K >= 8192 and K % 64 == 0 and (-(-M // 256) * 256) <= 1.1 * M and 32 <= -(-M // 256) * -(-N // 256) <= 64:
-        return 28, 4
+        # round 5: 48 tiles of 256 x 256 x 4 K slices on the one-wave-per-SIMD tile 78.3 us vs 83.9 (profiles/r05_m767_sweep.txt)
+        return (34, 4) if BIG_TILE == 34 else (28, 4)
     return None
 
 

@@ -7,7 +7,7 @@ from gpt4roi_amd import kernels as K
 
 
 @pytest.mark.parametrize("M,N,Kd,tile,main", [
-    (767, 12288, 4096, 28, None),      # LLaMA fused qkv: ring ping-pong with 192-row tiles (4 x 48 = 192 workgroups)
+    (767, 12288, 4096, 34, None),      # LLaMA fused qkv: 144 one-wave-per-SIMD tiles (round 5: 82.6 us vs 95.5 on 192 x 256 ring tiles)
     (767, 22016, 4096, 0, 21760),      # gate|up: whole-wave column split, 255 tiles on the ring kernel + 256 columns
     (767, 32006, 4096, 0, 21760),      # lm_head
     (767, 4096, 4096, 7, None),        # o_proj: 128x128 x 8 waves, ring of 4
@@ -15,7 +15,7 @@ from gpt4roi_amd import kernels as K
     (577, 3072, 1024, 14, None), (577, 1024, 1024, 14, None), (577, 4096, 1024, 13, None), (577, 1024, 4096, 14, None),  # ViT, batch 1
     (4616, 3072, 1024, 34, None), (4616, 1024, 4096, 0, None),                                                           # ViT, batch 8
     (12272, 12288, 4096, 34, None), (12272, 4096, 4096, 34, None), (12272, 22016, 4096, 34, 21760), (12272, 4096, 11008, 34, None),   # 16 merged requests (bench default): the one-wave-per-SIMD 256 x 256 tile (round 5) in whole waves
-    (9232, 3072, 1024, 34, None), (9232, 4096, 1024, 0, None), (9232, 1024, 4096, 34, None),                                          # ViT, batch 16
+    (9232, 3072, 1024, 34, None), (9232, 4096, 1024, 34, None), (9232, 1024, 4096, 34, None),                                          # ViT, batch 16
     (8, 12288, 4096, 14, None), (8, 4096, 4096, 14, None), (8, 22016, 4096, 13, None), (16, 4096, 11008, 14, None),      # batched decode
 ])
 def test_gemm_tile_dispatch(M, N, Kd, tile, main):
@@ -37,8 +37,8 @@ def test_partial_wave_plan(M, N, Kd, want):
 @pytest.mark.parametrize("M,Cout,Kd,want", [
     (36864, 1024, 9216, (34, 1)),      # a 192^2 level on its own (the fuse rounds use conv3x3_mlvl: one launch for all levels)
     (2304, 1024, 9216, (4, 1)),
-    (6272, 1024, 36864, (24, 2)),      # pconv, 32 RoIs: 100 tiles x 2 K slices on the ring kernel
-    (15288, 1024, 36864, (24, 1)),     # pconv, training batch (78 RoIs)
+    (6272, 1024, 36864, (34, 2)),      # pconv, 32 RoIs: 100 tiles x 2 K slices
+    (15288, 1024, 36864, (34, 1)),     # pconv, training batch (78 RoIs)
 ])
 def test_conv_tile_dispatch(M, Cout, Kd, want):
     assert K.pick_conv_tile(M, Cout, Kd) == want

@@ -42,7 +42,7 @@ def test_cosine_schedule_matches_hf_trainer():
 def test_tile_planners():
     from gpt4roi_amd import kernels as K
     # the ring ping-pong tile only where whole waves of 256x256 tiles come out; never for skinny or short-K problems
-    assert K.pick_tile(767, 12288, 4096) == 28 and K.pick_tile(4096, 4096, 4096) == K.BIG_TILE   # 192-row ring tile / the 256-row production tile
+    assert K.pick_tile(767, 12288, 4096) == K.BIG_TILE and K.pick_tile(4096, 4096, 4096) == K.BIG_TILE   # the 256-row production tile
     assert all(K.pick_tile(*shp) not in (24, 34) for shp in [(767, 22016, 4096), (577, 4096, 1024), (1, 4096, 4096)])
     assert K.wave_split(767, 22016, 4096) == 85 * 256      # 3 x 85 = 255 tiles = one wave; tail of 256 columns
     assert K.wave_split(767, 32006, 4096) == 85 * 256
