@@ -2852,8 +2852,12 @@ int g4r_conv3x3_mlvl_nhwc_bf16(const void* X, const void* W, void* Y, const floa
   p.lda = Cin; p.ldw = p.K; p.ldc = Cout;
   p.act = act; p.H = level_h[0]; p.Wd = level_w[0]; p.Cin = Cin; p.groups = 1;
   p.n_fastest = 1; p.dbg = g_gemm_dbg; p.splits = 1;
-  if (g_gemm_dbg == 41) p.group_m = -2;     // tools: an XCD's wave = 16 pixel tiles x 2 weight panels (instead of 8 x 4)
-  if (g_gemm_dbg == 42) p.group_m = -1;     // tools: 32 pixel tiles x 1 weight panel
+  // tile order: an XCD's wave of 32 workgroups = 16 pixel tiles x 2 weight panels (round 5, tools/order_ab.py: 1356-1360 vs
+  // 1321-1345 TF/s for the N-fastest 8 x 4 order on the one-wave-per-SIMD kernel; half the weight-panel bytes per wave).
+  // tools: debug mode 40 = the 8 x 4 order, 42 = 32 pixel tiles x 1 weight panel
+  p.group_m = -2;
+  if (g_gemm_dbg == 40 || g_gemm_dbg == 60) p.group_m = 0;
+  if (g_gemm_dbg == 42) p.group_m = -1;
   // round 5: the one-wave-per-SIMD K 64 kernel (1383-1393 vs 1286-1292 TF/s, profiles/r05_w4k64_epilogue.txt); debug mode 60 = the
   // ring ping-pong kernel (tools: A/B arm), also the fallback for maps of 2 GiB and more
   if (g_gemm_dbg != 60 && (size_t)rows * Cin * 2 < 0x7fffffffu) return launch_w4k64<2>(p, (hipStream_t)stream);
