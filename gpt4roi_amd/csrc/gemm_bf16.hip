@@ -53,6 +53,7 @@ struct GemmArgs {
   int dbg;  // ablation probe (tools only): 1 = skip the loads after the first tile, 2 = skip the MFMAs
   unsigned a_bytes, w_bytes;   // extent of the A / W operands in bytes when < 2 GiB (buffer descriptors), else 0
   int defer_reduce;            // split-K: leave the fp32 partials in ws, the CALLER's next kernel combines them
+  int stagger_ticks;           // one-wave-per-SIMD kernel: start offset step of the first 256 workgroups in 10 ns ticks (0 = none)
   // act == 5 (fused q|k|v projection of a LLaMA layer, ring ping-pong tiles only): RoPE and the KV-cache append happen in
   // the epilogue -- what g4r_rope_qkv_bf16 did in a launch of its own.  Columns [0, HD) -> rotated q rows of rope_q,
   // [HD, 2 HD) -> rotated k into the cache rows pos0 + t, [2 HD, 3 HD) -> v into the cache.  Row m = b * rope_T + t.
@@ -1943,6 +1944,7 @@ int launch_w4(GemmArgs& p, hipStream_t stream) {
 // A wave whose 128 columns are not all inside N, or whose tile crosses row M, takes the guarded forms.
 // ---------------------------------------------------------------------------------------------
 enum { W4_GENERIC = 0, W4_P16 = 1, W4_SWIGLU = 2, W4_ROPE = 3, W4_WIDE = 4 };
+#define G4R_W4_STAGGER_TICKS 0     // default start de-phasing step (10 ns ticks); see gemm_bf16_w4k64_kernel
 struct W4Epi {
   static constexpr int RS16 = 256 + 16;         // 128 x 16-bit row + 16 B (rows stay 16-byte aligned for the b128 read-back)
   static constexpr int RSW = 128 + 16;          // SwiGLU: 64 x 16-bit outputs per row
@@ -2203,8 +2205,21 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64_kernel(GemmArgs p) {
   // PROBE (tools/wg_timeline.py, tile 35): wave 0 of every workgroup records entry / loop begin / loop end / exit (s_memtime),
   // its XCC id and the 100 MHz wall clock at ws + 16 + 8 * blockIdx.x (int64) -- the convention of the ring kernel's probe
   long long* wg_stamps = reinterpret_cast<long long*>(p.ws) + 16 + 8 * (long)blockIdx.x;
-  const bool wg_probe = PROBE && blockIdx.y == 0 && wave == 0 && lane == 0;
+  const bool wg_probe = PROBE && blockIdx.y == 0 && wave == 0;       // (wave-uniform: all 64 lanes store the same stamp)
   if (PROBE) { if (wg_probe) { wg_stamps[0] = __builtin_amdgcn_s_memtime(); wg_stamps[4] = __builtin_amdgcn_s_getreg(6164); wg_stamps[5] = wall_clock64(); } }
+
+  // De-phasing (round 5): every workgroup of a launch runs the same number of K tiles, so all 256 CUs reach their epilogue at
+  // the same moment and the 32 MB of a wave's outputs hit the memory system as ONE burst while every matrix pipe idles.  The
+  // first 256 workgroups (one per CU) start `phase x stagger_ticks x 10 ns` late, phase = 0..7 by CU slot inside the XCD; later
+  // workgroups inherit the phase of the CU they land on, so at any moment only ~1/8 of the CUs are storing.
+  if (p.stagger_ticks > 0) {
+    const int lin = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    const int phase = (lin >> 3) & 7;
+    if (lin < 256 && phase != 0) {
+      const long long t_go = wall_clock64() + (long long)phase * p.stagger_ticks;
+      while (wall_clock64() < t_go) __builtin_amdgcn_s_sleep(8);
+    }
+  }
 
   // piece j of this wave covers rows 8 * (4 j + wave) + lane / 8; lane % 8 is the 16-byte slot it writes
   int a_voff[NP], b_voff[NP];
@@ -2457,6 +2472,11 @@ int launch_w4k64(GemmArgs& p, hipStream_t stream) {
   }
   p.tiles_m = g4r_ceil_div(p.M, 256);
   p.tiles_n = g4r_ceil_div(p.N, 256);
+  // start de-phasing of launches of several waves of tiles (tools: debug modes 70 + n = n x 0.25 us per phase, 79 = off)
+  p.stagger_ticks = 0;
+  if ((long)p.tiles_m * p.tiles_n * p.splits > 2 * 256) p.stagger_ticks = G4R_W4_STAGGER_TICKS;
+  if (g_gemm_dbg >= 70 && g_gemm_dbg < 79) p.stagger_ticks = (g_gemm_dbg - 70) * 25;
+  if (g_gemm_dbg == 79) p.stagger_ticks = 0;
   // the epilogue mode (W4Epi): the straight-line forms need 16-byte rows on every operand they touch
   const bool wide = p.splits > 1 || p.out_f32 || p.residual != nullptr;
   int mode = W4_GENERIC;
