@@ -67,6 +67,8 @@ def parse():
                     help="extra (not part of `value`): timed stage-1 training steps (SURVEY.md 8d config 3: batch 8 per GPU, "
                          "region module + projector trainable, gradient exchange over RCCL when N > 1); 0 = skip")
     ap.add_argument("--train-batch", type=int, default=8)
+    ap.add_argument("--train-deadline", type=float, default=300.0,
+                    help="N > 1 only: seconds the training leg (with its gradient exchange) may take before the line is printed without it")
     ap.add_argument("--decode-batch", type=int, default=8, help="extra: batched greedy decode of this many sequences (<= 1 skips it)")
     ap.add_argument("--mixed-tokens", type=int, default=512,
                     help="extra: SURVEY.md 8d config 5 on one GPU (224^2 crop, 64 RoIs, --decode-batch requests together): greedy "
@@ -342,6 +344,35 @@ def stage2_leg(args, model, ids, device):
             "steps": args.stage2_steps, "ms_per_step": round(1e3 * dt, 2), "images_per_s": round(B / dt, 2),
             "tokens_per_s": round(B * prompt.size(1) / dt, 1), "peak_mem_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
             "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)]}
+
+
+class _Deadline(Exception):
+    pass
+
+
+def with_deadline(fn, seconds, device_index):
+    """Run fn() on a worker thread and wait at most `seconds`: the multi-rank training leg's collectives (RCCL over xGMI) have
+    never run on more than one GPU here, and a rank stuck in one must not cost the run its headline line.  On a timeout the
+    caller reports the leg as an error and the process leaves through os._exit after the line is printed (a stuck collective
+    cannot be cancelled)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            torch.cuda.set_device(device_index)
+            torch.set_grad_enabled(False)           # (thread-local: the main thread switched it off for the whole run)
+            box["out"] = fn()
+        except Exception as ex:                     # noqa: BLE001
+            box["err"] = ex
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        raise _Deadline(f"still running after {seconds} s")
+    if "err" in box:
+        raise box["err"]
+    return box["out"]
 
 
 def self_launch(args):
@@ -675,6 +706,7 @@ def main():
             except Exception as ex:
                 extras["mixed_prefill_decode"] = {"error": repr(ex)}
     train = None
+    hard_exit = False                                    # a rank stuck in a collective of the training leg (see with_deadline)
     n_ctx, graph_ok = len(ctxs), all(g is not None for g in graphs)
     # the OTHER storage type of the same configuration (extras) and the training leg.  The reference trains in bf16
     # (train_stage1.sh:19) and serves in fp16 (app.py:74-98): with the fp16 headline the bf16 model built for the extras leg is
@@ -692,7 +724,10 @@ def main():
     want_stage2 = want_other_leg and args.stage2_steps > 0
     if want_train and m_train is not None:
         try:
-            train = train_leg(args, m_train, ids, device, rank, world, dist, device if backend == "nccl" else "cpu")
+            leg = lambda: train_leg(args, m_train, ids, device, rank, world, dist, device if backend == "nccl" else "cpu")   # noqa: E731
+            train = leg() if world == 1 else with_deadline(leg, args.train_deadline, local)
+        except _Deadline as ex:
+            train, hard_exit = {"error": f"training leg: {ex}"}, True
         except Exception as ex:                                      # never lose the headline: every rank carries on to the
             train = {"error": repr(ex)}                              # end and exits 0 (no collective follows this leg); a
             #                                                          rank left waiting in one gets the group's timeout here
@@ -723,7 +758,10 @@ def main():
             try:
                 if m2 is None:
                     raise RuntimeError("the bf16 model of the training leg could not be built")
-                train = train_leg(args, m2, ids2, device, rank, world, dist, device if backend == "nccl" else "cpu")
+                leg = lambda: train_leg(args, m2, ids2, device, rank, world, dist, device if backend == "nccl" else "cpu")   # noqa: E731
+                train = leg() if world == 1 else with_deadline(leg, args.train_deadline, local)
+            except _Deadline as ex:
+                train, hard_exit = {"error": f"training leg: {ex}"}, True
             except Exception as ex:
                 train = {"error": repr(ex)}
         if want_stage2 and other_name == "bf16" and m2 is not None:
@@ -798,6 +836,9 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "train": train, "extras": extras, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
+    if hard_exit:
+        sys.stdout.flush()
+        os._exit(0)
     if dist is not None:
         dist.destroy_process_group()
 
