@@ -543,7 +543,7 @@ def main():
             """launch-weighted mean over every counter-pass row of the tag's kernel symbol family (the epilogue modes of the
             one-wave-per-SIMD kernel are template instances of one symbol)"""
             pre = PMC_PREFIX.get(tag)
-            rows = [v for k, v in pmc.items() if pre and k.startswith(pre)]
+            rows = [v for k, v in pmc.items() if pre and k.startswith(pre) and k != "_meta"]
             if not rows:
                 return {}
             n = sum(r.get("launches", 1) for r in rows)
@@ -554,6 +554,19 @@ def main():
                     out[key] = int(val) if key.endswith("bytes") else round(val, 4)
             return out
         rec = pmc_rec(dom)
+        # do the committed counters belong to THIS tree's kernels?  (sha of gpt4roi_amd/csrc at collection time, tools/pmc_report.py)
+        try:
+            import hashlib
+            h_ = hashlib.sha256()
+            cdir = os.path.join(ROOT, "gpt4roi_amd", "csrc")
+            for f_ in sorted(os.listdir(cdir)):
+                h_.update(open(os.path.join(cdir, f_), "rb").read())
+            want_sha = (pmc.get("_meta") or {}).get("kernel_sources_sha256_16")
+            roofline["pmc_counters_match_kernel_sources"] = (want_sha == h_.hexdigest()[:16]) if want_sha else None
+        except Exception:
+            roofline["pmc_counters_match_kernel_sources"] = None
+        if not rec and pmc:
+            roofline["pmc_error"] = f"no counter row for {dom!r} in {pmc_file}"
         if "hbm_read_bytes" in rec:
             roofline["traffic"] = rec["hbm_read_bytes"] + rec.get("hbm_write_bytes", 0)
             roofline["traffic_source"] = (f"{pmc_file} (PMC FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 per launch, "

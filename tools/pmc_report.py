@@ -55,8 +55,19 @@ def main():
             for k, a in load(dirs[idx + 1]).items():
                 rep.setdefault(k, {"launches": int(a["n"]), "avg_us": round(a["us"] / a["n"], 2)})[key] = int(a.get(cname, 0.0) / a["n"] * mul)
     rep = dict(sorted(rep.items(), key=lambda kv: -(kv[1].get("avg_us", 0) * kv[1].get("launches", 0))))
+    # which kernel sources these counters belong to: bench.py compares this with the tree it runs from and says so on its line
+    # (a stale file must not pass for a fresh measurement)
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    csrc = os.path.join(root, "gpt4roi_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    rep["_meta"] = {"kernel_sources_sha256_16": h.hexdigest()[:16], "launches": 0}
     json.dump(rep, open(out_path, "w"), indent=1)
     for k, v in list(rep.items())[:25]:
+        if k == "_meta":
+            continue
         print(f"{k[:60]:60s} n={v['launches']:5d} {v.get('avg_us', 0):9.1f}us clk={v.get('clock_GHz')} util={v.get('mfma_util')} "
               f"rd={v.get('hbm_read_bytes')} wr={v.get('hbm_write_bytes')}")
 
