@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 
 
 # the inference path (ViT, region module, projector, splice, LLaMA prefill + decode); training-only files stay bf16
-F16_SOURCES = ("gemm_bf16.hip", "attention.hip", "attention_v2.hip", "norm.hip", "elementwise.hip", "roi_align.hip")
+F16_SOURCES = ("gemm_bf16.hip", "gemv_mfma.hip", "attention.hip", "attention_v2.hip", "norm.hip", "elementwise.hip", "roi_align.hip")
 F16_NAMES = os.path.join(os.path.dirname(HERE), "include", "g4r_f16_names.h")
 
 

@@ -23,6 +23,7 @@ _SIGS = {
     "g4r_conv3x3_mlvl_nhwc_bf16": [P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P],
     "g4r_batch_advance": [P, c_int, P, P, P, P, P, c_int, P],
     "g4r_gemv_rmsnorm_bf16": [P, P, c_float, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "g4r_gemv_batch_bf16": [P, c_int, c_long, P, c_float, P, P, c_long, P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "g4r_attn_decode_bf16": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_long, c_long, c_float, c_int, P, c_int,
                              c_int, c_long, c_long, c_long, c_long, P],
     "g4r_attn_decode_ragged_bf16": [P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, c_int, P, P, c_int,
@@ -437,6 +438,10 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=None, spl
     assert out.dtype in (dt, torch.float32), f"gemm: out is {out.dtype}, operands are {dt}"     # (the epilogue writes dt or fp32 bits)
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
+    if tile_cfg is None and splits == 1 and workspace is None and gemv_batch_wins(M, N, K) and a.stride(0) % 8 == 0 \
+            and a.stride(0) >= K and w.stride(0) % 8 == 0 and (residual is None or residual.data_ptr() != out.data_ptr()):
+        # a handful of rows (the decode step of a batch of sequences): weight streaming with the products on the matrix pipe
+        return gemv_batch(a, w, bias=bias, residual=residual, act=act, out=out)
     thin_tail = False
     if tile_cfg is None and splits == 1 and M >= 1024 and pick_tile(M, N, K) == BIG_TILE and out.dtype != torch.float32:
         # several whole waves of 256 x 256 tiles plus a THIN last one (batch-4 gate|up 3068 x 22016: 1032 tiles = 4 waves + 8
@@ -512,6 +517,43 @@ def gemv(x, w, norm_weight=None, eps=1e-6, bias=None, residual=None, act=None, o
                                       w.stride(0), ACT[act], 1 if out.dtype == torch.float32 else 0, _stream(x),),
             tag="gemv_bf16", flops=2.0 * N * K, nbytes=2.0 * (K + N * K) + out.element_size() * n_out, dt=dt)
     return out
+
+
+GEMV_BATCH_MAX = 16
+
+
+def gemv_batch(x, w, norm_weight=None, eps=1e-6, bias=None, residual=None, act=None, out=None, out_dtype=None, variant=0):
+    """out[B, N] = act(w[N, K] . rmsnorm(x_b; norm_weight, eps) + bias) + residual_b for B = 2..16 rows x [B, K] sharing ONE pass
+    over the weights: the projections of a batched decode step (round 5, csrc/gemv_mfma.hip; `gemv` is the one-row form).
+    norm_weight None = no norm; the normalised rows are bit-identical to rmsnorm()'s."""
+    dt = _h16(x, w, residual)
+    _f32(bias, norm_weight)
+    assert x.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1 and x.size(1) == w.size(1)
+    B, K = x.shape
+    N = w.size(0)
+    assert 2 <= B <= GEMV_BATCH_MAX
+    n_out = N // 2 if act == "swiglu" else N
+    if out is None:
+        out = torch.empty((B, n_out), dtype=out_dtype or dt, device=x.device)
+    assert out.shape == (B, n_out) and out.stride(1) == 1 and out.dtype in (dt, torch.float32)
+    if residual is not None:
+        assert residual.shape == (B, N) and residual.stride(1) == 1 and residual.data_ptr() != out.data_ptr()
+    _launch("g4r_gemv_batch_bf16", (_p(x), B, x.stride(0), _p(norm_weight), float(eps), _p(w), _p(out), out.stride(0), _p(bias),
+                                    _p(residual), residual.stride(0) if residual is not None else 0, N, K, w.stride(0), ACT[act],
+                                    1 if out.dtype == torch.float32 else 0, int(variant), _stream(x),),
+            tag="gemv_batch", flops=2.0 * B * N * K, nbytes=2.0 * (B * K + N * K) + out.element_size() * B * n_out, dt=dt)
+    return out
+
+
+def gemv_batch_wins(M, N, K):
+    """Where gemm() hands a few-row problem to the weight-streaming MFMA kernel instead of the small-M GEMM tiles
+    (profiles/r05_gemv_batch.txt).  Launch by launch, weights out of cache, the kernel wins up to 8 rows on q|k|v, o_proj,
+    gate|up and lm_head (o_proj 12 vs 18 us) and loses on down_proj (K = 11008: two staging passes); INSIDE the batched decode
+    step (hipGraph replay, LLaMA-7B, 767-token prompts) it wins at 2-4 sequences (3.66 / 3.74 / 3.83 vs 3.91 / 4.00 / 4.02 ms per
+    step) and loses at 8 (4.51 vs 4.36) -- each of its N / 16 workgroups stages all the rows, which the tiles amortise over 64
+    output columns.  So: 2..4 rows, one staging pass, K <= 8192."""
+    return (2 <= M <= 4 and 512 <= K <= 8192 and K % 64 == 0 and M * (2 * K + 16) <= 98304
+            and os.environ.get("G4R_GEMV_BATCH", "1") != "0")
 
 
 def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=None, splits=1, tile_cfg=None,

@@ -17,6 +17,7 @@
 #define g4r_gemm_qkv_rope_bf16              g4r_gemm_qkv_rope_f16
 #define g4r_gemm_bf16_nt                    g4r_gemm_f16_nt
 #define g4r_gemv_rmsnorm_bf16               g4r_gemv_rmsnorm_f16
+#define g4r_gemv_batch_bf16                 g4r_gemv_batch_f16
 #define g4r_gemv_attn_merge_bf16            g4r_gemv_attn_merge_f16
 #define g4r_conv3x3_nhwc_bf16               g4r_conv3x3_nhwc_f16
 #define g4r_conv3x3_mlvl_nhwc_bf16          g4r_conv3x3_mlvl_nhwc_f16

@@ -87,6 +87,19 @@ int g4r_gemv_rmsnorm_bf16(const void* x, const float* gamma, float eps, const vo
                           const void* residual, int N, int K, int ldw, int act, int out_f32, void* stream);
 
 /*
+ * B = 2..16 activation rows through a projection (round 5, csrc/gemv_mfma.hip): the batched form of g4r_gemv_rmsnorm_bf16 --
+ * the decode step of several sequences sharing ONE pass over the weights, what HF `generate()` runs per token for a batch
+ * (gpt4roi/app.py:293-300 with a batched prompt).  C [B, N] = act(W [N, K] . h_b + bias) + residual_b with
+ * h_b as above (gamma null: h_b = x_b); x / C / residual rows are `ldx` / `ldc` / `ldr` elements apart; act 4 = SwiGLU over
+ * interleaved (gate, up) rows (C has N / 2 columns).  K >= 512, K % 64 == 0.  h_b is bit-identical to g4r_rmsnorm_bf16's output;
+ * the products run on the matrix pipe (v_mfma_f32_16x16x32, fp32 accumulation), the weights stream straight into its operand
+ * registers.  variant: 0 (tools: other wave counts / row blocks / LDS budgets, see csrc/gemv_mfma.hip).
+ */
+int g4r_gemv_batch_bf16(const void* x, int B, long ldx, const float* gamma, float eps, const void* W, void* C, long ldc,
+                        const float* bias, const void* residual, long ldr, int N, int K, int ldw, int act, int out_f32,
+                        int variant, void* stream);
+
+/*
  * Single-query attention over a KV cache: the per-token step of the decode loop the reference reaches through HF
  * `generate()` (gpt4roi/app.py:293-300 -> LlamaAttention with past_key_values).  Q/O [H*head_dim] bf16; K/V cache rows
  * `k_row`/`v_row` elements apart; the first Tk rows are attended, Tk = *kv_len_dev + 1 when kv_len_dev is given (read on

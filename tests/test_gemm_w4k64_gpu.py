@@ -137,3 +137,44 @@ def test_conv_over_all_levels_one_wave_per_simd_vs_ring_kernel():
     ref = torch.cat([F.conv2d(m.float().permute(0, 3, 1, 2), wc.to(torch.bfloat16).float(), padding=1).permute(0, 2, 3, 1).reshape(-1, 256)
                      for m in mm.levels])
     assert rel(got, ref) < TOL[torch.bfloat16] and rel(got, ring) < TOL[torch.bfloat16]
+
+
+# ------------------------------------------------------------------------------------------ batched decode projections (round 5)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,Kd", [(2, 1000, 512), (3, 4096, 4096), (8, 12288, 4096), (8, 4096, 11008), (16, 2050, 11008), (5, 32006, 4096),
+                                     (16, 4096, 4096)])
+def test_gemv_batch_rows_share_one_weight_stream(B, N, Kd, dtype):
+    """g4r_gemv_batch (csrc/gemv_mfma.hip): B = 2..16 activation rows, K staged in one pass or several (8 x 11008 and 16 x 4096 do not
+    fit the LDS budget), N not a multiple of 16, strided activations; every epilogue against fp32 torch.  What HF generate()
+    computes per token for a batch (LlamaRMSNorm + nn.Linear on [B, 1, K])."""
+    xw = rnd(B, Kd + 64, seed=30, dtype=dtype)
+    x = xw[:, :Kd]                                             # row stride Kd + 64
+    w = rnd(N, Kd, seed=31, scale=0.05, dtype=dtype)
+    bias = rnd(N, seed=32, dtype=torch.float32)
+    res = rnd(B, N, seed=33, dtype=dtype)
+    ref = x.float() @ w.float().t()
+    assert rel(K.gemv_batch(x, w), ref) < TOL[dtype]
+    assert rel(K.gemv_batch(x, w, bias=bias, residual=res, act="silu"), F.silu(ref + bias) + res.float()) < 2 * TOL[dtype]
+    f32 = K.gemv_batch(x, w, bias=bias, out_dtype=torch.float32)
+    assert f32.dtype == torch.float32 and rel(f32, ref + bias) < 2e-4
+    if K.gemv_batch_wins(B, N, Kd):                             # gemm() routes these shapes here
+        assert torch.equal(K.gemm(x, w, bias=bias, residual=res), K.gemv_batch(x, w, bias=bias, residual=res))
+    if N % 4 == 0:
+        sw = K.gemv_batch(x, w, act="swiglu")
+        assert sw.shape == (B, N // 2) and rel(sw, F.silu(ref[:, 0::2]) * ref[:, 1::2]) < 3 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B", [2, 7, 16])
+def test_gemv_batch_fused_rmsnorm_is_the_separate_launch(B, dtype):
+    """the RMSNorm in front of q|k|v / gate|up / lm_head fused into the staging: bit-identical to rmsnorm() followed by the
+    un-normed call (same element -> thread map, summation order and roundings as rmsnorm_bf16_kernel), one pass and two"""
+    x = rnd(B, 4096, seed=40, dtype=dtype)
+    gamma = 1 + 0.1 * rnd(4096, seed=41, dtype=torch.float32)
+    w = rnd(1536, 4096, seed=42, scale=0.05, dtype=dtype)
+    fused = K.gemv_batch(x, w, norm_weight=gamma, eps=1e-6)
+    assert torch.equal(fused, K.gemv_batch(K.rmsnorm(x, gamma, 1e-6), w))
+    h = x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6)
+    assert rel(fused, (h.to(dtype).float() * gamma).to(dtype).float() @ w.float().t()) < TOL[dtype]
+    sw = K.gemv_batch(x, w, norm_weight=gamma, eps=1e-6, act="swiglu")
+    assert torch.equal(sw, K.gemv_batch(K.rmsnorm(x, gamma, 1e-6), w, act="swiglu"))
