@@ -560,7 +560,8 @@ def main():
             h_ = hashlib.sha256()
             cdir = os.path.join(ROOT, "gpt4roi_amd", "csrc")
             for f_ in sorted(os.listdir(cdir)):
-                h_.update(open(os.path.join(cdir, f_), "rb").read())
+                if f_.endswith((".hip", ".h")):
+                    h_.update(open(os.path.join(cdir, f_), "rb").read())
             want_sha = (pmc.get("_meta") or {}).get("kernel_sources_sha256_16")
             roofline["pmc_counters_match_kernel_sources"] = (want_sha == h_.hexdigest()[:16]) if want_sha else None
         except Exception:

@@ -62,7 +62,8 @@ def main():
     h = hashlib.sha256()
     csrc = os.path.join(root, "gpt4roi_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        h.update(open(os.path.join(csrc, f), "rb").read())
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
     rep["_meta"] = {"kernel_sources_sha256_16": h.hexdigest()[:16], "launches": 0}
     json.dump(rep, open(out_path, "w"), indent=1)
     for k, v in list(rep.items())[:25]:
