@@ -360,7 +360,8 @@ def with_deadline(fn, seconds, device_index):
 
     def run():
         try:
-            torch.cuda.set_device(device_index)
+            if torch.cuda.is_available():
+                torch.cuda.set_device(device_index)
             torch.set_grad_enabled(False)           # (thread-local: the main thread switched it off for the whole run)
             box["out"] = fn()
         except Exception as ex:                     # noqa: BLE001
