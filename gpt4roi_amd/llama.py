@@ -21,35 +21,42 @@ class RaggedLayout:
 
     The reference's training attention unpads the batch with the mask, runs varlen flash attention over the kept tokens and
     pads the result back with zeros (llava/train/llama_flash_attn_monkey_patch.py:60-85: unpad_input -> cu_seqlens ->
-    pad_input); its serving path hands the same mask to HF's LlamaModel (llava/model/llava.py:263-283).  Here the kept rows
-    are gathered into one packed [nnz, C] buffer (sequence b = rows cu[b]:cu[b+1], order preserved = the causal order),
-    attention runs per sequence on views of it, and `inv` scatters the result back (pad rows = zero rows).  RoPE has
-    already been applied at the positions of the PADDED layout, as the reference applies it before unpadding (:46-50).
-    Building the layout reads the mask once on the host (B lengths)."""
+    pad_input); its serving path hands the same mask to HF's LlamaModel (llava/model/llava.py:263-283).  Here every
+    sequence's kept rows are gathered to the FRONT of its slot of one [B, Tc, C] buffer (Tc = the longest sequence, order
+    preserved = the causal order, the slots behind a sequence's last token are zero rows), ONE causal attention launch runs
+    over the B slots, and `inv` scatters the result back (pad rows = zero rows).  Under the causal mask a kept row i only sees
+    rows <= i of its own slot, all of them kept rows, so the zero rows behind need no length argument: their own outputs are
+    never read, and in the backward their dO rows are zero, which makes their contribution to dK / dV exactly zero.  RoPE
+    has already been applied at the positions of the PADDED layout, as the reference applies it before unpadding (:46-50).
+    The index sets are built on the device; building the layout reads the B lengths once on the host (for Tc)."""
 
     def __init__(self, mask, max_positions):
         m = mask.to(torch.bool)
         assert m.dim() == 2
         B, T = m.shape
         dev = m.device
-        keep = torch.nonzero(m.reshape(-1)).view(-1)
+        n = m.sum(1)
+        order = torch.argsort((~m).to(torch.int8), dim=1, stable=True)          # kept positions first, in their own order
         self.B, self.T = B, T
-        self.lens = [int(n) for n in m.sum(1).tolist()]
+        self.lens = [int(v) for v in n.tolist()]
         self.cu = [0]
-        for n in self.lens:
-            self.cu.append(self.cu[-1] + n)
+        for v in self.lens:
+            self.cu.append(self.cu[-1] + v)
         self.nnz = self.cu[-1]
-        b = torch.div(keep, T, rounding_mode="floor")
-        self.idx = keep.to(torch.int32).contiguous()                                     # row of the [B*T, C] activations
-        self.idx_cache = (b * max_positions + (keep - b * T)).to(torch.int32).contiguous()   # row of a layer's [B_alloc*maxpos, C] cache
-        inv = torch.full((B * T,), -1, dtype=torch.int32, device=dev)
-        inv[keep] = torch.arange(self.nnz, dtype=torch.int32, device=dev)
-        self.inv = inv                                                                   # padded row -> packed row (-1: pad)
-        self.pos0 = torch.tensor(self.lens + [T], dtype=torch.int32, device=dev)         # the ragged decode state after the prompt:
-        #                                                                                  B cache lengths + the RoPE position
-        keep_h = keep.tolist()
-        self.last = torch.tensor([keep_h[self.cu[i + 1] - 1] if self.lens[i] else -1 for i in range(B)], dtype=torch.int32,
-                                 device=dev)                                             # padded row of each sequence's last token
+        self.Tc = Tc = max(max(self.lens), 1)
+        row = torch.arange(B, device=dev)[:, None]
+        t_of = order[:, :Tc]
+        live = torch.arange(Tc, device=dev)[None, :] < n[:, None]
+        none = torch.full((), -1, dtype=torch.int64, device=dev)
+        # slot (b, i) -> row of the [B*T, C] activations / of a layer's [B_alloc*maxpos, C] cache (-1: behind the sequence)
+        self.idx = torch.where(live, row * T + t_of, none).to(torch.int32).reshape(-1).contiguous()
+        self.idx_cache = torch.where(live, row * max_positions + t_of, none).to(torch.int32).reshape(-1).contiguous()
+        rank = torch.cumsum(m, 1) - 1
+        self.inv = torch.where(m, row * Tc + rank, none).to(torch.int32).reshape(-1).contiguous()   # padded row -> slot (-1: pad)
+        self.pos0 = torch.cat([n, torch.full((1,), T, dtype=n.dtype, device=dev)]).to(torch.int32)   # the ragged decode state
+        #                                                              after the prompt: B cache lengths + the RoPE position
+        last_t = order.gather(1, (n - 1).clamp(min=0)[:, None])[:, 0]
+        self.last = torch.where(n > 0, row[:, 0] * T + last_t, none).to(torch.int32)   # padded row of each sequence's last token
 
     @staticmethod
     def of(mask, max_positions):
@@ -127,46 +134,31 @@ class LlamaDecoder:
 
     def _attn_ragged(self, li, q, rag, want_lse=False, compact=False):
         """Causal attention of a masked batch (see RaggedLayout): q [B, T, C] rotated, K/V of this layer already in the
-        cache at the padded positions.  -> (a [B, T, C] with zero pad rows, packed operands for the backward).
-        compact: each sequence's kept K/V rows move to the front of its cache slot (rows [0, n_b)), which is what the
-        ragged decode launch continues from."""
+        cache at the padded positions.  -> (a [B, T, C] with zero pad rows, the front-packed operands for the backward).
+        One launch for the whole batch, whatever B.  compact: each sequence's kept K/V rows move to the front of its cache
+        slot (rows [0, n_b)), which is what the ragged decode launch continues from."""
         B, T, C = q.shape
-        H, D = self.heads, self.head_dim
-        scale = 1.0 / math.sqrt(D)
-        qp = K.gather_rows(q.view(B * T, C), rag.idx)
-        kp = K.gather_rows(self.kc[li].view(-1, C), rag.idx_cache)
-        vp = K.gather_rows(self.vc[li].view(-1, C), rag.idx_cache)
+        H, D, Tc = self.heads, self.head_dim, rag.Tc
+        qp = K.gather_rows(q.view(B * T, C), rag.idx).view(B, Tc, C)
+        kp = K.gather_rows(self.kc[li].view(-1, C), rag.idx_cache).view(B, Tc, C)
+        vp = K.gather_rows(self.vc[li].view(-1, C), rag.idx_cache).view(B, Tc, C)
         ap = torch.empty_like(qp)
-        lses = []
-        for b in range(B):
-            lo, hi = rag.cu[b], rag.cu[b + 1]
-            if hi == lo:
-                lses.append(None)
-                continue
-            lse = torch.empty((1, H, hi - lo), dtype=torch.float32, device=q.device) if want_lse else None
-            K.flash_attn(qp[lo:hi][None], kp[lo:hi][None], vp[lo:hi][None], H, scale, True, out=ap[lo:hi][None], lse=lse)
-            lses.append(lse)
-            if compact:
-                self.kc[li, b, :hi - lo].copy_(kp[lo:hi])
-                self.vc[li, b, :hi - lo].copy_(vp[lo:hi])
-        a = K.gather_rows(ap, rag.inv).view(B, T, C)
-        return a, dict(qp=qp, kp=kp, vp=vp, ap=ap, lses=lses)
+        lse = torch.empty((B, H, Tc), dtype=torch.float32, device=q.device) if want_lse else None
+        K.flash_attn(qp, kp, vp, H, 1.0 / math.sqrt(D), True, out=ap, lse=lse)
+        if compact:
+            self.kc[li, :B, :Tc].copy_(kp)
+            self.vc[li, :B, :Tc].copy_(vp)
+        a = K.gather_rows(ap.view(B * Tc, C), rag.inv).view(B, T, C)
+        return a, dict(qp=qp, kp=kp, vp=vp, ap=ap, lse=lse)
 
     def _attn_ragged_bwd(self, pk, da, rag):
-        """Backward of `_attn_ragged`: da [B, T, C] -> dq, dk, dv [B, T, C] (zero pad rows)."""
+        """Backward of `_attn_ragged`: da [B, T, C] -> dq, dk, dv [B, T, C] (zero pad rows).  One launch."""
         B, T, C = da.shape
-        H = self.heads
-        scale = 1.0 / math.sqrt(self.head_dim)
-        dap = K.gather_rows(da.reshape(B * T, C), rag.idx)
-        dqp, dkp, dvp = torch.empty_like(dap), torch.empty_like(dap), torch.empty_like(dap)
-        for b in range(B):
-            lo, hi = rag.cu[b], rag.cu[b + 1]
-            if hi == lo:
-                continue
-            K.flash_attn_bwd(pk['qp'][lo:hi][None], pk['kp'][lo:hi][None], pk['vp'][lo:hi][None], pk['ap'][lo:hi][None],
-                             dap[lo:hi][None], pk['lses'][b], H, scale, True,
-                             out=(dqp[lo:hi][None], dkp[lo:hi][None], dvp[lo:hi][None]))
-        return tuple(K.gather_rows(t, rag.inv).view(B, T, C) for t in (dqp, dkp, dvp))
+        Tc = rag.Tc
+        dap = K.gather_rows(da.reshape(B * T, C), rag.idx).view(B, Tc, C)
+        dqp, dkp, dvp = K.flash_attn_bwd(pk['qp'], pk['kp'], pk['vp'], pk['ap'], dap, pk['lse'], self.heads,
+                                         1.0 / math.sqrt(self.head_dim), True)
+        return tuple(K.gather_rows(t.view(B * Tc, C), rag.inv).view(B, T, C) for t in (dqp, dkp, dvp))
 
     @torch.no_grad()
     def forward(self, inputs_embeds, all_logits=True, return_hidden=False, key_padding_mask=None):

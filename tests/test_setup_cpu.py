@@ -224,19 +224,19 @@ def test_prompt_assembly_matches_the_reference(ref):
 
 
 def test_ragged_layout_index_sets_on_the_host():
-    """llama.RaggedLayout is plain index bookkeeping (no kernel): the packed-row index, its inverse with -1 on the pad rows,
+    """llama.RaggedLayout is plain index bookkeeping (no kernel): the front-packed slot index (-1 behind a sequence), its inverse with -1 on the pad rows,
     the cache rows of the kept positions and each sequence's last kept row, for left padding, holes and an empty row."""
     from gpt4roi_amd.llama import RaggedLayout
     m = torch.tensor([[0, 0, 1, 1, 1], [1, 1, 1, 1, 1], [1, 0, 1, 0, 0], [0, 0, 0, 0, 0]])
     r = RaggedLayout.of(m, 16)
     assert r.lens == [3, 5, 2, 0] and r.cu == [0, 3, 8, 10, 10] and r.nnz == 10
-    assert r.idx.tolist() == [2, 3, 4, 5, 6, 7, 8, 9, 10, 12]
-    assert r.idx_cache.tolist() == [2, 3, 4, 16, 17, 18, 19, 20, 32, 34]
-    assert r.inv.tolist() == [-1, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8, -1, 9] + [-1] * 7
+    assert r.Tc == 5 and r.idx.tolist() == [2, 3, 4, -1, -1, 5, 6, 7, 8, 9, 10, 12, -1, -1, -1] + [-1] * 5
+    assert r.idx_cache.tolist() == [2, 3, 4, -1, -1, 16, 17, 18, 19, 20, 32, 34, -1, -1, -1] + [-1] * 5
+    assert r.inv.tolist() == [-1, -1, 0, 1, 2, 5, 6, 7, 8, 9, 10, -1, 11] + [-1] * 7
     assert r.last.tolist() == [4, 9, 12, -1]
     assert RaggedLayout.of(torch.ones(2, 3), 16) is None and RaggedLayout.of(None, 16) is None
     # packing then padding back with `inv` is the identity on the kept rows and zero on the pad rows
     x = torch.arange(20.).view(20, 1) + 1
-    packed = x[r.idx.long()]
+    packed = torch.where(r.idx[:, None] >= 0, x[r.idx.clamp(min=0).long()], torch.zeros(1))
     back = torch.where(r.inv[:, None] >= 0, packed[r.inv.clamp(min=0).long()], torch.zeros(1))
     assert torch.equal(back * m.reshape(-1, 1), back) and torch.equal(back[m.reshape(-1).bool()], x[m.reshape(-1).bool()])

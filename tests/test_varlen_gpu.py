@@ -259,8 +259,8 @@ def test_ragged_layout_index_sets():
     m = torch.tensor([[0, 0, 1, 1, 1], [1, 1, 1, 1, 1], [1, 0, 1, 0, 0], [0, 0, 0, 0, 0]], device=DEV)
     r = RaggedLayout.of(m, 16)
     assert r.lens == [3, 5, 2, 0] and r.cu == [0, 3, 8, 10, 10]
-    assert r.idx.tolist() == [2, 3, 4, 5, 6, 7, 8, 9, 10, 12]
-    assert r.idx_cache.tolist() == [2, 3, 4, 16, 17, 18, 19, 20, 32, 34]
-    assert r.inv.tolist() == [-1, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8, -1, 9] + [-1] * 7
+    assert r.Tc == 5 and r.idx.tolist() == [2, 3, 4, -1, -1, 5, 6, 7, 8, 9, 10, 12, -1, -1, -1] + [-1] * 5
+    assert r.idx_cache.tolist() == [2, 3, 4, -1, -1, 16, 17, 18, 19, 20, 32, 34, -1, -1, -1] + [-1] * 5
+    assert r.inv.tolist() == [-1, -1, 0, 1, 2, 5, 6, 7, 8, 9, 10, -1, 11] + [-1] * 7
     assert r.last.tolist() == [4, 9, 12, -1]
     assert RaggedLayout.of(torch.ones(2, 3, device=DEV), 16) is None and RaggedLayout.of(None, 16) is None
