@@ -76,6 +76,10 @@ def parse():
     ap.add_argument("--stage2-steps", type=int, default=2,
                     help="extra: timed stage-2 training steps (SURVEY.md 8d config 4 per GPU: LLaMA-7B unfrozen, fp32 masters + "
                          "fused AdamW, --train-batch images); N = 1 only; 0 = skip")
+    ap.add_argument("--parity-tokens", type=int, default=64,
+                    help="N = 1 only, measured in THIS run (never part of `value`): greedy ids of the merged launch sequence -- the "
+                         "--batch requests prefilled together (M = batch x T) and decoded together for this many tokens -- against HF "
+                         "LlamaForCausalLM fp32 built from the same weights, from the path's own prompt embeddings; 0 = skip")
     ap.add_argument("--decode-tokens", type=int, default=32,
                     help="extra (not part of `value`): greedy KV-cache decode steps timed after the prefill")
     return ap.parse_args()
@@ -250,6 +254,65 @@ def vit_roofline(model, args, device):
     return out
 
 
+def live_parity_leg(args, model, image, boxes, prompt, device):
+    """Greedy-id parity of the configuration `value` is timed on, MEASURED IN THIS RUN (the line used to
+    quote a file written by a test on another box, for the single-request dispatch).  The --batch requests of the timed
+    step go through stages a4-a15 (ViT, region module, projector, splice) and ONE merged decoder prefill (M = batch x T rows:
+    the dense 256 x 256 tile in whole waves) + `decode_graph_batch`; the reference side is HF `LlamaForCausalLM` (the
+    arithmetic spi_llava.py:198-205 calls) in fp32 with eager attention, built from the SAME weights (export_hf_state_dict),
+    prefilled and decoded one request at a time from the SAME prompt embeddings.  What this leg does not cover -- the vision
+    and region stages against their oracle -- is tests/test_fullwidth_gpu.py::test_sixteen_merged_requests_... .
+    Returns exact-match lengths per request; a difference is reported with HF's fp32 logit gap between the two choices."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    n_new = args.parity_tokens
+    dec = model.llama
+    t0 = time.perf_counter()
+    emb = model.embed_inputs(prompt, image, model.prepare_boxes(boxes, args.image_size))
+    got = dec.decode_graph_batch(emb, n_new) if emb.size(0) > 1 else [dec.greedy_graph(emb, n_new)]
+    torch.cuda.synchronize()
+    t_hip = time.perf_counter() - t0
+    sd = dec.export_hf_state_dict()
+    V, C = sd["lm_head.weight"].shape
+    cfg = LlamaConfig(vocab_size=V, hidden_size=C, intermediate_size=sd["model.layers.0.mlp.down_proj.weight"].size(1),
+                      num_hidden_layers=len(dec.layers), num_attention_heads=dec.heads, num_key_value_heads=dec.heads,
+                      rms_norm_eps=1e-6, max_position_embeddings=2048, attention_bias=False, tie_word_embeddings=False,
+                      rope_theta=10000.0, attn_implementation="eager")
+    with torch.device(device):
+        hf = LlamaForCausalLM(cfg).float().eval()
+    r = hf.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    del sd
+    embed = hf.get_input_embeddings()
+    lens, first = [], None
+    t0 = time.perf_counter()
+    for b in range(emb.size(0)):
+        o = hf(inputs_embeds=emb[b:b + 1].float(), use_cache=True)
+        past, last = o.past_key_values, o.logits[0, -1]
+        k = n_new
+        for s_ in range(n_new):
+            nxt = int(last.argmax())
+            if nxt != got[b][s_]:
+                k = s_
+                if first is None:
+                    first = {"request": b, "step": s_, "hf_fp32_gap_between_the_two_choices": float(last[nxt] - last[got[b][s_]]),
+                             "hf_fp32_logit_range": float(last.max() - last.min())}
+                break
+            o = hf(inputs_embeds=embed(torch.tensor([[nxt]], device=device)), past_key_values=past, use_cache=True)
+            past, last = o.past_key_values, o.logits[0, -1]
+        lens.append(k)
+        del o, past
+    torch.cuda.synchronize()
+    t_hf = time.perf_counter() - t0
+    del hf
+    torch.cuda.empty_cache()
+    return {"scope": f"merged{emb.size(0)}: the {emb.size(0)} requests of the timed step, ONE merged decoder prefill (M = {emb.size(0) * emb.size(1)}) "
+                     f"+ decode_graph_batch, from the path's own prompt embeddings", "measured_in_this_run": True,
+            "against": "HF transformers LlamaForCausalLM fp32, eager attention, the same weights (export_hf_state_dict), one request at a "
+                       "time, on the GPU", "dtype": args.dtype, "new_tokens": n_new, "requests": int(emb.size(0)),
+            "exact": all(k == n_new for k in lens), "exact_len": lens, "first_divergence": first,
+            "seconds": {"hip_embed_prefill_decode": round(t_hip, 2), "hf_fp32": round(t_hf, 2)}}
+
+
 def train_leg(args, model, ids, device, rank, world, dist, agg_device):
     """Stage-1 training step (train_stage1.sh: region module [+ projector] trainable, ViT / LLaMA frozen) on RefCOCO-shaped
     synthetic batches (B images per GPU, 1..15 regions each, refcoco.py:55), data-parallel over the
@@ -317,33 +380,54 @@ def train_leg(args, model, ids, device, rank, world, dist, agg_device):
 def stage2_leg(args, model, ids, device):
     """Stage-2 step (train_stage2.sh / SURVEY.md 8d config 4, the per-GPU part): everything but the vision tower trains --
     forward + hand-written backward of every stage incl. all LLaMA weight gradients + clip + fused AdamW on fp32 masters.
-    One rank (the exchange of the 6.7 B gradients is covered by the gloo tests and needs the 8-GPU node)."""
+    One rank (the exchange of the 6.7 B gradients is covered by the gloo tests and needs the 8-GPU node).  Two batches on ONE
+    trainer: (a) --train-batch RefCOCO-shaped images (1..15 regions), activations kept; (b) configs[3]'s own per-GPU share --
+    16 images x 32 regions (global 128 over 8 GPUs, train_stage2.sh:40-52), T = 767 -- with per-layer decoder checkpointing
+    (`--gradient_checkpointing True`, train_stage2.sh:47), which is what makes it fit beside the replicated masters + Adam."""
     from gpt4roi_amd import synthetic as syn
     from gpt4roi_amd.train import FullTrainer
-    B, P = args.train_batch, args.image_size // 14
-    g = torch.Generator().manual_seed(6000)
-    n_i = torch.randint(1, 16, (B,), generator=g).tolist()
-    images = torch.randn(B, 3, args.image_size, args.image_size, generator=g).to(device)
-    boxes = [syn.boxes(n, g).to(device) for n in n_i]
-    prompt = torch.stack([syn.prompt_ids(ids, P, n, g, question_len=20 + 4 * (15 - n)) for n in n_i]).to(device)
-    labels = prompt.clone()
-    labels[:, :42 + P * P] = -100
-    labels[labels >= 32000] = -100
-    torch.cuda.reset_peak_memory_stats(device)
+    P = args.image_size // 14
     torch.cuda.empty_cache()
     tr = FullTrainer(model, lr=2e-5)
-    losses = [tr.step(prompt, images, boxes, labels).item() for _ in range(2)]      # warm-up: allocations, plans, the allocator's pools
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.stage2_steps):
-        losses.append(tr.step(prompt, images, boxes, labels).item())
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.stage2_steps
-    return {"what": "stage-2 step (SURVEY.md 8d config 4, one GPU's share): forward + backward with every LLaMA-7B weight gradient "
-                    "+ clip + fused AdamW on fp32 masters", "batch_per_gpu": B, "tokens_per_sequence": int(prompt.size(1)),
-            "steps": args.stage2_steps, "ms_per_step": round(1e3 * dt, 2), "images_per_s": round(B / dt, 2),
-            "tokens_per_s": round(B * prompt.size(1) / dt, 1), "peak_mem_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
-            "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)]}
+
+    def run(B, n_i, seed, checkpoint, what):
+        g = torch.Generator().manual_seed(seed)
+        images = torch.randn(B, 3, args.image_size, args.image_size, generator=g).to(device)
+        boxes = [syn.boxes(n, g).to(device) for n in n_i]
+        prompt = torch.stack([syn.prompt_ids(ids, P, n, g, question_len=20 + 4 * (15 - min(n, 15))) for n in n_i]).to(device)
+        labels = prompt.clone()
+        labels[:, :42 + P * P] = -100
+        labels[labels >= 32000] = -100
+        model.gradient_checkpointing = bool(checkpoint)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(device)
+        losses = [tr.step(prompt, images, boxes, labels).item() for _ in range(2)]      # warm-up: allocations, plans, the allocator's pools
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.stage2_steps):
+            losses.append(tr.step(prompt, images, boxes, labels).item())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.stage2_steps
+        return {"what": what, "batch_per_gpu": B, "tokens_per_sequence": int(prompt.size(1)), "decoder_checkpointing": bool(checkpoint),
+                "steps": args.stage2_steps, "ms_per_step": round(1e3 * dt, 2), "images_per_s": round(B / dt, 2),
+                "tokens_per_s": round(B * prompt.size(1) / dt, 1), "region_tokens_trained_per_s": round(sum(n_i) / dt, 1),
+                "peak_mem_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
+                "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)]}
+    try:
+        B = args.train_batch
+        n_i = torch.randint(1, 16, (B,), generator=torch.Generator().manual_seed(6000)).tolist()
+        out = run(B, n_i, 6000, False, "stage-2 step (SURVEY.md 8d config 4, one GPU's share): forward + backward with every LLaMA-7B "
+                                         "weight gradient + clip + fused AdamW on fp32 masters")
+        try:
+            out["config4_batch16"] = run(16, [32] * 16, 6001, True,
+                                         "the same step at configs[3]'s OWN per-GPU batch: 16 images x 32 regions (global 128 on 8 GPUs), "
+                                         "per-layer decoder checkpointing (train_stage2.sh:40-52)")
+        except Exception as ex:                              # e.g. out of memory beside the replicated masters + Adam state
+            out["config4_batch16"] = {"error": repr(ex)[:300]}
+            torch.cuda.empty_cache()
+    finally:
+        model.gradient_checkpointing = False
+    return out
 
 
 class _Deadline(Exception):
@@ -569,6 +653,11 @@ def main():
             roofline["pmc_counters_match_kernel_sources"] = None
         if not rec and pmc:
             roofline["pmc_error"] = f"no counter row for {dom!r} in {pmc_file}"
+        counters_ok = roofline["pmc_counters_match_kernel_sources"] is not False      # (False: counters of OTHER kernel sources)
+        if not counters_ok:
+            roofline["traffic_note"] = (f"null: the committed counters ({pmc_file}) were collected on different kernel sources; "
+                                        "re-run tools/pmc_report.py")
+            rec = {}
         if "hbm_read_bytes" in rec:
             roofline["traffic"] = rec["hbm_read_bytes"] + rec.get("hbm_write_bytes", 0)
             roofline["traffic_source"] = (f"{pmc_file} (PMC FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 per launch, "
@@ -580,7 +669,7 @@ def main():
         conv_tag = max((t_ for t_ in agg if t_.startswith("conv3x3_igemm<256x256")), key=lambda t_: agg[t_]["ms"], default=None)
         cv = agg.get(conv_tag)
         if cv and cv.get("flops"):
-            crec = pmc_rec(conv_tag)
+            crec = pmc_rec(conv_tag) if counters_ok else {}
             tf = cv["flops"] / (cv["ms"] * 1e-3) / 1e12
             roofline["conv"] = {"kernel": conv_tag, "bound": "mfma", "achieved": round(tf, 1),
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
@@ -608,7 +697,7 @@ def main():
                                      "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(ra["bytes"]),
                                      "avg_launch_us": round(1e3 * ra["ms"] / ra["calls"], 2),
                                      "traffic": (lambda r: r["hbm_read_bytes"] + r.get("hbm_write_bytes", 0) if "hbm_read_bytes" in r
-                                                 else None)(pmc_rec("roi_align_mlvl_nhwc"))}
+                                                 else None)(pmc_rec("roi_align_mlvl_nhwc") if counters_ok else {})}
 
     decode = None
     if rank == 0 and args.decode_tokens > 0:
@@ -656,6 +745,14 @@ def main():
             del embB
         except Exception as ex:
             decode["batched"] = {"error": repr(ex)}
+
+    live_parity = None
+    if rank == 0 and world == 1 and args.parity_tokens > 0:
+        try:
+            live_parity = live_parity_leg(args, model, image, boxes, prompt, device)
+        except Exception as ex:                                      # never lose the headline
+            live_parity = {"error": repr(ex)[:300]}
+            torch.cuda.empty_cache()
 
     vit = None
     if rank == 0 and not args.no_roofline:
@@ -816,13 +913,34 @@ def main():
                             "decoder_free_running_exact_len": [r["free_running_exact_len"] for r in rs],
                             "teacher_forced_identical": [r["teacher_forced_identical"] for r in rs],
                             "first_divergence": [r["whole_path_first_divergence"] for r in rs if r["whole_path_first_divergence"]] or None}
-                greedy = {"source": os.path.relpath(cands[-1], ROOT), "against": runs[0]["against"],
+                import hashlib
+                doc = json.load(open(cands[-1]))
+                greedy = {"source": os.path.relpath(cands[-1], ROOT),
+                          "source_sha256_16": hashlib.sha256(open(cands[-1], "rb").read()).hexdigest()[:16],
+                          "quoted": True, "scope": "batch1 (one request at a time): tests/test_fullwidth_gpu.py::test_bench_model_full_depth_...",
+                          "against": runs[0]["against"],
                           args.dtype: summary(args.dtype), ("bf16" if args.dtype == "fp16" else "fp16"): summary("bf16" if args.dtype == "fp16" else "fp16")}
+                m16 = doc.get("merged16")
+                if m16:      # tests/test_fullwidth_gpu.py::test_sixteen_merged_requests_... (whole path incl. vision + region stages)
+                    greedy["merged16_" + m16.get("dtype", "fp16")] = {k: m16[k] for k in (
+                        "requests", "new_tokens", "merged_exact_len", "alone_exact_len", "merged_equals_alone_len",
+                        "max_logit_err_of_range", "max_merged_vs_alone_logits_rel") if k in m16}
         except Exception as ex:
             greedy = {"error": repr(ex)}
     if rank == 0:
         P = args.image_size // 14
         total_regions = args.rois * args.batch * args.steps * world
+        # forward FLOPs of one request: ViT 23 blocks + patch embed, 1x1 + 5 fuse rounds of 3x3 convs over the
+        # 85 P^2 pyramid pixels, pconvs + flatten_linear + updims per RoI, projector, LLaMA prefill (12.95 GF/token incl. lm_head
+        # + causal attention)
+        S_, C_, T_ = P * P + 1, 1024, int(prompt.size(1))
+        npix = 85 * P * P
+        flops_per_request = (23 * (24.0 * S_ * C_ * C_ + 4.0 * S_ * S_ * C_) + 2.0 * (S_ - 1) * 588 * C_
+                             + 2.0 * 1026 * C_ * npix + 5 * 2.0 * 9 * C_ * C_ * npix
+                             + args.rois * (4 * 2.0 * 9 * C_ * C_ * 196 + 2.0 * 196 * C_ * 1024 + 2.0 * 1024 * 4096)
+                             + 2.0 * P * P * C_ * 4096
+                             + T_ * (args.llama_layers * (8.0 * 4096 * 4096 + 6.0 * 4096 * 11008) + 2.0 * 4096 * 32006)
+                             + args.llama_layers * 2.0 * T_ * T_ * 4096)
         line = {
             "metric": f"region-tokens/sec (336^2 img, 32 RoIs, CLIP ViT-L/14 + region module + LLaMA-7B fwd; {args.batch} batch-1 requests "
                       "merged per launch sequence, value_batch1 = one request at a time)",
@@ -845,9 +963,33 @@ def main():
                        "image_size": args.image_size, "rois_per_image": args.rois, "prompt_tokens": int(prompt.size(1)),
                        "parallelism": f"replicas x{world} (no data-path collective); {n_ctx} launch sequences of {args.batch} "
                                       f"requests in flight per GPU on separate HIP streams",
-                       "valid": args.llama_layers == 32 and args.image_size == 336 and args.rois == 32},
-            "greedy_exact": (greedy or {}).get(args.dtype, {}).get("exact") if isinstance((greedy or {}).get(args.dtype), dict) else None,
+                       "valid": args.llama_layers == 32 and args.image_size == 336 and args.rois == 32,
+                       # why `value` is where it is against north_star's 5000 (SURVEY.md section 7 "hard parts")
+                       "target_arithmetic": {
+                           "north_star_target_region_tokens_per_s": 5000,
+                           "forward_TFLOP_per_request": round(flops_per_request / 1e12, 2),
+                           "PFLOP_per_s_needed_at_target": round(5000 / args.rois * flops_per_request / 1e15, 3),
+                           "fraction_of_dense_16bit_peak_needed": round(5000 / args.rois * flops_per_request / 1e12 / PEAK_BF16_TFLOPS, 3),
+                           "this_run_PFLOP_per_s": round(total_regions / dt / args.rois * flops_per_request / 1e15, 3),
+                           "this_run_fraction_of_peak": round(total_regions / dt / args.rois * flops_per_request / 1e12 / PEAK_BF16_TFLOPS, 3),
+                           "value_if_every_kernel_ran_at_the_vendor_gemm_fraction_0p62": round(0.62 * PEAK_BF16_TFLOPS * 1e12 / flops_per_request * args.rois, 0),
+                           "note": "5000 region-tokens/s at 336^2 needs ~99 % of the dense MFMA peak for the whole forward; at the "
+                                   "reference-native 224^2 it needs ~59 % (extras.native_224 is that configuration)"},
+                       "headline_defaults": {"dtype": "fp16 since round 5 (bf16 rounds 1-4; the other type is extras." + other_name + ")",
+                                             "requests_merged": "16 since round 4 (1 x 2 streams rounds 1-3, 4 x 2 early round 4)"}},
+            # greedy ids against HF fp32: MEASURED in this run for the merged dispatch `value` is timed on (live_parity_leg) when
+            # that leg ran; otherwise the quotation of the committed test record, whose scope is the single request
+            "greedy_exact": (live_parity["exact"] if isinstance(live_parity, dict) and "exact" in live_parity else
+                             ((greedy or {}).get(args.dtype, {}).get("exact") if isinstance((greedy or {}).get(args.dtype), dict) else None)),
+            "greedy_exact_scope": (f"merged{args.batch}, measured in this run (decoder: merged prefill + batched decode, "
+                                   f"{args.parity_tokens} tokens x {args.batch} requests vs HF fp32)"
+                                   if isinstance(live_parity, dict) and "exact" in live_parity else
+                                   ("batch1, quoted from " + str((greedy or {}).get("source")) + " sha256:" + str((greedy or {}).get("source_sha256_16"))
+                                    if greedy and "source" in greedy else None)),
+            "greedy_exact_len": live_parity.get("exact_len") if isinstance(live_parity, dict) else None,
+            "greedy_live": live_parity,
             "greedy_parity": greedy,
+            "train_leg_timed_out": bool(hard_exit),
             "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "train": train, "extras": extras, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)

@@ -2452,13 +2452,22 @@ int launch_w4k64_epi(GemmArgs& p, hipStream_t stream) {
   return G4R_OK;
 }
 
+template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true, int SCHED = 0>
+int launch_pp32(GemmArgs& p, hipStream_t stream);      // (defined below: the fallback for operands beyond a buffer descriptor)
+
 template <int AMODE, bool PROBE = false>
 int launch_w4k64(GemmArgs& p, hipStream_t stream) {
   {
     // extents for the buffer descriptors: the last byte a clamped row / in-image tap can touch
     size_t ab = (size_t)p.M * p.lda * 2, wb = (size_t)p.N * p.ldw * 2;
     if (AMODE == 1) ab = ((size_t)(p.groups - 1) * p.a_group_stride + (size_t)p.M * p.lda) * 2;
-    if (ab >= 0x7fffffffu || wb >= 0x7fffffffu) return g4r_note_error(G4R_ERR_UNSUPPORTED, "gemm_w4k64: operands of 2 GiB and more (use tile 24)");
+    // operands of 2 GiB and more do not fit a buffer descriptor's 32-bit extent: the ring ping-pong tile with plain
+    // global_load_lds pieces (64-bit addresses) serves them, as it did before this kernel became the default (e.g. the
+    // stage-2 data gradient dgu[tokens, 22016] x W^T above ~48.7 k tokens)
+    if (ab >= 0x7fffffffu || wb >= 0x7fffffffu) {
+      if (PROBE) return g4r_note_error(G4R_ERR_UNSUPPORTED, "gemm_w4k64 (probe): operands of 2 GiB and more");
+      return launch_pp32<AMODE, false, 256, 256, false, (AMODE >= 1 ? 1 : 0)>(p, stream);
+    }
     p.a_bytes = (unsigned)ab;
     p.w_bytes = (unsigned)wb;
   }
@@ -2513,7 +2522,7 @@ int launch_w4k64(GemmArgs& p, hipStream_t stream) {
   return G4R_OK;
 }
 
-template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true, int SCHED = 0>
+template <int AMODE, bool PROBE, int BM, int BN, bool BUF, int SCHED>
 int launch_pp32(GemmArgs& p, hipStream_t stream) {
   if (BUF) {
     // extents for the buffer descriptors: the last byte a clamped row / in-image tap can touch
@@ -2637,23 +2646,35 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
   if (AMODE >= 1 && g_gemm_dbg == 41) p.group_m = -2;   // tools: conv, an XCD's wave = 16 pixel tiles x 2 weight panels
   if (AMODE >= 1 && g_gemm_dbg == 42) p.group_m = -1;   // tools: 32 pixel tiles x 1 weight panel
   switch (tile_cfg) {
+    // ---- the tiles kernels.py dispatches (pick_tile / pick_conv_tile / long_k_plan / partial_wave_plan / layers.py) ----
     case 0: return launch_tile<128, 128, 2, 2, AMODE, true>(p, stream);
+    case 4: return launch_tile<64, 128, 1, 4, AMODE, true>(p, stream);
+    case 7: return launch_tile<128, 128, 2, 4, AMODE, true, 4, 64, 3>(p, stream);   // 8 waves, 64x32 wave tiles; counted-wait fragment pipeline
+    // Small-M shapes (CLIP ViT, M = 577; K = 1024 is only 16 K tiles): fewer workgroups than CUs, so what matters is ONE
+    // workgroup's latency -> deep LDS-DMA rings instead of co-resident workgroups.
+    case 13: return launch_tile<64, 128, 1, 4, AMODE, true, 3, 64, 3>(p, stream);   // 72 KB ring of 3: 2 wg/CU; counted-wait fragment pipeline
+    case 14: return launch_tile<64, 64, 2, 2, AMODE, true, 4, 64, 3>(p, stream);    // 64 KB ring of 4: 2 wg/CU; counted-wait fragment pipeline
+    case 34: return launch_w4k64<AMODE>(p, stream);                              // 256x256, 4 waves x (128x128), K 64 x 2 buffers refilled as consumed (round 5)
+    case 24:                                                                     // 256x256 ping-pong, K 32 ring of 4 (G4R_BIG_TILE=24; operands >= 2 GiB)
+      // the implicit-GEMM convs take the rotated single-barrier schedule (192^2 conv 693 -> 668 us, tools/gemm_bench.cpp
+      // tile 31); the dense GEMMs lose 8-12 % on it (4096^3 1172 -> 1076 TF/s) and keep the two-barrier form
+      if constexpr (AMODE >= 1) return launch_pp32<AMODE, false, 256, 256, true, 1>(p, stream);
+      else return launch_pp32<AMODE>(p, stream);
+    case 28: return launch_pp32<AMODE, false, 192, 256>(p, stream);              // 192x256 ring ping-pong (767 x 12288: 4 x 48 = 192 workgroups)
+#ifdef G4R_TOOLS_BUILD
+    // ---- superseded forms and A/B arms: compiled only into the tools build (G4R_EXTRA_HIPCC_FLAGS=-DG4R_TOOLS_BUILD python -m
+    //      gpt4roi_amd.build --force); the shipped library holds the dispatched kernels only ----
     case 1: return launch_tile<256, 128, 4, 2, AMODE, true>(p, stream);
     case 2: return launch_tile<128, 128, 2, 2, AMODE, false>(p, stream);  // register-staged A/B probe
-    case 4: return launch_tile<64, 128, 1, 4, AMODE, true>(p, stream);
     case 5: return launch_tile<128, 128, 2, 2, AMODE, true, 3>(p, stream);   // 96 KB ring
     case 6: return launch_tile<128, 128, 2, 2, AMODE, true, 4>(p, stream);   // 128 KB ring
-    case 7: return launch_tile<128, 128, 2, 4, AMODE, true, 4, 64, 3>(p, stream);   // 8 waves, 64x32 wave tiles; counted-wait fragment pipeline
     case 8: return launch_tile<256, 128, 4, 2, AMODE, true, 3>(p, stream);   // 144 KB ring, 8 waves
     case 9: return launch_tile<256, 256, 2, 4, AMODE, true, 2>(p, stream);   // 128 KB, wave tile 128x64
     case 10: return launch_tile<128, 128, 2, 4, AMODE, true, 2>(p, stream);  // 8 waves x (64x32), 2 wg/CU
     case 11: return launch_tile<128, 64, 2, 2, AMODE, true, 2>(p, stream);   // 48 KB: 3 wg/CU
     // (12-21 of round 1 were the BK = 32 / interleaved-read ring experiments of DESIGN.md section 3; they lost and
-    // were removed.)  Small-M shapes (CLIP ViT, M = 577; K = 1024 is only 16 K tiles): fewer workgroups than CUs, so
-    // what matters is ONE workgroup's latency -> deep LDS-DMA rings instead of co-resident workgroups.
+    // were removed.)
     case 12: return launch_tile<64, 128, 1, 4, AMODE, true, 4>(p, stream);   // 96 KB ring of 4
-    case 13: return launch_tile<64, 128, 1, 4, AMODE, true, 3, 64, 3>(p, stream);   // 72 KB ring of 3: 2 wg/CU; counted-wait fragment pipeline
-    case 14: return launch_tile<64, 64, 2, 2, AMODE, true, 4, 64, 3>(p, stream);    // 64 KB ring of 4: 2 wg/CU; counted-wait fragment pipeline
     case 15: return launch_tile<128, 64, 2, 2, AMODE, true, 4>(p, stream);   // 96 KB ring of 4
     // A/B arms of round 3c (dense GEMM only): tiles 13 / 14 / 7 with the compiler's own read order (STYLE 0; the counted-wait
     // fragment pipeline, STYLE 3, is their production form: ViT qkv 10.9 -> 10.8 us, o 8.2 -> 7.9, fc1 15.5 -> 14.6, fc2 21.1 ->
@@ -2662,25 +2683,19 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 43: if constexpr (AMODE == 0) return launch_tile<64, 128, 1, 4, AMODE, true, 3>(p, stream); else break;
     case 44: if constexpr (AMODE == 0) return launch_tile<64, 64, 2, 2, AMODE, true, 4>(p, stream); else break;
     case 47: if constexpr (AMODE == 0) return launch_tile<128, 128, 2, 4, AMODE, true, 4>(p, stream); else break;
-    case 34: return launch_w4k64<AMODE>(p, stream);                              // 256x256, 4 waves x (128x128), K 64 x 2 buffers refilled as consumed (round 5)
-    case 35: if constexpr (AMODE == 0) return launch_w4k64<AMODE, true>(p, stream); else break;   // same + s_memtime stamps (tools only)
+    case 35: if constexpr (AMODE == 0) return launch_w4k64<AMODE, true>(p, stream); else break;   // tile 34 + s_memtime stamps
     case 26: return launch_w4<AMODE>(p, stream);                                 // 256x256, 4 waves x (128x128): one wave per SIMD, K 32 ring of 4
     case 22: return launch_pp<AMODE>(p, stream);                                 // 256x256 ping-pong (4 barriers / K tile)
-    case 24:                                                                     // 256x256 ping-pong, K 32 ring of 4
-      // the implicit-GEMM convs take the rotated single-barrier schedule (192^2 conv 693 -> 668 us, tools/gemm_bench.cpp
-      // tile 31); the dense GEMMs lose 8-12 % on it (4096^3 1172 -> 1076 TF/s) and keep the two-barrier form
-      if constexpr (AMODE >= 1) return launch_pp32<AMODE, false, 256, 256, true, 1>(p, stream);
-      else return launch_pp32<AMODE>(p, stream);
     case 27: return launch_pp32<AMODE, false, 128, 384>(p, stream);              // 128x384 ring ping-pong (767 x 12288: 192 workgroups)
-    case 28: return launch_pp32<AMODE, false, 192, 256>(p, stream);              // 192x256 ring ping-pong (767 x 12288: 4 x 48 = 192 workgroups)
-    case 25: return launch_pp32<AMODE, true>(p, stream);                         // same + s_memtime stamps (tools only)
+    case 25: return launch_pp32<AMODE, true>(p, stream);                         // tile 24 + s_memtime stamps
     case 30: return launch_pp32<AMODE, false, 256, 256, false>(p, stream);       // A/B arm: pieces by global_load_lds (the round-2 form)
     case 31: return launch_pp32<AMODE, false, 256, 256, true, 1>(p, stream);     // rotated single-barrier schedule (A/B arm for dense)
     case 33: return launch_pp32<AMODE, false, 256, 256, true, 0>(p, stream);     // two-barrier schedule (A/B arm for the convs)
-    case 23: return launch_pp<AMODE, true>(p, stream);                           // same + s_memtime stamps into ws (tools only)
+    case 23: return launch_pp<AMODE, true>(p, stream);                           // tile 22 + s_memtime stamps into ws
+#endif
     default: break;
   }
-  return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg");
+  return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm: unknown tile_cfg (superseded forms / A-B arms exist in the tools build only: -DG4R_TOOLS_BUILD)");
 }
 
 }  // namespace

@@ -439,7 +439,8 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=None, spl
     if residual is not None:
         assert residual.shape == (M, N) and residual.stride(1) == 1
     if tile_cfg is None and splits == 1 and workspace is None and gemv_batch_wins(M, N, K) and a.stride(0) % 8 == 0 \
-            and a.stride(0) >= K and w.stride(0) % 8 == 0 and (residual is None or residual.data_ptr() != out.data_ptr()):
+            and a.stride(0) >= K and w.stride(0) % 8 == 0 and (residual is None or residual.data_ptr() != out.data_ptr()) \
+            and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0:        # (the kernel reads both operands in 16-byte pieces)
         # a handful of rows (the decode step of a batch of sequences): weight streaming with the products on the matrix pipe
         return gemv_batch(a, w, bias=bias, residual=residual, act=act, out=out)
     thin_tail = False
@@ -552,8 +553,10 @@ def gemv_batch_wins(M, N, K):
     step (hipGraph replay, LLaMA-7B, 767-token prompts) it wins at 2-4 sequences (3.66 / 3.74 / 3.83 vs 3.91 / 4.00 / 4.02 ms per
     step) and loses at 8 (4.51 vs 4.36) -- each of its N / 16 workgroups stages all the rows, which the tiles amortise over 64
     output columns.  So: 2..4 rows, one staging pass, K <= 8192."""
-    return (2 <= M <= 4 and 512 <= K <= 8192 and K % 64 == 0 and M * (2 * K + 16) <= 98304
-            and os.environ.get("G4R_GEMV_BATCH", "1") != "0")
+    return _GEMV_BATCH_ON and 2 <= M <= 4 and 512 <= K <= 8192 and K % 64 == 0 and M * (2 * K + 16) <= 98304
+
+
+_GEMV_BATCH_ON = os.environ.get("G4R_GEMV_BATCH", "1") != "0"      # (read once: gemm() sits in the eager decode loop)
 
 
 def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=None, splits=1, tile_cfg=None,

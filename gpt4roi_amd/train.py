@@ -54,7 +54,9 @@ class RegionTrainer:
     the decoder stay frozen.  `step()` returns the mean token loss as a device tensor."""
 
     def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
-                 train_projector=False, group=None, bucket_bytes=256 << 20, _build_reducer=True):
+                 train_projector=False, group=None, bucket_bytes=256 << 20, _build_reducer=True, exchange_algo="rs_ag"):
+        """exchange_algo: "rs_ag" (reduce-scatter + all-gather per bucket: every xGMI link carries 1 / world of it) or
+        "all_reduce" (one ring all-reduce per bucket, the measured alternative) -- grad_reduce.GradBucketReducer."""
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -73,8 +75,8 @@ class RegionTrainer:
         self.opt = K.MultiTensorAdamW([p.data for p in self.params.values()], None, betas, eps, weight_decay)
         self.steps = 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.reducer = GradBucketReducer(list(self.params.values()), bucket_bytes=bucket_bytes, group=group,
-                                         comm_dtype=torch.float32) if (self.world > 1 and _build_reducer) else None
+        self.reducer = GradBucketReducer(list(self.params.values()), bucket_bytes=bucket_bytes, group=group, comm_dtype=torch.float32,
+                                         algo=exchange_algo) if (self.world > 1 and _build_reducer) else None
         self.last_grad_norm = None
 
     # ---- forward + backward: parameter gradients in the reference layout ------------------------------------
@@ -159,7 +161,7 @@ class FullTrainer(RegionTrainer):
     (train_stage2.sh:51-52)."""
 
     def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
-                 bucket_bytes=256 << 20):
+                 bucket_bytes=256 << 20, exchange_algo="rs_ag"):
         super().__init__(model, lr, betas, eps, weight_decay, max_grad_norm, train_projector=True, group=group,
                          bucket_bytes=bucket_bytes, _build_reducer=False)   # one reducer over ALL tensors, below
         dec = model.llama
@@ -178,7 +180,7 @@ class FullTrainer(RegionTrainer):
         if self.world > 1:
             tensors = list(self.params.values()) + list(self.dec_master.values())
             self.reducer = GradBucketReducer(tensors, bucket_bytes=bucket_bytes, group=group, comm_dtype=torch.float32,
-                                             trainable_only=False)
+                                             trainable_only=False, algo=exchange_algo)
 
     def _exchange_tensors(self):
         return {**self.params, **self.dec_master}

@@ -139,6 +139,25 @@ def test_conv_over_all_levels_one_wave_per_simd_vs_ring_kernel():
     assert rel(got, ref) < TOL[torch.bfloat16] and rel(got, ring) < TOL[torch.bfloat16]
 
 
+def test_operands_of_2_GiB_and_more_fall_back_to_the_ring_tile():
+    """tile 34 addresses its operands through buffer descriptors (32-bit extents).  An activation matrix
+    of 2 GiB and more -- the stage-2 data gradient dgu[tokens, 22016] x W^T above ~48.7 k tokens -- must run (on the ring
+    ping-pong tile with 64-bit global_load_lds pieces), under the default dispatch and when tile 34 is asked for by number;
+    sampled rows against fp32 torch.  (The arithmetic nn.Linear's backward delegates to cuBLAS, llava/model/llava.py:52.)"""
+    M, N, Kd = 66048, 512, 16384                                # A: 2.16 GB of bf16
+    g = torch.Generator(device=DEV).manual_seed(50)
+    a = (torch.randn(M, Kd, generator=g, device=DEV) * 0.5).to(torch.bfloat16)
+    w = rnd(N, Kd, seed=51, scale=0.05)
+    assert a.numel() * 2 >= 2 ** 31
+    rows = torch.tensor([0, 1, 255, 256, 32767, 65535, 65536, 65537, M - 257, M - 1], device=DEV)
+    ref = a[rows].float() @ w.float().t()
+    for tile in (None, 34):
+        got = K.gemm(a, w, tile_cfg=tile)
+        assert rel(got[rows], ref) < TOL[torch.bfloat16], tile
+    assert K.pick_tile(M, N, Kd) == 34                           # (the default dispatch did ask for tile 34)
+    del a
+
+
 # ------------------------------------------------------------------------------------------ batched decode projections (round 5)
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,N,Kd", [(2, 1000, 512), (3, 4096, 4096), (8, 12288, 4096), (8, 4096, 11008), (16, 2050, 11008), (5, 32006, 4096),

@@ -162,7 +162,11 @@ def test_gemm_grouped_tile_order_with_ragged_groups(tile, M, N, K):
     close(got, ref, 0.06 * math.sqrt(K / 64), 1e-2, f"grouped gemm {M}x{N}x{K} tile {tile}")
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 22, 24, 26, 27, 28])
+# every tile the shipped library holds (the superseded forms / A-B arms live in the tools build only: -DG4R_TOOLS_BUILD)
+SHIPPED_TILES = [0, 4, 7, 13, 14, 24, 28, 34]
+
+
+@pytest.mark.parametrize("tile", SHIPPED_TILES)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 328, 192), (37, 1024, 1024), (800, 512, 2048),
                                    (50, 30, 64), (300, 256, 128)])
 def test_gemm_plain(tile, M, N, K):
@@ -200,7 +204,7 @@ def test_gemm_epilogue(act):
     # the 256x256 kernels finish through LDS (row-major, whole-line stores): same arithmetic, bit-identical results to the
     # direct epilogue of the 128-wide tiles on the same fp32 sums -- checked on ragged shapes too (N not a multiple of 8,
     # strided output / residual, fp32 output, split-K partials)
-    for tile in (22, 24, 26, 27, 28):
+    for tile in (24, 28, 34):
         close(K.gemm(a, w, bias=bias, residual=res, act=act, tile_cfg=tile), ref, 0.05, 1e-2, f"epilogue {act} tile {tile}")
         close(K.gemm(a, w, bias=bias, residual=res, act=act, out_dtype=torch.float32, tile_cfg=tile), ref, 0.02, 2e-3,
               f"f32 out tile {tile}")
@@ -220,7 +224,7 @@ def test_gemm_swiglu_epilogue():
     a, g, u = rnd(M, Kd, seed=20), rnd(Fd, Kd, scale=0.1, seed=21), rnd(Fd, Kd, scale=0.1, seed=22)
     gate, up = a.float() @ g.float().t(), a.float() @ u.float().t()
     ref = F.silu(gate).to(torch.bfloat16).float() * up
-    for tile in (0, 4, 7, 24, 26, 28):
+    for tile in (0, 4, 7, 24, 28, 34):
         got = K.gemm(a, K.interleave_gate_up(g, u), act="swiglu", tile_cfg=tile)
         assert got.shape == (M, Fd)
         close(got, ref, 0.03, 2e-2, f"swiglu epilogue tile {tile}")
@@ -258,7 +262,7 @@ def test_gemm_flatten_linear_shape():
     close(got, ref, 0.05, 1e-2, "flatten_linear")
 
 
-@pytest.mark.parametrize("tile", [0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 22, 24, 26, 28])
+@pytest.mark.parametrize("tile", [0, 4, 7, 14, 24, 28, 34])
 def test_conv3x3(tile):
     B, H, W, Cin, Cout = 2, 13, 9, 64, 96
     x = rnd(B, H, W, Cin, seed=14)
