@@ -54,6 +54,8 @@ struct GemmArgs {
   unsigned a_bytes, w_bytes;   // extent of the A / W operands in bytes when < 2 GiB (buffer descriptors), else 0
   int defer_reduce;            // split-K: leave the fp32 partials in ws, the CALLER's next kernel combines them
   int stagger_ticks;           // one-wave-per-SIMD kernel: start offset step of the first 256 workgroups in 10 ns ticks (0 = none)
+  // persistent form (gemm_bf16_w4k64p_kernel): extents in bytes of the tensors its epilogue addresses through buffer descriptors
+  unsigned c_bytes, r_bytes, rq_bytes, rkv_bytes;
   // act == 5 (fused q|k|v projection of a LLaMA layer, ring ping-pong tiles only): RoPE and the KV-cache append happen in
   // the epilogue -- what g4r_rope_qkv_bf16 did in a launch of its own.  Columns [0, HD) -> rotated q rows of rope_q,
   // [HD, 2 HD) -> rotated k into the cache rows pos0 + t, [2 HD, 3 HD) -> v into the cache.  Row m = b * rope_T + t.
@@ -2452,6 +2454,509 @@ int launch_w4k64_epi(GemmArgs& p, hipStream_t stream) {
   return G4R_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 6 -- the PERSISTENT form of the one-wave-per-SIMD kernel ("w4k64p"): the same 256 x 256 tile, K loop and schedule as
+// gemm_bf16_w4k64_kernel, but ONE workgroup per CU walks the launch's tiles (tile t of CU slot b is the t-th tile the
+// hardware dispatcher would have handed that slot: linear id b + 256 t through the same XCD map), and the epilogue goes
+// straight from the accumulator registers to memory.
+// Why (profiles/r05_wg_timeline.txt): of a K = 4096 tile's lifetime the K loop is 0.88; the rest is the
+// prologue (~3 k cycles: nothing to multiply until the first two K tiles have landed), the LDS-parked epilogue (~16 k) and
+// the gap between a workgroup's exit and its successor's start (the launch of 9 waves of tiles takes ~5 us per wave longer
+// than 9 workgroup lifetimes).  Here the first two K tiles of the NEXT tile are requested (LDS-DMA into the idle operand
+// buffers) before the epilogue of the finished one starts, so they land while it stores; nothing is parked in LDS:
+//   * in the swapped-operand accumulator layout a lane holds, of output row m, the column quads {8 q + 4 wh .. + 3}.  After
+//     rounding to 16 bit a quad is two dwords; ONE v_permlane32_swap per dword between the quads q = 2 p of the upper
+//     half-wave and q = 2 p + 1 of the lower one leaves every lane with 8 CONSECUTIVE columns = one 16-byte store (lane
+//     wh = 0: columns 16 p .. + 7, wh = 1: 16 p + 8 .. + 15), so a store instruction writes 32 contiguous bytes of 32 rows:
+//     4 096 line requests per tile against 32 768 for the 8-byte direct epilogue of round 1 and ~1 000 + two LDS passes for
+//     the parked one;
+//   * stores are buffer stores: a row beyond M gets an offset beyond the descriptor's extent (dropped by the hardware), so
+//     the number of vector-memory instructions of an epilogue is a compile-time constant and the wait for the next tile's
+//     first K tile can be COUNTED (vmcnt = 16 pieces of its second K tile + the epilogue's stores) instead of draining the
+//     store queue -- vector-memory operations retire in issue order on gfx9 (loads and stores share vmcnt);
+//   * SwiGLU (two levels of the swap), the fused RoPE + KV-cache append (the rotation partner d +- 64 is accumulator
+//     [i][j +- 2] of the SAME lane and register: no exchange at all) and bias / activation / residual are done in the
+//     accumulator layout with the arithmetic and rounding points of w4_epilogue: bit-identical results.
+// Serves launches of more than one wave of tiles with N % 256 == 0, no K slices and 16-bit outputs; everything else stays on
+// gemm_bf16_w4k64_kernel (launch_w4k64).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w4p_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// two quads of 16-bit values (x = quad 2 p, y = quad 2 p + 1; two dwords each) -> this lane's 8 consecutive columns
+__device__ __forceinline__ uint4v w4p_gather8(uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1) {
+  const auto ra = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+  const auto rb = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+  return uint4v{ra[0], rb[0], ra[1], rb[1]};
+}
+
+constexpr int w4p_stores(int epi) { return epi == W4_SWIGLU ? 16 : 32; }     // buffer stores per wave and tile
+
+template <int EPI>
+__device__ __forceinline__ void w4p_epilogue(const GemmArgs& p, float16v (&acc)[4][4], char* wave_lds, int m_wave0, int n_wave0, int lane) {
+  const int wr = lane & 31, wh = lane >> 5;
+  constexpr int OOR = (int)0x80000000;                    // beyond any extent: the store is dropped, a load returns zeros
+  int mrow[4];
+  bool live[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mrow[i] = m_wave0 + i * 32 + wr;
+    live[i] = mrow[i] < p.M;
+  }
+  if (EPI == W4_SWIGLU) {
+    // 64 output columns per wave: a parked row is 128 B = 16 slots of 8 B; slot s of row r sits at s ^ (r & 15)
+    const __amdgpu_buffer_rsrc_t rc = w4p_rsrc(p.C, p.c_bytes);
+    const int rrow = lane >> 3, rch = lane & 7;           // read-back: 8 rows x 128 B per wave instruction
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float16v& c = acc[i][j];
+        uint32_t d[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float g0 = w4_acc(c, q * 4), u0 = w4_acc(c, q * 4 + 1), g1 = w4_acc(c, q * 4 + 2), u1 = w4_acc(c, q * 4 + 3);
+          const float s0 = h16lo(pack_h16x2(g0 / (1.f + __expf(-g0)), 0.f));
+          const float s1 = h16lo(pack_h16x2(g1 / (1.f + __expf(-g1)), 0.f));
+          d[q] = pack_h16x2(s0 * u0, s1 * u1);             // output columns 16 j + 4 q + 2 wh + {0, 1}
+        }
+        // quads q = 0,1 -> the 8-byte slot 4 j + wh of this row; q = 2,3 -> slot 4 j + 2 + wh
+        const auto c0 = __builtin_amdgcn_permlane32_swap(d[0], d[1], false, false);   // 4 columns: wh 0 -> [0, 4), wh 1 -> [4, 8)
+        const auto c1 = __builtin_amdgcn_permlane32_swap(d[2], d[3], false, false);   //            wh 0 -> [8, 12), wh 1 -> [12, 16)
+        *reinterpret_cast<uint2v*>(wave_lds + wr * 128 + (((4 * j + wh) ^ (wr & 15)) << 3)) = uint2v{c0[0], c0[1]};
+        *reinterpret_cast<uint2v*>(wave_lds + wr * 128 + (((4 * j + 2 + wh) ^ (wr & 15)) << 3)) = uint2v{c1[0], c1[1]};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = u * 8 + rrow;
+        // 16-byte chunk rch of row r = slots 2 rch, 2 rch + 1 -> chunk rch ^ ((r & 15) >> 1), halves swapped when r is odd
+        uint4v v = *reinterpret_cast<const uint4v*>(wave_lds + r * 128 + ((rch ^ ((r & 15) >> 1)) << 4));
+        if (r & 1) v = uint4v{v.z, v.w, v.x, v.y};
+        const int m = m_wave0 + i * 32 + r;
+        const int off = m < p.M ? (m * p.ldc + (n_wave0 >> 1) + rch * 8) * 2 : OOR;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
+      }
+    }
+    return;
+  }
+  if (EPI == W4_ROPE) {
+    // fused RoPE + KV-cache append in the accumulator layout: d = 32 jj + 8 q + 4 wh + k (< 64) is accumulator block jj, its
+    // rotation partner d + 64 block jj + 2, SAME lane and register.  32 rows at a time are rotated, parked (slot layout of the
+    // 16-bit epilogue below) and stored as whole rows of q_out / the cache.
+    const int part = n_wave0 / p.rope_HD;                // 0 q, 1 k, 2 v (wave-uniform; the wave's 128 columns are one head)
+    const int col0 = n_wave0 - part * p.rope_HD;
+    const __amdgpu_buffer_rsrc_t rc = part == 0 ? w4p_rsrc(p.rope_q, p.rq_bytes) : w4p_rsrc(part == 1 ? p.rope_k : p.rope_v, p.rkv_bytes);
+    const int rrow = lane >> 4, rch = lane & 15;          // read-back: 4 rows x 256 B per wave instruction
+    const float inv_T = 1.0f / (float)p.rope_T;           // (m + 0.5) / T never lands within 0.5 / T of an integer: exact for M < 2^20
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (part < 2) {
+        const int m = live[i] ? mrow[i] : p.M - 1;       // (table reads stay in range; the row is not stored)
+        const int b = (int)(((float)m + 0.5f) * inv_T);
+        const int tab = (p.rope_pos0 + m - b * p.rope_T) * 64 + wh * 4;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4v cs = *reinterpret_cast<const float4v*>(p.rope_cos + tab + jj * 32 + q * 8);
+            const float4v sn = *reinterpret_cast<const float4v*>(p.rope_sin + tab + jj * 32 + q * 8);
+            const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
+            float lo[4], hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              // the unfused path stored the projection in 16 bit before rotating it: keep that rounding point
+              const float a = h16lo(pack_h16x2(w4_acc(acc[i][jj], q * 4 + k), 0.f));
+              const float bb = h16lo(pack_h16x2(w4_acc(acc[i][jj + 2], q * 4 + k), 0.f));
+              lo[k] = __builtin_fmaf(a, c4[k], -(bb * s4[k]));      // rotate_half: a' = a cos - b sin
+              hi[k] = __builtin_fmaf(bb, c4[k], a * s4[k]);         //              b' = b cos + a sin
+            }
+            *reinterpret_cast<uint2v*>(wave_lds + wr * 256 + (((8 * jj + 2 * q + wh) ^ (wr & 15)) << 3)) =
+                uint2v{pack_h16x2(lo[0], lo[1]), pack_h16x2(lo[2], lo[3])};
+            *reinterpret_cast<uint2v*>(wave_lds + wr * 256 + (((8 * (jj + 2) + 2 * q + wh) ^ (wr & 15)) << 3)) =
+                uint2v{pack_h16x2(hi[0], hi[1]), pack_h16x2(hi[2], hi[3])};
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float16v& c = acc[i][j];
+            *reinterpret_cast<uint2v*>(wave_lds + wr * 256 + (((8 * j + 2 * q + wh) ^ (wr & 15)) << 3)) =
+                uint2v{pack_h16x2(w4_acc(c, q * 4), w4_acc(c, q * 4 + 1)), pack_h16x2(w4_acc(c, q * 4 + 2), w4_acc(c, q * 4 + 3))};
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = u * 4 + rrow;
+        uint4v v = *reinterpret_cast<const uint4v*>(wave_lds + r * 256 + ((rch ^ ((r & 15) >> 1)) << 4));
+        if (r & 1) v = uint4v{v.z, v.w, v.x, v.y};
+        const int m = m_wave0 + i * 32 + r;
+        const int b = (int)(((float)m + 0.5f) * inv_T);
+        const int pos = p.rope_pos0 + m - b * p.rope_T;
+        const long o = part == 0 ? (long)m * p.rope_HD + col0 + rch * 8 : (long)b * p.rope_kbatch + (long)pos * p.rope_krow + col0 + rch * 8;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rc, m < p.M ? (int)(o * 2) : OOR, 0, 0);
+      }
+    }
+    return;
+  }
+  // ---- W4_P16 (bias -> activation -> one rounding) and W4_WIDE (... -> + residual -> one rounding): 16-bit output ----
+  // a parked row is 256 B = 32 slots of 8 B; slot s of row r sits at s ^ (r & 15): the 16 lanes of a ds_write_b64 group (16
+  // rows, one slot) hit 16 different slots, the 16 lanes of a ds_read_b128 group (one row) 16 different chunks
+  const __amdgpu_buffer_rsrc_t rc = w4p_rsrc(p.C, p.c_bytes);
+  const bool has_res = EPI == W4_WIDE && p.residual != nullptr;
+  const __amdgpu_buffer_rsrc_t rr = w4p_rsrc(has_res ? (const void*)p.residual : (const void*)p.C, has_res ? p.r_bytes : 0u);
+  int rres[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rres[i] = (live[i] && has_res) ? (mrow[i] * p.ldr + n_wave0 + 4 * wh) * 2 : OOR;
+  const bool has_bias = p.bias != nullptr;
+  const int rrow = lane >> 4, rch = lane & 15;            // read-back: 4 rows x 256 B per wave instruction
+  auto run = [&](auto act_tag) {                          // the activation is a compile-time constant of each copy
+    constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4v b = {0.f, 0.f, 0.f, 0.f};
+          if (has_bias) b = *reinterpret_cast<const float4v*>(p.bias + n_wave0 + j * 32 + q * 8 + wh * 4);
+          const float16v& c = acc[i][j];
+          float v[4] = {w4_acc(c, q * 4) + b.x, w4_acc(c, q * 4 + 1) + b.y, w4_acc(c, q * 4 + 2) + b.z, w4_acc(c, q * 4 + 3) + b.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float x = v[k];
+            v[k] = ACT == 0 ? x : (ACT == 1 ? fmaxf(x, 0.f) : (ACT == 2 ? x / (1.f + __expf(-1.702f * x)) : x / (1.f + __expf(-x))));
+          }
+          if (EPI == W4_WIDE) {                           // (an absent residual reads zeros: extent 0)
+            const uint2v r0 = __builtin_amdgcn_raw_buffer_load_b64(rr, rres[i] + (j * 32 + q * 8) * 2, 0, 0);
+            v[0] += h16lo(r0.x); v[1] += h16hi(r0.x); v[2] += h16lo(r0.y); v[3] += h16hi(r0.y);
+          }
+          // columns 32 j + 8 q + 4 wh .. + 3 = slot 8 j + 2 q + wh of the row
+          *reinterpret_cast<uint2v*>(wave_lds + wr * 256 + (((8 * j + 2 * q + wh) ^ (wr & 15)) << 3)) =
+              uint2v{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3])};
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = u * 4 + rrow;
+        uint4v v = *reinterpret_cast<const uint4v*>(wave_lds + r * 256 + ((rch ^ ((r & 15) >> 1)) << 4));
+        if (r & 1) v = uint4v{v.z, v.w, v.x, v.y};
+        const int m = m_wave0 + i * 32 + r;
+        const int off = m < p.M ? (m * p.ldc + n_wave0 + rch * 8) * 2 : OOR;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
+      }
+    }
+  };
+  if (p.act == 0) run(std::integral_constant<int, 0>{});
+  else if (p.act == 1) run(std::integral_constant<int, 1>{});
+  else if (p.act == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 3>{});
+}
+
+template <int AMODE, int EPI, bool PF>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, NW = 4, BKT = 64, ROWB = 128, NP = 8;
+  constexpr int TM = 4, TN = 4;
+  constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;      // 32 KB + 32 KB per K tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];            // 2 * STAGE_BYTES = 128 KB + 4 x 8 KB of epilogue staging
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int total = p.tiles_m * p.tiles_n;                                // (no K slices in this form)
+  const int nt = p.K / BKT;
+
+  int a_voff[NP], b_voff[NP];
+  unsigned a_ok[NP];
+  int a_pitch[NP];
+  int m0 = 0, n0 = 0;
+  // work item -> tile, and the per-lane piece offsets of that tile (piece j of this wave covers rows 8 (4 j + wave) + lane / 8;
+  // lane % 8 is the 16-byte slot it writes: gemm_bf16_w4k64_kernel)
+  auto setup = [&](int item) {
+    const int q = total >> 3, r = total & 7, xcd = item & 7, idx = item >> 3;     // g4r_workgroup_tile_slice on a linear id
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int tile_m, tile_n;
+    g4r_tile_coords(wg, p.tiles_m, p.tiles_n, p.n_fastest, p.group_m, tile_m, tile_n);
+    m0 = tile_m * BM;
+    n0 = tile_n * BN;
+    // (opaque copy of the lane id: without it hipcc hoists the tile-invariant parts of the offsets out of the persistent loop
+    //  and keeps them alive through the K loop, where the convolution forms then spill)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int row = (j * NW + wave) * 8 + (ln >> 3);
+      const int kslot = (ln & 7) ^ ((row >> 1) & 7);
+      int gm = m0 + row;
+      if (gm > p.M - 1) gm = p.M - 1;
+      a_voff[j] = (gm * p.lda + kslot * 8) * 2;
+      int gn = n0 + row;
+      if (gn > p.N - 1) gn = p.N - 1;
+      b_voff[j] = (gn * p.ldw + kslot * 8) * 2;
+      a_ok[j] = 0;
+      a_pitch[j] = p.Wd * p.lda;
+      if (AMODE >= 1) {
+        int h = p.H, w = p.Wd, local = gm;
+        if (AMODE == 2) {
+          int lv = 0;
+#pragma unroll
+          for (int q2 = 1; q2 < 4; ++q2)
+            if (q2 < p.n_lvl && gm >= p.lvl_start[q2]) lv = q2;
+          h = p.lvl_h[lv]; w = p.lvl_w[lv];
+          local = gm - p.lvl_start[lv];
+          a_pitch[j] = w * p.lda;
+        }
+        const int hw = h * w;
+        const int rem = local - (local / hw) * hw;
+        const int y = rem / w, x = rem - y * w;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+          if (yy >= 0 && yy < h && xx >= 0 && xx < w) a_ok[j] |= 1u << tp;
+        }
+      }
+    }
+  };
+  // the NEXT K tile to stage (tiles are staged strictly in order): dense = a K offset; conv = (64-channel slice, group, tap),
+  // taps fastest, walked by a counter
+  int st_t = 0, st_ct = 0, st_g = 0, st_tap = 0;
+  struct TileSrc { int a_soff, w_soff, tap, dy, dx; };
+  auto next_tile = [&]() {
+    TileSrc ts;
+    ts.tap = ts.dy = ts.dx = 0;
+    ts.a_soff = ts.w_soff = st_t * BKT * 2;
+    ++st_t;
+    if (AMODE >= 1) {
+      const int c0 = st_ct * BKT;
+      ts.tap = st_tap;
+      ts.dy = st_tap / 3 - 1;
+      ts.dx = st_tap - (st_tap / 3) * 3 - 1;
+      ts.a_soff = (int)(((long)st_g * p.a_group_stride + c0) * 2);
+      ts.w_soff = ((st_g * 9 + st_tap) * p.Cin + c0) * 2;
+      if (++st_tap == 9) {
+        st_tap = 0;
+        if (++st_g == p.groups) { st_g = 0; ++st_ct; }
+      }
+    }
+    return ts;
+  };
+  auto piece = [&](int q, const TileSrc& ts, int buf) {
+    char* sa = smem + buf * STAGE_BYTES;
+    if (q < NP) {
+      int voff = a_voff[q];
+      if (AMODE == 1) voff += (ts.dy * p.Wd + ts.dx) * p.lda * 2;
+      if (AMODE == 2) voff += (ts.dy * a_pitch[q] + ts.dx * p.lda) * 2;
+      if (AMODE >= 1 && !((a_ok[q] >> ts.tap) & 1u)) voff = (int)0x80000000;      // beyond num_records: reads as zeros
+      g4r_buffer_piece(p.A, p.a_bytes, sa + (q * NW + wave) * 1024, voff, ts.a_soff);
+    } else {
+      g4r_buffer_piece(p.W, p.w_bytes, sa + A_BYTES + ((q - NP) * NW + wave) * 1024, b_voff[q - NP], ts.w_soff);
+    }
+  };
+  // the first two K tiles of the tile `setup` prepared: 16 + 16 pieces into buffers 0 / 1
+  auto prologue = [&]() {
+    st_t = st_ct = st_g = st_tap = 0;
+    {
+      const TileSrc ts = next_tile();
+#pragma unroll
+      for (int q = 0; q < 2 * NP; ++q) piece(q, ts, 0);
+    }
+    if (nt > 1) {
+      const TileSrc ts = next_tile();
+#pragma unroll
+      for (int q = 0; q < 2 * NP; ++q) piece(q, ts, 1);
+    }
+  };
+  float16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frow = lane & 31, fsw = (frow >> 1) & 7, fhi = lane >> 5;
+  const int a_row_off = (wm * 128 + frow) * ROWB;
+  const int b_row_off = A_BYTES + (wn * 128 + frow) * ROWB;
+  h16x8 fa[4][TM], fw[4][TN];                  // [k-step][block]: k-steps 0,1 = H0, 2,3 = H1
+  auto ldfrag = [&](auto ks_tag, int buf) {
+    constexpr int ks = decltype(ks_tag)::value;
+    const char* sb = smem + buf * STAGE_BYTES;
+    const int slot = ((2 * ks + fhi) ^ fsw) << 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const h16x8*>(sb + a_row_off + i * 32 * ROWB + slot);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fw[ks][j] = *reinterpret_cast<const h16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
+  };
+  auto mma_rows = [&](auto ks_tag, auto i0_tag, auto i1_tag) {    // rows [i0, i1) of k-step ks
+    constexpr int ks = decltype(ks_tag)::value, i0 = decltype(i0_tag)::value, i1 = decltype(i1_tag)::value;
+#pragma unroll
+    for (int i = i0; i < i1; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = G4R_MFMA_32X32X16(fw[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
+  // the K-tile body of gemm_bf16_w4k64_kernel (phases A / B / C, see there), unchanged
+  // RELAX: the epilogue's stores of the previous output tile sit between K tile 1's pieces and K tile 2's in the (in-order)
+  // vector-memory queue; the wait for K tile 1 at the end of phase B of K tile 0 may leave them in flight (RELAX = their
+  // number), which gives them two K tiles (~4.4 k cycles) to drain behind the matrix pipe instead of one phase
+  auto body = [&](int i, auto steady_tag, auto relax_tag) {
+    constexpr bool STEADY = decltype(steady_tag)::value;      // tiles i+1, i+2 exist: no branches in the body
+    constexpr int RELAX = decltype(relax_tag)::value;
+    const int buf = i & 1;
+    ldfrag(I2{}, buf);
+    ldfrag(I3{}, buf);
+    mma_rows(I0{}, I0{}, I4{});
+    mma_rows(I1{}, I0{}, I1{});
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): every fragment of X is in registers
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                            // ... in every wave: X may be overwritten
+    __builtin_amdgcn_sched_barrier(0);
+    TileSrc ts2 = {};
+    const bool more = STEADY || i + 2 < nt;
+    if (more) {
+      ts2 = next_tile();
+#pragma unroll
+      for (int q = 0; q < 12; ++q) piece(q, ts2, buf);
+    }
+    mma_rows(I1{}, I1{}, I4{});
+    mma_rows(I2{}, I0{}, I3{});
+    if (STEADY) {
+#pragma unroll
+      for (int n = 0; n < 12; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 2, 1);
+        __builtin_amdgcn_sched_group_barrier(0x10, 1, 1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      if (RELAX == 32) __builtin_amdgcn_s_waitcnt(0x8f7c);   // vmcnt(44): tile i+1 has landed; 32 stores + this tile's 12 pieces may be in flight
+      else if (RELAX == 16) __builtin_amdgcn_s_waitcnt(0x4f7c);   // vmcnt(28)
+      else __builtin_amdgcn_s_waitcnt(0x0f7c);               // vmcnt(12): tile i+1 has landed (and every older store has retired)
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0)
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (STEADY || i + 1 < nt) {
+      ldfrag(I0{}, buf ^ 1);
+      ldfrag(I1{}, buf ^ 1);
+    }
+    if (more) {
+#pragma unroll
+      for (int q = 12; q < 16; ++q) piece(q, ts2, buf);
+    }
+    mma_rows(I2{}, I3{}, I4{});
+    mma_rows(I3{}, I0{}, I4{});
+    if (STEADY) {
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 2);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
+      }
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 2);
+        __builtin_amdgcn_sched_group_barrier(0x10, 1, 2);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // PF ("pieces first"): epilogues without loads of their own (no bias, no residual, no tables) run BEHIND the next tile's
+  // pieces, which land while they store.  The others run first: next to an LDS-DMA in flight hipcc waits vmcnt(0) before the
+  // first use of any ordinary load (cdna_hip_programming.md section 5), which would stall the epilogue until the pieces have
+  // landed.  (The epilogue sits at the loop's END: with it at the head hipcc moves all 256 accumulators to VGPRs and spills.)
+  int item = blockIdx.x;
+  setup(item);
+  prologue();
+  // vector-memory operations issued AFTER the first K tile's 16 pieces when the loop is entered: the second K tile's 16
+  // pieces and, when the epilogue ran behind the pieces, its stores (a compile-time count: a row beyond M is a dropped
+  // store, not a skipped one).  They retire in issue order (loads and stores share vmcnt on gfx9), so at most that many
+  // outstanding = the first K tile has landed.
+  int behind = nt > 1 ? 16 : 0;
+  for (;;) {
+    if (behind >= 48) __builtin_amdgcn_s_waitcnt(0xcf70);        // vmcnt(48)
+    else if (behind >= 32) __builtin_amdgcn_s_waitcnt(0x8f70);   // vmcnt(32)
+    else if (behind >= 16) __builtin_amdgcn_s_waitcnt(0x4f70);   // vmcnt(16)
+    else __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ldfrag(I0{}, 0);
+    ldfrag(I1{}, 0);
+    int i = 0;
+    if (PF && behind > 16 && nt > 2) {                           // (behind > 16: an epilogue's stores are in the queue)
+      body(0, std::true_type{}, std::integral_constant<int, PF ? w4p_stores(EPI) : 0>{});
+      i = 1;
+    }
+    for (; i + 2 < nt; ++i) body(i, std::true_type{}, I0{});
+    for (; i < nt; ++i) body(i, std::false_type{}, I0{});
+    // every wave has read its last fragments (phase A of the last K tile ends in a barrier) and no piece is in flight: the
+    // operand buffers are idle
+    const int em = m0 + wm * 128, en = n0 + wn * 128;
+    const int next = item + (int)gridDim.x;
+    const bool has_next = next < total;
+    if (PF && has_next) {
+      setup(next);
+      prologue();
+    }
+    w4p_epilogue<EPI>(p, acc, smem + 2 * STAGE_BYTES + wave * 8192, em, en, lane);
+    if (!has_next) break;
+#pragma unroll
+    for (int i2 = 0; i2 < TM; ++i2)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i2][j][r] = 0.f;
+    if (!PF) {
+      setup(next);
+      prologue();
+    }
+    behind = (nt > 1 ? 16 : 0) + (PF ? w4p_stores(EPI) : 0);
+    item = next;
+  }
+}
+
+template <int AMODE, int EPI, bool PF>
+int launch_w4k64p_epi(GemmArgs& p, int grid, hipStream_t stream) {
+  const size_t lds = 2 * (256 + 256) * 64 * 2 + 4 * 8192;        // the operand ring + 8 KB of epilogue staging per wave = all 160 KB
+  auto kern = gemm_bf16_w4k64p_kernel<AMODE, EPI, PF>;
+  static G4rPerDeviceOnce attr_set;
+  if (attr_set.first()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { attr_set.failed(); return g4r_note_hip_error(e, "gemm_w4k64p: hipFuncSetAttribute"); }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+  G4R_CHECK_LAUNCH("gemm_bf16_w4k64p");
+  return G4R_OK;
+}
+
+// workgroups of the persistent form = CUs of the device (one workgroup of 256 AGPRs + 128 KB LDS per CU)
+static int g4r_cu_count() {
+  static int n[64] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return 256;
+  if (n[d] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+    n[d] = v;
+  }
+  return n[d];
+}
+
 template <int AMODE, bool PROBE = false, int BM = 256, int BN = 256, bool BUF = true, int SCHED = 0>
 int launch_pp32(GemmArgs& p, hipStream_t stream);      // (defined below: the fallback for operands beyond a buffer descriptor)
 
@@ -2496,6 +3001,38 @@ int launch_w4k64(GemmArgs& p, hipStream_t stream) {
       mode = wide ? W4_WIDE : (p.act == 4 ? W4_SWIGLU : W4_P16);
   }
   if (p.act == 5 && mode != W4_ROPE) return g4r_note_error(G4R_ERR_INVALID_ARG, "gemm_w4k64: the fused RoPE epilogue needs N % 8 == 0");
+  // Round 6: launches of more than one wave of tiles take the PERSISTENT form (gemm_bf16_w4k64p_kernel: one workgroup per CU
+  // walks the tiles, the next tile's first K tiles land during the epilogue, which stores straight from the accumulators).
+  // tools: debug mode 61 = off (A/B arm; the bit-identity tests compare the two forms).
+  if (!PROBE && g_gemm_dbg != 61 && p.splits == 1 && (p.N % 256) == 0 && !p.out_f32 && (p.ldc & 7) == 0) {
+    const int ncu = g4r_cu_count();
+    const long tiles = (long)p.tiles_m * p.tiles_n;
+    const bool mode_ok = mode == W4_P16 || mode == W4_SWIGLU || mode == W4_ROPE || (mode == W4_WIDE && p.residual != nullptr);
+    size_t cb = (size_t)p.M * p.ldc * 2, rb = p.residual ? (size_t)p.M * p.ldr * 2 : 0, rq = 0, rkv = 0;
+    if (mode == W4_ROPE) {
+      const long nb = p.M / p.rope_T;
+      rq = (size_t)p.M * p.rope_HD * 2;
+      rkv = (size_t)((nb - 1) * p.rope_kbatch + (long)(p.rope_pos0 + p.rope_T - 1) * p.rope_krow + p.rope_HD) * 2;
+      cb = rq;
+    }
+    if (mode_ok && tiles > ncu && p.M < (1 << 20) && cb < 0x7fffffffu && rb < 0x7fffffffu && rq < 0x7fffffffu && rkv < 0x7fffffffu) {
+      p.c_bytes = (unsigned)cb; p.r_bytes = (unsigned)rb; p.rq_bytes = (unsigned)rq; p.rkv_bytes = (unsigned)rkv;
+      if (AMODE != 0) {
+        // (the convolution forms of the persistent kernel do not fit hipcc's register allocation yet: one accumulator block ends
+        //  up in VGPRs with 32 v_accvgpr moves per K tile; they stay on gemm_bf16_w4k64_kernel)
+      } else {
+        switch (mode) {
+          // (with a bias the epilogue has loads of its own and must run AHEAD of the next tile's pieces: measured 7-9 % slower
+          //  than the per-tile form on the K = 1024 ViT shapes, profiles/r06_persist_ab.txt -- those stay per tile)
+          case W4_P16: if (p.bias == nullptr) return launch_w4k64p_epi<0, W4_P16, true>(p, ncu, stream);
+                       break;
+          case W4_SWIGLU: return launch_w4k64p_epi<0, W4_SWIGLU, true>(p, ncu, stream);
+          case W4_ROPE: return launch_w4k64p_epi<0, W4_ROPE, false>(p, ncu, stream);
+          default: return launch_w4k64p_epi<0, W4_WIDE, false>(p, ncu, stream);
+        }
+      }
+    }
+  }
   int rc = G4R_OK;
   if (AMODE != 0) {                       // the convolutions: bias / ReLU only
     rc = (mode == W4_P16) ? launch_w4k64_epi<AMODE, false, W4_P16>(p, stream)

@@ -139,6 +139,91 @@ def test_conv_over_all_levels_one_wave_per_simd_vs_ring_kernel():
     assert rel(got, ref) < TOL[torch.bfloat16] and rel(got, ring) < TOL[torch.bfloat16]
 
 
+# ------------------------------------------------------------------------------------------ the persistent form (round 6)
+# Launches of MORE than one wave of 256 x 256 tiles with N % 256 == 0 run gemm_bf16_w4k64p_kernel: one workgroup per CU walks
+# the tiles, the next tile's first K tiles are requested before the epilogue, which stores straight from the accumulators
+# (v_permlane32_swap pairs -> 16-byte buffer stores).  Same K order and rounding points: bit-identical to the ring tile 24.
+PERSIST_SHAPES = [(4100, 4096, 192), (4353, 4096, 64), (8200, 2304, 128), (4352, 4352, 320)]      # 272 / 288 / 297 / 289 tiles; ragged last row tiles
+
+
+def _tiles(M, N):
+    return -(-M // 256) * -(-N // 256)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,Kd", PERSIST_SHAPES)
+def test_persistent_form_plain_and_bias_activation(M, N, Kd, dtype):
+    """W4_P16 behind the next tile's pieces (no bias) and ahead of them (bias + every activation); one, two, three, five K tiles"""
+    assert _tiles(M, N) > 256 and N % 256 == 0
+    a, w = rnd(M, Kd, seed=60, dtype=dtype), rnd(N, Kd, seed=61, scale=0.2, dtype=dtype)
+    got = K.gemm(a, w, tile_cfg=34)
+    assert torch.equal(got, K.gemm(a, w, tile_cfg=24))
+    assert rel(got, a.float() @ w.float().t()) < TOL[dtype]
+    bias = rnd(N, seed=62, dtype=torch.float32)
+    for act in (None, "relu", "quick_gelu", "silu"):
+        assert torch.equal(K.gemm(a, w, bias=bias, act=act, tile_cfg=34), K.gemm(a, w, bias=bias, act=act, tile_cfg=24)), act
+    # a strided output view: rows 16-byte aligned, nothing written outside it
+    big = torch.zeros(M, N + 64, dtype=dtype, device=DEV)
+    K.gemm(a, w, out=big[:, 32:32 + N], tile_cfg=34)
+    assert torch.equal(big[:, 32:32 + N], got) and float(big[:, :32].abs().max()) == 0 and float(big[:, 32 + N:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,Kd", PERSIST_SHAPES[:3])
+def test_persistent_form_residual_and_swiglu(M, N, Kd, dtype):
+    a, w = rnd(M, Kd, seed=63, dtype=dtype), rnd(N, Kd, seed=64, scale=0.2, dtype=dtype)
+    bias, res = rnd(N, seed=65, dtype=torch.float32), rnd(M, N, seed=66, dtype=dtype)
+    for b_, act in ((None, None), (bias, "silu"), (bias, "quick_gelu")):
+        got = K.gemm(a, w, bias=b_, residual=res, act=act, tile_cfg=34)
+        assert torch.equal(got, K.gemm(a, w, bias=b_, residual=res, act=act, tile_cfg=24)), act
+    # in place (x += a @ w^T, as o_proj / down_proj update the residual stream)
+    x = res.clone()
+    K.gemm(a, w, residual=x, out=x, tile_cfg=34)
+    assert torch.equal(x, K.gemm(a, w, residual=res, tile_cfg=24))
+    r = a.float() @ w.float().t() + res.float()
+    assert rel(x, r) < 2 * TOL[dtype]
+    sw = K.gemm(a, w, act="swiglu", tile_cfg=34)
+    assert sw.shape == (M, N // 2) and torch.equal(sw, K.gemm(a, w, act="swiglu", tile_cfg=24))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T,heads,pos0", [(3, 1950, 8, 7), (5, 767, 12, 0)])
+def test_persistent_form_fused_qkv_rope(B, T, heads, pos0, dtype):
+    """W4_ROPE in the accumulator layout (the rotation partner d +- 64 is accumulator block j +- 2 of the same lane): q, rotated k
+    and v rows against the ring tile's LDS-staged epilogue, several sequences, a last row tile that is mostly empty"""
+    HD = heads * 128
+    assert _tiles(B * T, 3 * HD) > 256
+    h, wqkv = rnd(B * T, 128, seed=67, dtype=dtype), rnd(3 * HD, 128, seed=68, dtype=dtype)
+    ang = torch.rand(2048, 64, generator=torch.Generator().manual_seed(69)) * 6.28
+    cos, sin = ang.cos().contiguous().to(DEV), ang.sin().contiguous().to(DEV)
+    outs = {}
+    for t in (24, 34):
+        q = torch.zeros(B, T, HD, dtype=dtype, device=DEV)
+        kc = torch.zeros(B, 2048, HD, dtype=dtype, device=DEV)
+        vc = torch.zeros(B, 2048, HD, dtype=dtype, device=DEV)
+        assert K.gemm_qkv_rope(h, wqkv, B, T, heads, 128, q, kc, vc, cos, sin, pos0, tile_cfg=t) is not None
+        outs[t] = (q, kc, vc)
+    for x, y in zip(outs[24], outs[34]):
+        assert torch.equal(x, y)
+    assert (outs[34][0] != 0).float().mean() > 0.9
+
+
+def test_persistent_form_is_what_the_merged_llama_shapes_run():
+    """the dispatch of the benchmarked step: M = 16 x 767 rows through q|k|v, o_proj, gate|up (main part) and down_proj all
+    qualify (more than 256 tiles, N % 256 == 0); the same problems against fp32 torch on sampled rows"""
+    M, dtype = 12272, torch.float16
+    a = rnd(M, 4096, seed=70, dtype=dtype)
+    rows = torch.tensor([0, 255, 256, 6000, 12031, 12032, M - 1], device=DEV)
+    for N, Kd, kw in ((4096, 4096, {}), (21760, 4096, {"act": "swiglu"})):
+        assert _tiles(M, N) > 256 and N % 256 == 0
+        w = rnd(N, Kd, seed=71, scale=0.02, dtype=dtype)
+        got = K.gemm(a, w, tile_cfg=34, **kw)
+        y = a[rows].float() @ w.float().t()
+        ref = F.silu(y[:, 0::2]).to(dtype).float() * y[:, 1::2] if kw else y
+        assert rel(got[rows], ref) < 3 * TOL[dtype]
+        assert torch.equal(got, K.gemm(a, w, tile_cfg=24, **kw))
+
+
 def test_operands_of_2_GiB_and_more_fall_back_to_the_ring_tile():
     """tile 34 addresses its operands through buffer descriptors (32-bit extents).  An activation matrix
     of 2 GiB and more -- the stage-2 data gradient dgu[tokens, 22016] x W^T above ~48.7 k tokens -- must run (on the ring
