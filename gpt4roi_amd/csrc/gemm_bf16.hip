@@ -2493,21 +2493,40 @@ __device__ __forceinline__ uint4v w4p_gather8(uint32_t x0, uint32_t x1, uint32_t
 
 constexpr int w4p_stores(int epi) { return epi == W4_SWIGLU ? 16 : 32; }     // buffer stores per wave and tile
 
+// Epilogue of the persistent form, phase 1: accumulators -> final 16-bit values (bias / activation / residual / SwiGLU / RoPE in
+// the accumulator layout, the arithmetic and rounding points of w4_epilogue), transposed 32 rows at a time through the wave's
+// 8 KB of spare LDS into ROW-major 16-byte chunks: chunk (lane % LPR) of row 32 i + RPI u + lane / LPR of the wave tile (LPR = 16
+// lanes per 256-byte row, RPI = 4 rows per instruction; SwiGLU: 8 and 8) goes back into the accumulator registers of pass i,
+// which are dead by then -- acc[i][u / 4][4 (u % 4) .. + 3] -- so the finished tile waits for its stores in AGPRs and costs no
+// VGPRs while the next tile's offsets are computed and its pieces issued.
+// Every ordinary load and every LDS operation of the epilogue happens HERE, i.e. before the next tile's LDS-DMA pieces are
+// issued: an LDS instruction behind a wave's own pieces waits until they have landed, and hipcc waits vmcnt(0) for an ordinary
+// load next to an LDS-DMA in flight.  A parked row is 32 (SwiGLU: 16) slots of 8 B; slot s of row r sits at s ^ (r & 15): the
+// 16 lanes of a ds_write_b64 group (16 rows, one slot) hit 16 different slots, the 16 lanes of a ds_read_b128 group (one row) 16
+// different chunks.
 template <int EPI>
-__device__ __forceinline__ void w4p_epilogue(const GemmArgs& p, float16v (&acc)[4][4], char* wave_lds, int m_wave0, int n_wave0, int lane) {
+__device__ __forceinline__ void w4p_epilogue_compute(const GemmArgs& p, float16v (&acc)[4][4], char* wave_lds, int m_wave0, int n_wave0,
+                                                     int lane) {
   const int wr = lane & 31, wh = lane >> 5;
-  constexpr int OOR = (int)0x80000000;                    // beyond any extent: the store is dropped, a load returns zeros
-  int mrow[4];
-  bool live[4];
+  constexpr int OOR = (int)0x80000000;                    // beyond any extent: a load returns zeros
+  constexpr int RB = EPI == W4_SWIGLU ? 128 : 256;        // parked row bytes
+  constexpr int LPR = RB / 16, RPI = 64 / LPR, NU = 32 / RPI;
+  const int rrow = lane / LPR, rch = lane % LPR;
+  auto read_back = [&](int i) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    mrow[i] = m_wave0 + i * 32 + wr;
-    live[i] = mrow[i] < p.M;
-  }
+    for (int u = 0; u < NU; ++u) {
+      const int r = u * RPI + rrow;
+      // 16-byte chunk rch of row r = slots 2 rch, 2 rch + 1 -> chunk rch ^ ((r & 15) >> 1), halves swapped when r is odd
+      uint4v v = *reinterpret_cast<const uint4v*>(wave_lds + r * RB + ((rch ^ ((r & 15) >> 1)) << 4));
+      if (r & 1) v = uint4v{v.z, v.w, v.x, v.y};
+      float16v& dst = acc[i][u >> 2];
+      dst[(u & 3) * 4 + 0] = __uint_as_float(v.x);
+      dst[(u & 3) * 4 + 1] = __uint_as_float(v.y);
+      dst[(u & 3) * 4 + 2] = __uint_as_float(v.z);
+      dst[(u & 3) * 4 + 3] = __uint_as_float(v.w);
+    }
+  };
   if (EPI == W4_SWIGLU) {
-    // 64 output columns per wave: a parked row is 128 B = 16 slots of 8 B; slot s of row r sits at s ^ (r & 15)
-    const __amdgpu_buffer_rsrc_t rc = w4p_rsrc(p.C, p.c_bytes);
-    const int rrow = lane >> 3, rch = lane & 7;           // read-back: 8 rows x 128 B per wave instruction
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -2521,47 +2540,39 @@ __device__ __forceinline__ void w4p_epilogue(const GemmArgs& p, float16v (&acc)[
           const float s1 = h16lo(pack_h16x2(g1 / (1.f + __expf(-g1)), 0.f));
           d[q] = pack_h16x2(s0 * u0, s1 * u1);             // output columns 16 j + 4 q + 2 wh + {0, 1}
         }
-        // quads q = 0,1 -> the 8-byte slot 4 j + wh of this row; q = 2,3 -> slot 4 j + 2 + wh
-        const auto c0 = __builtin_amdgcn_permlane32_swap(d[0], d[1], false, false);   // 4 columns: wh 0 -> [0, 4), wh 1 -> [4, 8)
-        const auto c1 = __builtin_amdgcn_permlane32_swap(d[2], d[3], false, false);   //            wh 0 -> [8, 12), wh 1 -> [12, 16)
-        *reinterpret_cast<uint2v*>(wave_lds + wr * 128 + (((4 * j + wh) ^ (wr & 15)) << 3)) = uint2v{c0[0], c0[1]};
-        *reinterpret_cast<uint2v*>(wave_lds + wr * 128 + (((4 * j + 2 + wh) ^ (wr & 15)) << 3)) = uint2v{c1[0], c1[1]};
+        // quads q = 0,1 -> the 8-byte slot 4 j + wh of this row (4 consecutive outputs); q = 2,3 -> slot 4 j + 2 + wh
+        const auto c0 = __builtin_amdgcn_permlane32_swap(d[0], d[1], false, false);
+        const auto c1 = __builtin_amdgcn_permlane32_swap(d[2], d[3], false, false);
+        *reinterpret_cast<uint2v*>(wave_lds + wr * RB + (((4 * j + wh) ^ (wr & 15)) << 3)) = uint2v{c0[0], c0[1]};
+        *reinterpret_cast<uint2v*>(wave_lds + wr * RB + (((4 * j + 2 + wh) ^ (wr & 15)) << 3)) = uint2v{c1[0], c1[1]};
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int r = u * 8 + rrow;
-        // 16-byte chunk rch of row r = slots 2 rch, 2 rch + 1 -> chunk rch ^ ((r & 15) >> 1), halves swapped when r is odd
-        uint4v v = *reinterpret_cast<const uint4v*>(wave_lds + r * 128 + ((rch ^ ((r & 15) >> 1)) << 4));
-        if (r & 1) v = uint4v{v.z, v.w, v.x, v.y};
-        const int m = m_wave0 + i * 32 + r;
-        const int off = m < p.M ? (m * p.ldc + (n_wave0 >> 1) + rch * 8) * 2 : OOR;
-        __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
-      }
+      read_back(i);
     }
     return;
   }
   if (EPI == W4_ROPE) {
-    // fused RoPE + KV-cache append in the accumulator layout: d = 32 jj + 8 q + 4 wh + k (< 64) is accumulator block jj, its
-    // rotation partner d + 64 block jj + 2, SAME lane and register.  32 rows at a time are rotated, parked (slot layout of the
-    // 16-bit epilogue below) and stored as whole rows of q_out / the cache.
+    // d = 32 jj + 8 q + 4 wh + k (< 64) is accumulator block jj, its rotation partner d + 64 block jj + 2, SAME lane and register
     const int part = n_wave0 / p.rope_HD;                // 0 q, 1 k, 2 v (wave-uniform; the wave's 128 columns are one head)
-    const int col0 = n_wave0 - part * p.rope_HD;
-    const __amdgpu_buffer_rsrc_t rc = part == 0 ? w4p_rsrc(p.rope_q, p.rq_bytes) : w4p_rsrc(part == 1 ? p.rope_k : p.rope_v, p.rkv_bytes);
-    const int rrow = lane >> 4, rch = lane & 15;          // read-back: 4 rows x 256 B per wave instruction
-    const float inv_T = 1.0f / (float)p.rope_T;           // (m + 0.5) / T never lands within 0.5 / T of an integer: exact for M < 2^20
+    const float inv_T = 1.0f / (float)p.rope_T;          // (m + 0.5) / T never lands within 0.5 / T of an integer: exact for M < 2^20
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (part < 2) {
-        const int m = live[i] ? mrow[i] : p.M - 1;       // (table reads stay in range; the row is not stored)
+        int m = m_wave0 + i * 32 + wr;
+        if (m > p.M - 1) m = p.M - 1;                    // (table reads stay in range; the row is not stored)
         const int b = (int)(((float)m + 0.5f) * inv_T);
         const int tab = (p.rope_pos0 + m - b * p.rope_T) * 64 + wh * 4;
+        float4v cs[8], sn[8];                            // this pass's table entries, all in flight together
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          cs[e] = *reinterpret_cast<const float4v*>(p.rope_cos + tab + e * 8);
+          sn[e] = *reinterpret_cast<const float4v*>(p.rope_sin + tab + e * 8);
+        }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float4v cs = *reinterpret_cast<const float4v*>(p.rope_cos + tab + jj * 32 + q * 8);
-            const float4v sn = *reinterpret_cast<const float4v*>(p.rope_sin + tab + jj * 32 + q * 8);
-            const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
+            const float4v c_ = cs[jj * 4 + q], s_ = sn[jj * 4 + q];
+            const float c4[4] = {c_.x, c_.y, c_.z, c_.w}, s4[4] = {s_.x, s_.y, s_.z, s_.w};
             float lo[4], hi[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -2571,9 +2582,9 @@ __device__ __forceinline__ void w4p_epilogue(const GemmArgs& p, float16v (&acc)[
               lo[k] = __builtin_fmaf(a, c4[k], -(bb * s4[k]));      // rotate_half: a' = a cos - b sin
               hi[k] = __builtin_fmaf(bb, c4[k], a * s4[k]);         //              b' = b cos + a sin
             }
-            *reinterpret_cast<uint2v*>(wave_lds + wr * 256 + (((8 * jj + 2 * q + wh) ^ (wr & 15)) << 3)) =
+            *reinterpret_cast<uint2v*>(wave_lds + wr * RB + (((8 * jj + 2 * q + wh) ^ (wr & 15)) << 3)) =
                 uint2v{pack_h16x2(lo[0], lo[1]), pack_h16x2(lo[2], lo[3])};
-            *reinterpret_cast<uint2v*>(wave_lds + wr * 256 + (((8 * (jj + 2) + 2 * q + wh) ^ (wr & 15)) << 3)) =
+            *reinterpret_cast<uint2v*>(wave_lds + wr * RB + (((8 * (jj + 2) + 2 * q + wh) ^ (wr & 15)) << 3)) =
                 uint2v{pack_h16x2(hi[0], hi[1]), pack_h16x2(hi[2], hi[3])};
           }
       } else {
@@ -2582,78 +2593,111 @@ __device__ __forceinline__ void w4p_epilogue(const GemmArgs& p, float16v (&acc)[
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float16v& c = acc[i][j];
-            *reinterpret_cast<uint2v*>(wave_lds + wr * 256 + (((8 * j + 2 * q + wh) ^ (wr & 15)) << 3)) =
+            *reinterpret_cast<uint2v*>(wave_lds + wr * RB + (((8 * j + 2 * q + wh) ^ (wr & 15)) << 3)) =
                 uint2v{pack_h16x2(w4_acc(c, q * 4), w4_acc(c, q * 4 + 1)), pack_h16x2(w4_acc(c, q * 4 + 2), w4_acc(c, q * 4 + 3))};
           }
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = u * 4 + rrow;
-        uint4v v = *reinterpret_cast<const uint4v*>(wave_lds + r * 256 + ((rch ^ ((r & 15) >> 1)) << 4));
-        if (r & 1) v = uint4v{v.z, v.w, v.x, v.y};
-        const int m = m_wave0 + i * 32 + r;
-        const int b = (int)(((float)m + 0.5f) * inv_T);
-        const int pos = p.rope_pos0 + m - b * p.rope_T;
-        const long o = part == 0 ? (long)m * p.rope_HD + col0 + rch * 8 : (long)b * p.rope_kbatch + (long)pos * p.rope_krow + col0 + rch * 8;
-        __builtin_amdgcn_raw_buffer_store_b128(v, rc, m < p.M ? (int)(o * 2) : OOR, 0, 0);
-      }
+      read_back(i);
     }
     return;
   }
   // ---- W4_P16 (bias -> activation -> one rounding) and W4_WIDE (... -> + residual -> one rounding): 16-bit output ----
-  // a parked row is 256 B = 32 slots of 8 B; slot s of row r sits at s ^ (r & 15): the 16 lanes of a ds_write_b64 group (16
-  // rows, one slot) hit 16 different slots, the 16 lanes of a ds_read_b128 group (one row) 16 different chunks
-  const __amdgpu_buffer_rsrc_t rc = w4p_rsrc(p.C, p.c_bytes);
   const bool has_res = EPI == W4_WIDE && p.residual != nullptr;
   const __amdgpu_buffer_rsrc_t rr = w4p_rsrc(has_res ? (const void*)p.residual : (const void*)p.C, has_res ? p.r_bytes : 0u);
-  int rres[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) rres[i] = (live[i] && has_res) ? (mrow[i] * p.ldr + n_wave0 + 4 * wh) * 2 : OOR;
   const bool has_bias = p.bias != nullptr;
-  const int rrow = lane >> 4, rch = lane & 15;            // read-back: 4 rows x 256 B per wave instruction
-  auto run = [&](auto act_tag) {                          // the activation is a compile-time constant of each copy
-    constexpr int ACT = decltype(act_tag)::value;
+  auto run = [&](auto act_tag, auto bias_tag) {           // activation and bias are compile-time constants of each copy:
+    constexpr int ACT = decltype(act_tag)::value;         // straight-line code (a branch per quad costs more than the quad)
+    constexpr bool BIAS = decltype(bias_tag)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      uint2v res[16];                                     // this pass's residual quads, all in flight together
+      if (EPI == W4_WIDE) {
+        const int m = m_wave0 + i * 32 + wr;
+        const int roff = (m < p.M && has_res) ? (m * p.ldr + n_wave0 + 4 * wh) * 2 : OOR;     // (absent / beyond M: zeros)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) res[e] = __builtin_amdgcn_raw_buffer_load_b64(rr, roff + e * 16, 0, 0);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float4v b = {0.f, 0.f, 0.f, 0.f};
-          if (has_bias) b = *reinterpret_cast<const float4v*>(p.bias + n_wave0 + j * 32 + q * 8 + wh * 4);
           const float16v& c = acc[i][j];
-          float v[4] = {w4_acc(c, q * 4) + b.x, w4_acc(c, q * 4 + 1) + b.y, w4_acc(c, q * 4 + 2) + b.z, w4_acc(c, q * 4 + 3) + b.w};
+          // (+ 0.f: the per-tile form always adds its bias quad, zeros when absent -- keeps -0 -> +0 bit-identical)
+          float v[4] = {w4_acc(c, q * 4) + 0.f, w4_acc(c, q * 4 + 1) + 0.f, w4_acc(c, q * 4 + 2) + 0.f, w4_acc(c, q * 4 + 3) + 0.f};
+          if (BIAS) {
+            const float4v b = *reinterpret_cast<const float4v*>(p.bias + n_wave0 + j * 32 + q * 8 + wh * 4);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+          }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float x = v[k];
             v[k] = ACT == 0 ? x : (ACT == 1 ? fmaxf(x, 0.f) : (ACT == 2 ? x / (1.f + __expf(-1.702f * x)) : x / (1.f + __expf(-x))));
           }
-          if (EPI == W4_WIDE) {                           // (an absent residual reads zeros: extent 0)
-            const uint2v r0 = __builtin_amdgcn_raw_buffer_load_b64(rr, rres[i] + (j * 32 + q * 8) * 2, 0, 0);
+          if (EPI == W4_WIDE) {
+            const uint2v r0 = res[j * 4 + q];
             v[0] += h16lo(r0.x); v[1] += h16hi(r0.x); v[2] += h16lo(r0.y); v[3] += h16hi(r0.y);
           }
           // columns 32 j + 8 q + 4 wh .. + 3 = slot 8 j + 2 q + wh of the row
-          *reinterpret_cast<uint2v*>(wave_lds + wr * 256 + (((8 * j + 2 * q + wh) ^ (wr & 15)) << 3)) =
+          *reinterpret_cast<uint2v*>(wave_lds + wr * RB + (((8 * j + 2 * q + wh) ^ (wr & 15)) << 3)) =
               uint2v{pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3])};
         }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = u * 4 + rrow;
-        uint4v v = *reinterpret_cast<const uint4v*>(wave_lds + r * 256 + ((rch ^ ((r & 15) >> 1)) << 4));
-        if (r & 1) v = uint4v{v.z, v.w, v.x, v.y};
-        const int m = m_wave0 + i * 32 + r;
-        const int off = m < p.M ? (m * p.ldc + n_wave0 + rch * 8) * 2 : OOR;
-        __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
-      }
+      read_back(i);
     }
   };
-  if (p.act == 0) run(std::integral_constant<int, 0>{});
-  else if (p.act == 1) run(std::integral_constant<int, 1>{});
-  else if (p.act == 2) run(std::integral_constant<int, 2>{});
-  else run(std::integral_constant<int, 3>{});
+  if (has_bias) {
+    if (p.act == 0) run(std::integral_constant<int, 0>{}, std::true_type{});
+    else if (p.act == 1) run(std::integral_constant<int, 1>{}, std::true_type{});
+    else if (p.act == 2) run(std::integral_constant<int, 2>{}, std::true_type{});
+    else run(std::integral_constant<int, 3>{}, std::true_type{});
+  } else {
+    if (p.act == 0) run(std::integral_constant<int, 0>{}, std::false_type{});
+    else if (p.act == 1) run(std::integral_constant<int, 1>{}, std::false_type{});
+    else if (p.act == 2) run(std::integral_constant<int, 2>{}, std::false_type{});
+    else run(std::integral_constant<int, 3>{}, std::false_type{});
+  }
 }
 
-template <int AMODE, int EPI, bool PF>
+// Phase 2: the 32 (SwiGLU: 16) whole-row buffer stores of a wave tile.  A row beyond M gets an offset beyond the descriptor's
+// extent (dropped by the hardware), so the count is a compile-time constant.
+template <int EPI>
+__device__ __forceinline__ void w4p_epilogue_store(const GemmArgs& p, float16v (&acc)[4][4], int m_wave0, int n_wave0, int lane) {
+  constexpr int OOR = (int)0x80000000;
+  constexpr int LPR = EPI == W4_SWIGLU ? 8 : 16, RPI = 64 / LPR, NU = 32 / RPI;
+  const int rrow = lane / LPR, rch = lane % LPR;
+  auto chunk = [&](int i, int u) {
+    const float16v& c = acc[i][u >> 2];
+    return uint4v{__float_as_uint(w4_acc(c, (u & 3) * 4)), __float_as_uint(w4_acc(c, (u & 3) * 4 + 1)),
+                  __float_as_uint(w4_acc(c, (u & 3) * 4 + 2)), __float_as_uint(w4_acc(c, (u & 3) * 4 + 3))};
+  };
+  if (EPI == W4_ROPE) {
+    const int part = n_wave0 / p.rope_HD;
+    const int col0 = n_wave0 - part * p.rope_HD + rch * 8;
+    const __amdgpu_buffer_rsrc_t rc = part == 0 ? w4p_rsrc(p.rope_q, p.rq_bytes) : w4p_rsrc(part == 1 ? p.rope_k : p.rope_v, p.rkv_bytes);
+    const float inv_T = 1.0f / (float)p.rope_T;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int m = m_wave0 + i * 32 + u * RPI + rrow;
+        const int b = (int)(((float)m + 0.5f) * inv_T);
+        const int pos = p.rope_pos0 + m - b * p.rope_T;
+        const long o = part == 0 ? (long)m * p.rope_HD + col0 : (long)b * p.rope_kbatch + (long)pos * p.rope_krow + col0;
+        __builtin_amdgcn_raw_buffer_store_b128(chunk(i, u), rc, m < p.M ? (int)(o * 2) : OOR, 0, 0);
+      }
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t rc = w4p_rsrc(p.C, p.c_bytes);
+  const int ncol = (EPI == W4_SWIGLU ? (n_wave0 >> 1) : n_wave0) + rch * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int m = m_wave0 + i * 32 + u * RPI + rrow;
+      __builtin_amdgcn_raw_buffer_store_b128(chunk(i, u), rc, m < p.M ? (m * p.ldc + ncol) * 2 : OOR, 0, 0);
+    }
+}
+
+template <int AMODE, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, NW = 4, BKT = 64, ROWB = 128, NP = 8;
   constexpr int TM = 4, TN = 4;
@@ -2786,13 +2830,16 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) fw[ks][j] = *reinterpret_cast<const h16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
   };
-  auto mma_rows = [&](auto ks_tag, auto i0_tag, auto i1_tag) {    // rows [i0, i1) of k-step ks
+  auto mma_rows = [&](auto ks_tag, auto i0_tag, auto i1_tag, auto zero_tag) {    // rows [i0, i1) of k-step ks
     constexpr int ks = decltype(ks_tag)::value, i0 = decltype(i0_tag)::value, i1 = decltype(i1_tag)::value;
+    constexpr bool ZERO = decltype(zero_tag)::value;              // the first products of an output tile: C = 0 (an inline constant)
+    const float16v z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = i0; i < i1; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = G4R_MFMA_32X32X16(fw[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j) acc[i][j] = G4R_MFMA_32X32X16(fw[ks][j], fa[ks][i], ZERO ? z16 : acc[i][j], 0, 0, 0);
   };
+  using NoZ = std::false_type;
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
@@ -2808,8 +2855,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
     const int buf = i & 1;
     ldfrag(I2{}, buf);
     ldfrag(I3{}, buf);
-    mma_rows(I0{}, I0{}, I4{});
-    mma_rows(I1{}, I0{}, I1{});
+    mma_rows(I0{}, I0{}, I4{}, NoZ{});      // (C = 0 for the first K tile after an epilogue instead of zeroing the accumulators
+                                            //  was tried: hipcc then spills 50-200 VGPRs in every epilogue mode)
+    mma_rows(I1{}, I0{}, I1{}, NoZ{});
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
       __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
@@ -2829,8 +2877,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
 #pragma unroll
       for (int q = 0; q < 12; ++q) piece(q, ts2, buf);
     }
-    mma_rows(I1{}, I1{}, I4{});
-    mma_rows(I2{}, I0{}, I3{});
+    mma_rows(I1{}, I1{}, I4{}, NoZ{});
+    mma_rows(I2{}, I0{}, I3{}, NoZ{});
     if (STEADY) {
 #pragma unroll
       for (int n = 0; n < 12; ++n) {
@@ -2858,8 +2906,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
 #pragma unroll
       for (int q = 12; q < 16; ++q) piece(q, ts2, buf);
     }
-    mma_rows(I2{}, I3{}, I4{});
-    mma_rows(I3{}, I0{}, I4{});
+    mma_rows(I2{}, I3{}, I4{}, NoZ{});
+    mma_rows(I3{}, I0{}, I4{}, NoZ{});
     if (STEADY) {
 #pragma unroll
       for (int n = 0; n < 16; ++n) {
@@ -2875,10 +2923,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // PF ("pieces first"): epilogues without loads of their own (no bias, no residual, no tables) run BEHIND the next tile's
-  // pieces, which land while they store.  The others run first: next to an LDS-DMA in flight hipcc waits vmcnt(0) before the
-  // first use of any ordinary load (cdna_hip_programming.md section 5), which would stall the epilogue until the pieces have
-  // landed.  (The epilogue sits at the loop's END: with it at the head hipcc moves all 256 accumulators to VGPRs and spills.)
+  // Order at a tile boundary: epilogue phase 1 (every load and LDS operation of the epilogue; results in registers) -> the next
+  // tile's offsets and its first two K tiles' pieces -> epilogue phase 2 (the stores).  The pieces land while the stores issue,
+  // and the wait for them below leaves the stores in flight.  (The epilogue sits at the loop's END: with it at the head hipcc
+  // moves all 256 accumulators to VGPRs and spills.)
   int item = blockIdx.x;
   setup(item);
   prologue();
@@ -2887,7 +2935,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
   // store, not a skipped one).  They retire in issue order (loads and stores share vmcnt on gfx9), so at most that many
   // outstanding = the first K tile has landed.
   int behind = nt > 1 ? 16 : 0;
+#ifdef G4R_W4P_PROBE
+  // tools/w4p_timeline.py (build with G4R_EXTRA_HIPCC_FLAGS=-DG4R_W4P_PROBE, pass a workspace): wave 0 of every workgroup records
+  // s_memtime at [tile top, K loop begin, K loop end, epilogue end] of each of its tiles at ws + (blockIdx.x * 16 + tile) * 4
+  long long* stamps = reinterpret_cast<long long*>(p.ws) + (long)blockIdx.x * 64;
+  int tile_no = 0;
+#define G4R_W4P_STAMP(slot) do { if (p.ws != nullptr && wave == 0 && tile_no < 16) stamps[tile_no * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define G4R_W4P_STAMP(slot) do { } while (0)
+#endif
   for (;;) {
+    G4R_W4P_STAMP(0);
     if (behind >= 48) __builtin_amdgcn_s_waitcnt(0xcf70);        // vmcnt(48)
     else if (behind >= 32) __builtin_amdgcn_s_waitcnt(0x8f70);   // vmcnt(32)
     else if (behind >= 16) __builtin_amdgcn_s_waitcnt(0x4f70);   // vmcnt(16)
@@ -2897,23 +2955,30 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
     asm volatile("" ::: "memory");
     ldfrag(I0{}, 0);
     ldfrag(I1{}, 0);
+    G4R_W4P_STAMP(1);
     int i = 0;
-    if (PF && behind > 16 && nt > 2) {                           // (behind > 16: an epilogue's stores are in the queue)
-      body(0, std::true_type{}, std::integral_constant<int, PF ? w4p_stores(EPI) : 0>{});
+    if (behind > 16 && nt > 2) {                                 // (behind > 16: an epilogue's stores are in the queue)
+      body(0, std::true_type{}, std::integral_constant<int, w4p_stores(EPI)>{});
       i = 1;
     }
     for (; i + 2 < nt; ++i) body(i, std::true_type{}, I0{});
     for (; i < nt; ++i) body(i, std::false_type{}, I0{});
     // every wave has read its last fragments (phase A of the last K tile ends in a barrier) and no piece is in flight: the
     // operand buffers are idle
+    G4R_W4P_STAMP(2);
     const int em = m0 + wm * 128, en = n0 + wn * 128;
     const int next = item + (int)gridDim.x;
     const bool has_next = next < total;
-    if (PF && has_next) {
+    w4p_epilogue_compute<EPI>(p, acc, smem + 2 * STAGE_BYTES + wave * 8192, em, en, lane);
+    if (has_next) {
       setup(next);
       prologue();
     }
-    w4p_epilogue<EPI>(p, acc, smem + 2 * STAGE_BYTES + wave * 8192, em, en, lane);
+    w4p_epilogue_store<EPI>(p, acc, em, en, lane);
+    G4R_W4P_STAMP(3);
+#ifdef G4R_W4P_PROBE
+    ++tile_no;
+#endif
     if (!has_next) break;
 #pragma unroll
     for (int i2 = 0; i2 < TM; ++i2)
@@ -2921,19 +2986,15 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i2][j][r] = 0.f;
-    if (!PF) {
-      setup(next);
-      prologue();
-    }
-    behind = (nt > 1 ? 16 : 0) + (PF ? w4p_stores(EPI) : 0);
+    behind = (nt > 1 ? 16 : 0) + w4p_stores(EPI);
     item = next;
   }
 }
 
-template <int AMODE, int EPI, bool PF>
+template <int AMODE, int EPI>
 int launch_w4k64p_epi(GemmArgs& p, int grid, hipStream_t stream) {
   const size_t lds = 2 * (256 + 256) * 64 * 2 + 4 * 8192;        // the operand ring + 8 KB of epilogue staging per wave = all 160 KB
-  auto kern = gemm_bf16_w4k64p_kernel<AMODE, EPI, PF>;
+  auto kern = gemm_bf16_w4k64p_kernel<AMODE, EPI>;
   static G4rPerDeviceOnce attr_set;
   if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -3015,20 +3076,19 @@ int launch_w4k64(GemmArgs& p, hipStream_t stream) {
       rkv = (size_t)((nb - 1) * p.rope_kbatch + (long)(p.rope_pos0 + p.rope_T - 1) * p.rope_krow + p.rope_HD) * 2;
       cb = rq;
     }
-    if (mode_ok && tiles > ncu && p.M < (1 << 20) && cb < 0x7fffffffu && rb < 0x7fffffffu && rq < 0x7fffffffu && rkv < 0x7fffffffu) {
+    // (K < 2048 -- the ViT block GEMMs -- stays per tile: with 16 K tiles per output tile the epilogue is a fifth of a tile and the
+    //  per-tile form hides its store drain behind the next workgroup's start: 6-9 % faster there, profiles/r06_persist_ab.jsonl)
+    if (mode_ok && tiles > ncu && p.K >= 2048 && p.M < (1 << 20) && cb < 0x7fffffffu && rb < 0x7fffffffu && rq < 0x7fffffffu && rkv < 0x7fffffffu) {
       p.c_bytes = (unsigned)cb; p.r_bytes = (unsigned)rb; p.rq_bytes = (unsigned)rq; p.rkv_bytes = (unsigned)rkv;
       if (AMODE != 0) {
         // (the convolution forms of the persistent kernel do not fit hipcc's register allocation yet: one accumulator block ends
         //  up in VGPRs with 32 v_accvgpr moves per K tile; they stay on gemm_bf16_w4k64_kernel)
       } else {
         switch (mode) {
-          // (with a bias the epilogue has loads of its own and must run AHEAD of the next tile's pieces: measured 7-9 % slower
-          //  than the per-tile form on the K = 1024 ViT shapes, profiles/r06_persist_ab.txt -- those stay per tile)
-          case W4_P16: if (p.bias == nullptr) return launch_w4k64p_epi<0, W4_P16, true>(p, ncu, stream);
-                       break;
-          case W4_SWIGLU: return launch_w4k64p_epi<0, W4_SWIGLU, true>(p, ncu, stream);
-          case W4_ROPE: return launch_w4k64p_epi<0, W4_ROPE, false>(p, ncu, stream);
-          default: return launch_w4k64p_epi<0, W4_WIDE, false>(p, ncu, stream);
+          case W4_P16: return launch_w4k64p_epi<0, W4_P16>(p, ncu, stream);
+          case W4_SWIGLU: return launch_w4k64p_epi<0, W4_SWIGLU>(p, ncu, stream);
+          case W4_ROPE: return launch_w4k64p_epi<0, W4_ROPE>(p, ncu, stream);
+          default: return launch_w4k64p_epi<0, W4_WIDE>(p, ncu, stream);
         }
       }
     }
