@@ -616,7 +616,8 @@ def main():
         except Exception:
             pass
         # kernel names as the counter pass records them, matched by prefix (template tails change between rounds)
-        PMC_PREFIX = {"gemm_bf16_nt<256x256w4k64>": "void gemm_bf16_w4k64_kernel<0, false",       # (all epilogue modes of the symbol family)
+        PMC_PREFIX = {"gemm_bf16_nt<256x256w4k64>": ("void gemm_bf16_w4k64_kernel<0, false",       # (all epilogue modes of the per-tile form
+                                                     "void gemm_bf16_w4k64p_kernel<0,"),          #  and of the persistent form, round 6)
                       "conv3x3_igemm<256x256w4k64>": "void gemm_bf16_w4k64_kernel<2, false",
                       "gemm_bf16_nt<256x256pp32>": "void gemm_bf16_pp32_kernel<0, false, 256, 256",
                       "gemm_bf16_nt<192x256pp32>": "void gemm_bf16_pp32_kernel<0, false, 192, 256",
@@ -628,7 +629,8 @@ def main():
             """launch-weighted mean over every counter-pass row of the tag's kernel symbol family (the epilogue modes of the
             one-wave-per-SIMD kernel are template instances of one symbol)"""
             pre = PMC_PREFIX.get(tag)
-            rows = [v for k, v in pmc.items() if pre and k.startswith(pre) and k != "_meta"]
+            pre = (pre,) if isinstance(pre, str) else (pre or ())
+            rows = [v for k, v in pmc.items() if k != "_meta" and any(k.startswith(x) for x in pre)]
             if not rows:
                 return {}
             n = sum(r.get("launches", 1) for r in rows)

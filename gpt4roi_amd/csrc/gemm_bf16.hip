@@ -2608,14 +2608,33 @@ __device__ __forceinline__ void w4p_epilogue_compute(const GemmArgs& p, float16v
   auto run = [&](auto act_tag, auto bias_tag) {           // activation and bias are compile-time constants of each copy:
     constexpr int ACT = decltype(act_tag)::value;         // straight-line code (a branch per quad costs more than the quad)
     constexpr bool BIAS = decltype(bias_tag)::value;
+    // The residual tile is loaded ROW-major -- 32 loads of 4 rows x 256 B per wave tile, all in flight together (128 VGPRs: the
+    // operand fragments are dead) -- and transposed into the accumulator layout through the same 8 KB of LDS, one 32-row pass
+    // ahead of the values it is added to.  (Loading it in the accumulator layout -- 8 B per lane on 32 different rows per
+    // instruction -- took ~400 cycles per load instruction: profiles/r06_w4p_timeline.txt.)
+    uint4v resrow[EPI == W4_WIDE ? 32 : 1];
+    if (EPI == W4_WIDE) {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        const int m = m_wave0 + (e >> 3) * 32 + (e & 7) * 4 + rrow;
+        const int roff = (m < p.M && has_res) ? (m * p.ldr + n_wave0 + rch * 8) * 2 : OOR;          // (absent / beyond M: zeros)
+        resrow[e] = __builtin_amdgcn_raw_buffer_load_b128(rr, roff, 0, 0);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      uint2v res[16];                                     // this pass's residual quads, all in flight together
+      uint2v res[16];                                     // this lane's residual quads of pass i (slot 8 j + 2 q + wh of row wr)
       if (EPI == W4_WIDE) {
-        const int m = m_wave0 + i * 32 + wr;
-        const int roff = (m < p.M && has_res) ? (m * p.ldr + n_wave0 + 4 * wh) * 2 : OOR;     // (absent / beyond M: zeros)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) res[e] = __builtin_amdgcn_raw_buffer_load_b64(rr, roff + e * 16, 0, 0);
+        for (int u = 0; u < 8; ++u) {                     // row-major chunk -> the parked-row layout (see read_back)
+          const int r = u * 4 + rrow;
+          uint4v v = resrow[i * 8 + u];
+          if (r & 1) v = uint4v{v.z, v.w, v.x, v.y};
+          *reinterpret_cast<uint4v*>(wave_lds + r * RB + ((rch ^ ((r & 15) >> 1)) << 4)) = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          res[e] = *reinterpret_cast<const uint2v*>(wave_lds + wr * RB + (((2 * e + wh) ^ (wr & 15)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)

@@ -27,7 +27,12 @@ extern "C" {
  * act: 0 none, 1 relu, 2 quick_gelu, 3 silu.  K % 64 == 0 runs the MFMA kernel (lda, ldw
  * multiples of 8); any other K runs a scalar kernel (tiny layers only, no residual).
  * splits > 1: split-K with `workspace` of splits*M*N floats.
- * tile_cfg: 0 = 128x128 (LDS-DMA), 1 = 256x128, 2 = 128x128 register-staged, 4 = 64x128.
+ * tile_cfg (the tiles the shipped library holds; gpt4roi_amd/kernels.py pick_tile chooses among them by whole waves of the
+ * 256 CUs): 0 = 128x128 two-stage, 4 = 64x128, 7 = 128x128 x 8 waves ring of 4, 13 = 64x128 ring of 3, 14 = 64x64 ring of
+ * 4, 24 = 256x256 ring ping-pong (also the route for operands of 2 GiB and more), 28 = 192x256 ring ping-pong, 34 = 256x256
+ * one wave per SIMD, K tiles of 64 -- the production tile; launches of more than one wave of its tiles with N % 256 == 0,
+ * K >= 2048, 16-bit output and no K slices run its PERSISTENT form (one workgroup per CU walks the tiles; bit-identical).
+ * Any other number returns G4R_ERR_INVALID_ARG (superseded forms exist in the tools build only, -DG4R_TOOLS_BUILD).
  */
 int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, const void* residual,
                      float* workspace, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
