@@ -104,6 +104,13 @@ def build_model(args, device, seed, dtype=torch.bfloat16):
     model.spi_module.to(device)
     model.mm_projector.to(device)
     syn.spi_state_gpu(model.spi_module, seed=seed + 2)
+    # the projector too comes from a seeded generator (round 6: it was left at nn.Linear's default, i.e. a different draw in every
+    # process -- the live greedy-id leg then met different fp32 near-ties from run to run)
+    gp = torch.Generator(device=device).manual_seed(seed + 3)
+    with torch.no_grad():
+        pj = model.mm_projector
+        pj.weight.copy_(torch.randn(pj.weight.shape, generator=gp, device=device) / pj.weight.size(1) ** 0.5)
+        pj.bias.copy_(torch.randn(pj.bias.shape, generator=gp, device=device) * 0.05)
     model.prepare()
     # the kernel-ready copies are what the path reads; drop the fp32 masters of the big layers
     torch.cuda.empty_cache()
