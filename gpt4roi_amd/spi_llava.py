@@ -195,6 +195,11 @@ class SPILlavaLlamaModel(nn.Module):
         if self._proj is None or self._stamp != self._param_stamp():
             self.prepare()
         if self.llama_master is not None:
+            live = self.llama.trainable_tensors()
+            for k, prm in self.llama_master.named_kernel_tensors():          # (a table replaced behind the masters' back)
+                if tuple(live[k].shape) != tuple(prm.shape):
+                    raise RuntimeError(f"decoder tensor {k} changed shape {tuple(prm.shape)} -> {tuple(live[k].shape)} after "
+                                       "enable_decoder_training(): call enable_decoder_training() again (and re-create the optimizer)")
             st = tuple((p.data_ptr(), p._version) for _, p in self.llama_master.named_kernel_tensors())
             if st != self._llama_stamp:
                 self.sync_decoder_from_masters()
@@ -501,6 +506,13 @@ class SPILlavaMPTForCausalLM(nn.Module):
         dec._dstate = None
         dec._bstate = None
         self.config.vocab_size = new_num_tokens
+        if self.model.llama_master is not None:
+            # the fp32 masters of stage 2 were built from the OLD tables; left alone, the next optimizer step would
+            # write wrongly-shaped rows back.  Rebuild them from the resized tensors (an optimizer created before this call holds
+            # the old Parameters and must be re-created, as with HF's own resize after optimizer construction).
+            self.model.llama_master = None
+            self.model._llama_stamp = None
+            self.model.enable_decoder_training()
         return self.get_input_embeddings()
 
     def initialize_vision_tokenizer(self, mm_use_im_start_end, tokenizer, device=None, tune_mm_mlp_adapter=False,
