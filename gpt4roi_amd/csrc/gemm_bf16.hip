@@ -2504,7 +2504,7 @@ constexpr int w4p_stores(int epi) { return epi == W4_SWIGLU ? 16 : 32; }     // 
 // load next to an LDS-DMA in flight.  A parked row is 32 (SwiGLU: 16) slots of 8 B; slot s of row r sits at s ^ (r & 15): the
 // 16 lanes of a ds_write_b64 group (16 rows, one slot) hit 16 different slots, the 16 lanes of a ds_read_b128 group (one row) 16
 // different chunks.
-template <int EPI>
+template <int EPI, bool LIGHT = false>      // LIGHT (the convolutions): no bias, activation none / ReLU only -- two copies instead of eight
 __device__ __forceinline__ void w4p_epilogue_compute(const GemmArgs& p, float16v (&acc)[4][4], char* wave_lds, int m_wave0, int n_wave0,
                                                      int lane) {
   const int wr = lane & 31, wh = lane >> 5;
@@ -2663,7 +2663,10 @@ __device__ __forceinline__ void w4p_epilogue_compute(const GemmArgs& p, float16v
       read_back(i);
     }
   };
-  if (has_bias) {
+  if (LIGHT) {
+    if (p.act == 0) run(std::integral_constant<int, 0>{}, std::false_type{});
+    else run(std::integral_constant<int, 1>{}, std::false_type{});
+  } else if (has_bias) {
     if (p.act == 0) run(std::integral_constant<int, 0>{}, std::true_type{});
     else if (p.act == 1) run(std::integral_constant<int, 1>{}, std::true_type{});
     else if (p.act == 2) run(std::integral_constant<int, 2>{}, std::true_type{});
@@ -2729,9 +2732,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
   const int total = p.tiles_m * p.tiles_n;                                // (no K slices in this form)
   const int nt = p.K / BKT;
 
-  int a_voff[NP], b_voff[NP];
+  // per-lane piece state.  Dense: one byte offset per piece (rows clamped at M - 1 / N - 1).  AMODE 2 (the convolution over all
+  // pyramid levels, LEAN form): the launcher guarantees that every level starts on a tile boundary, so a tile lies in ONE level
+  // (map size and row pitch are wave-uniform) and the rows of piece j are the rows of piece 0 + 32 j: ONE offset for A and one for
+  // W (the 32 j rows go into the instruction's scalar offset), the tap masks of the 8 piece rows, and no clamping (a row beyond M
+  // is beyond the descriptor's extent: zeros) -- 10 registers instead of 32, which is what lets this form fit beside the 128
+  // fragment registers without moving an accumulator block to VGPRs.
+  constexpr bool LEAN = AMODE == 2;
+  int a_voff[LEAN ? 1 : NP], b_voff[LEAN ? 1 : NP];
   unsigned a_ok[NP];
-  int a_pitch[NP];
+  int a_pitch[LEAN ? 1 : NP];
+  int lean_pitch = 0;                         // LEAN: bytes between map rows of the tile's level (wave-uniform)
   int m0 = 0, n0 = 0;
   // work item -> tile, and the per-lane piece offsets of that tile (piece j of this wave covers rows 8 (4 j + wave) + lane / 8;
   // lane % 8 is the 16-byte slot it writes: gemm_bf16_w4k64_kernel)
@@ -2746,36 +2757,56 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
     //  and keeps them alive through the K loop, where the convolution forms then spill)
     int ln = lane;
     asm volatile("" : "+v"(ln));
+    if constexpr (LEAN) {
+      int lv = 0;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int row = (j * NW + wave) * 8 + (ln >> 3);
-      const int kslot = (ln & 7) ^ ((row >> 1) & 7);
-      int gm = m0 + row;
-      if (gm > p.M - 1) gm = p.M - 1;
-      a_voff[j] = (gm * p.lda + kslot * 8) * 2;
-      int gn = n0 + row;
-      if (gn > p.N - 1) gn = p.N - 1;
-      b_voff[j] = (gn * p.ldw + kslot * 8) * 2;
-      a_ok[j] = 0;
-      a_pitch[j] = p.Wd * p.lda;
-      if (AMODE >= 1) {
-        int h = p.H, w = p.Wd, local = gm;
-        if (AMODE == 2) {
-          int lv = 0;
+      for (int q2 = 1; q2 < 4; ++q2)
+        if (q2 < p.n_lvl && m0 >= p.lvl_start[q2]) lv = q2;                 // (scalar: the tile's level)
+      const int h = p.lvl_h[lv], w = p.lvl_w[lv], hw = h * w;
+      lean_pitch = w * p.lda * 2;
+      const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)w;       // (x + 0.5) / d is never within 0.5 / d of an integer: exact below 2^22
+      const int row0 = wave * 8 + (ln >> 3);
+      const int kslot = (ln & 7) ^ ((row0 >> 1) & 7);                       // (the same for all 8 pieces: (32 j) >> 1 is a multiple of 8)
+      a_voff[0] = ((m0 + row0) * p.lda + kslot * 8) * 2;
+      b_voff[0] = ((n0 + row0) * p.ldw + kslot * 8) * 2;
 #pragma unroll
-          for (int q2 = 1; q2 < 4; ++q2)
-            if (q2 < p.n_lvl && gm >= p.lvl_start[q2]) lv = q2;
-          h = p.lvl_h[lv]; w = p.lvl_w[lv];
-          local = gm - p.lvl_start[lv];
-          a_pitch[j] = w * p.lda;
-        }
-        const int hw = h * w;
-        const int rem = local - (local / hw) * hw;
-        const int y = rem / w, x = rem - y * w;
+      for (int j = 0; j < NP; ++j) {
+        const int gm = m0 + row0 + j * 32;
+        const int local = gm - p.lvl_start[lv];
+        const int img = (int)(((float)local + 0.5f) * inv_hw);
+        const int rem = local - img * hw;
+        const int y = (int)(((float)rem + 0.5f) * inv_w), x = rem - y * w;
+        unsigned ok = 0;
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
           const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-          if (yy >= 0 && yy < h && xx >= 0 && xx < w) a_ok[j] |= 1u << tp;
+          if (yy >= 0 && yy < h && xx >= 0 && xx < w) ok |= 1u << tp;
+        }
+        a_ok[j] = gm < p.M ? ok : 0u;                                       // (rows beyond M: every tap reads zeros)
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int row = (j * NW + wave) * 8 + (ln >> 3);
+        const int kslot = (ln & 7) ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        if (gm > p.M - 1) gm = p.M - 1;
+        a_voff[j] = (gm * p.lda + kslot * 8) * 2;
+        int gn = n0 + row;
+        if (gn > p.N - 1) gn = p.N - 1;
+        b_voff[j] = (gn * p.ldw + kslot * 8) * 2;
+        a_ok[j] = 0;
+        a_pitch[j] = p.Wd * p.lda;
+        if (AMODE >= 1) {
+          const int h = p.H, w = p.Wd, local = gm;
+          const int hw = h * w;
+          const int rem = local - (local / hw) * hw;
+          const int y = rem / w, x = rem - y * w;
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) a_ok[j] |= 1u << tp;
+          }
         }
       }
     }
@@ -2805,6 +2836,19 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
   };
   auto piece = [&](int q, const TileSrc& ts, int buf) {
     char* sa = smem + buf * STAGE_BYTES;
+    if constexpr (LEAN) {
+      if (q < NP) {
+        // the tap shift and the 32 q rows of piece q are wave-uniform (one level per tile): ONE scalar added to the lane's base
+        // offset.  (They cannot ride in the instruction's scalar offset: the descriptor's range check sees the VECTOR offset alone,
+        // and base + a negative tap shift is "out of range" before the scalar offset brings it back -- zeros instead of texels.)
+        int voff = a_voff[0] + (q * 32 * p.lda * 2 + ts.dy * lean_pitch + ts.dx * p.lda * 2);
+        if (!((a_ok[q] >> ts.tap) & 1u)) voff = (int)0x80000000;            // beyond num_records: reads as zeros
+        g4r_buffer_piece(p.A, p.a_bytes, sa + (q * NW + wave) * 1024, voff, ts.a_soff);
+      } else {
+        g4r_buffer_piece(p.W, p.w_bytes, sa + A_BYTES + ((q - NP) * NW + wave) * 1024, b_voff[0], ts.w_soff + (q - NP) * 32 * p.ldw * 2);
+      }
+      return;
+    }
     if (q < NP) {
       int voff = a_voff[q];
       if (AMODE == 1) voff += (ts.dy * p.Wd + ts.dx) * p.lda * 2;
@@ -2988,7 +3032,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64p_kernel(GemmArgs p) {
     const int em = m0 + wm * 128, en = n0 + wn * 128;
     const int next = item + (int)gridDim.x;
     const bool has_next = next < total;
-    w4p_epilogue_compute<EPI>(p, acc, smem + 2 * STAGE_BYTES + wave * 8192, em, en, lane);
+    w4p_epilogue_compute<EPI, (AMODE != 0)>(p, acc, smem + 2 * STAGE_BYTES + wave * 8192, em, en, lane);
     if (has_next) {
       setup(next);
       prologue();
@@ -3100,8 +3144,18 @@ int launch_w4k64(GemmArgs& p, hipStream_t stream) {
     if (mode_ok && tiles > ncu && p.K >= 2048 && p.M < (1 << 20) && cb < 0x7fffffffu && rb < 0x7fffffffu && rq < 0x7fffffffu && rkv < 0x7fffffffu) {
       p.c_bytes = (unsigned)cb; p.r_bytes = (unsigned)rb; p.rq_bytes = (unsigned)rq; p.rkv_bytes = (unsigned)rkv;
       if (AMODE != 0) {
-        // (the convolution forms of the persistent kernel do not fit hipcc's register allocation yet: one accumulator block ends
-        //  up in VGPRs with 32 v_accvgpr moves per K tile; they stay on gemm_bf16_w4k64_kernel)
+        // The convolution over all pyramid levels has a persistent form too (LEAN addressing, see the kernel: every level starts on a
+        // tile boundary -- true for the pyramids of the path at any batch: 64 P^2, 16 P^2 and 4 P^2 rows per image are multiples of
+        // 256 at P = 16 and 24).  It is bit-identical to the per-tile form and 4-6 % SLOWER (1282 vs 1358 TF/s at batch 16,
+        // profiles/r06_conv_persist_ab.txt: with 144 K tiles per output tile the boundary is 5 % of a tile and hipcc spills around it),
+        // so it is compiled into the tools build only (debug mode 63, tools/conv_persist_ab.py).
+#ifdef G4R_TOOLS_BUILD
+        if constexpr (AMODE == 2) {
+          bool aligned = p.groups == 1;
+          for (int l = 1; l < p.n_lvl; ++l) aligned = aligned && (p.lvl_start[l] % 256) == 0;
+          if (g_gemm_dbg == 63 && aligned && mode == W4_P16 && p.bias == nullptr && p.act <= 1) return launch_w4k64p_epi<2, W4_P16>(p, ncu, stream);
+        }
+#endif
       } else {
         switch (mode) {
           case W4_P16: return launch_w4k64p_epi<0, W4_P16>(p, ncu, stream);
