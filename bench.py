@@ -40,6 +40,20 @@ PEAK_BF16_TFLOPS = 2500.0   # dense MFMA peak, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak, same table
 
 
+def forward_flops_per_request(P, rois, T, llama_layers=32, C=1024, hidden=4096, inter=11008, vocab=32006):
+    """Forward FLOPs (2 x MAC) of ONE request of the path, SURVEY.md 8d: ViT-L/14 23 blocks (8 S C^2 + 16 S C^2 + 4 S^2 C, S = P^2 + 1) +
+    patch embed; 1x1 input convs + 5 fuse rounds of 3x3 convs over the 85 P^2 pyramid pixels; per RoI 4 pconvs (14 x 14 bins) +
+    flatten_linear + updims; projector; LLaMA prefill (q/k/v/o + SwiGLU MLP + lm_head per token, causal attention)."""
+    S = P * P + 1
+    npix = 85 * P * P
+    return (23 * (24.0 * S * C * C + 4.0 * S * S * C) + 2.0 * (S - 1) * 588 * C
+            + 2.0 * 1026 * C * npix + 5 * 2.0 * 9 * C * C * npix
+            + rois * (4 * 2.0 * 9 * C * C * 196 + 2.0 * 196 * C * 1024 + 2.0 * 1024 * hidden)
+            + 2.0 * P * P * C * hidden
+            + T * (llama_layers * (8.0 * hidden * hidden + 6.0 * hidden * inter) + 2.0 * hidden * vocab)
+            + llama_layers * 2.0 * T * T * hidden)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -942,14 +956,7 @@ def main():
         # forward FLOPs of one request: ViT 23 blocks + patch embed, 1x1 + 5 fuse rounds of 3x3 convs over the
         # 85 P^2 pyramid pixels, pconvs + flatten_linear + updims per RoI, projector, LLaMA prefill (12.95 GF/token incl. lm_head
         # + causal attention)
-        S_, C_, T_ = P * P + 1, 1024, int(prompt.size(1))
-        npix = 85 * P * P
-        flops_per_request = (23 * (24.0 * S_ * C_ * C_ + 4.0 * S_ * S_ * C_) + 2.0 * (S_ - 1) * 588 * C_
-                             + 2.0 * 1026 * C_ * npix + 5 * 2.0 * 9 * C_ * C_ * npix
-                             + args.rois * (4 * 2.0 * 9 * C_ * C_ * 196 + 2.0 * 196 * C_ * 1024 + 2.0 * 1024 * 4096)
-                             + 2.0 * P * P * C_ * 4096
-                             + T_ * (args.llama_layers * (8.0 * 4096 * 4096 + 6.0 * 4096 * 11008) + 2.0 * 4096 * 32006)
-                             + args.llama_layers * 2.0 * T_ * T_ * 4096)
+        flops_per_request = forward_flops_per_request(P, args.rois, int(prompt.size(1)), args.llama_layers)
         line = {
             "metric": f"region-tokens/sec (336^2 img, 32 RoIs, CLIP ViT-L/14 + region module + LLaMA-7B fwd; {args.batch} batch-1 requests "
                       "merged per launch sequence, value_batch1 = one request at a time)",

@@ -69,3 +69,40 @@ def test_batched_projection_dispatch_rule_and_abi_validation():
     assert b"multiple of 64" in lib.g4r_last_error()
     assert f(None, 4, 4096, None, 1e-6, None, None, 4096, None, None, 0, 4096, 4096, 4096, 0, 0, 0, None) == 1
     assert b"null pointer" in lib.g4r_last_error()
+
+
+def test_forward_flops_per_request_match_the_survey(bench):
+    """config.target_arithmetic of the line: SURVEY.md 8d puts one request at ~15.8 TFLOP (P = 24, 32 RoIs, T ~ 780) and ~9.4 TFLOP at
+    the reference-native P = 16 (T ~ 510); 5000 region-tokens/s at 336^2 is then ~2.47 PF/s = 0.99 of the dense 16-bit peak"""
+    f24 = bench.forward_flops_per_request(24, 32, 767)
+    f16 = bench.forward_flops_per_request(16, 32, 510)          # (the survey's T ~ 510; the bench's 224^2 prompt is 447 tokens: 8.7 TFLOP)
+    assert 15.5e12 < f24 < 16.2e12 and 9.0e12 < f16 < 9.9e12
+    assert abs(5000 / 32 * f24 / 1e15 - 2.48) < 0.03
+    # the parts SURVEY.md 8d lists: ViT 365 GF (23 layers, P = 24), fuse convs 4 620 GF, pconvs 473 GF at 32 RoIs
+    S, C = 577, 1024
+    assert abs(23 * (24.0 * S * C * C + 4.0 * S * S * C) / 1e9 - 365) < 2
+    assert abs(5 * 2.0 * 9 * C * C * 85 * 576 / 1e9 - 4620) < 5
+
+
+def test_greedy_record_merger(tmp_path, monkeypatch):
+    """tools/merge_greedy.py: the per-(dtype, seed) records of the single-request test and the merged-16 record become ONE file with
+    both scopes, which bench.py quotes with the file's hash"""
+    import importlib.util
+    import json
+    root = tmp_path / "repo"
+    (root / "tools").mkdir(parents=True)
+    (root / "gpurun_out" / "greedy_parity").mkdir(parents=True)
+    (root / "profiles").mkdir()
+    src = open(os.path.join(ROOT, "tools", "merge_greedy.py")).read()
+    (root / "tools" / "merge_greedy.py").write_text(src)
+    for dt, seed in (("fp16", 82), ("bf16", 82)):
+        json.dump({"dtype": dt, "seed": seed, "new_tokens": 64, "teacher_forced_identical": 64, "free_running_exact_len": 64,
+                   "whole_path_generate_exact_len": 64, "whole_path_first_divergence": None, "against": "HF"},
+                  open(root / "gpurun_out" / "greedy_parity" / f"{dt}_{seed}.json", "w"))
+    json.dump({"dtype": "fp16", "scope": "merged16", "requests": 16, "new_tokens": 64, "merged_exact_len": [64] * 15 + [40]},
+              open(root / "gpurun_out" / "greedy_parity" / "merged16_fp16.json", "w"))
+    monkeypatch.setattr(sys, "argv", ["merge_greedy.py", "07"])
+    spec = importlib.util.spec_from_file_location("merge_greedy_under_test", str(root / "tools" / "merge_greedy.py"))
+    spec.loader.exec_module(importlib.util.module_from_spec(spec))
+    doc = json.load(open(root / "profiles" / "r07_greedy_parity.json"))
+    assert [r["dtype"] for r in doc["runs"]] == ["bf16", "fp16"] and doc["merged16"]["merged_exact_len"][-1] == 40
