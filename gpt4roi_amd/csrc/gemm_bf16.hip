@@ -56,6 +56,7 @@ struct GemmArgs {
   int stagger_ticks;           // one-wave-per-SIMD kernel: start offset step of the first 256 workgroups in 10 ns ticks (0 = none)
   // persistent form (gemm_bf16_w4k64p_kernel): extents in bytes of the tensors its epilogue addresses through buffer descriptors
   unsigned c_bytes, r_bytes, rq_bytes, rkv_bytes;
+  int persist_any_k;           // tile_cfg 36: the persistent form whatever K (tests: one / two / three K tiles per output tile)
   // act == 5 (fused q|k|v projection of a LLaMA layer, ring ping-pong tiles only): RoPE and the KV-cache append happen in
   // the epilogue -- what g4r_rope_qkv_bf16 did in a launch of its own.  Columns [0, HD) -> rotated q rows of rope_q,
   // [HD, 2 HD) -> rotated k into the cache rows pos0 + t, [2 HD, 3 HD) -> v into the cache.  Row m = b * rope_T + t.
@@ -3141,7 +3142,7 @@ int launch_w4k64(GemmArgs& p, hipStream_t stream) {
     }
     // (K < 2048 -- the ViT block GEMMs -- stays per tile: with 16 K tiles per output tile the epilogue is a fifth of a tile and the
     //  per-tile form hides its store drain behind the next workgroup's start: 6-9 % faster there, profiles/r06_persist_ab.jsonl)
-    if (mode_ok && tiles > ncu && p.K >= 2048 && p.M < (1 << 20) && cb < 0x7fffffffu && rb < 0x7fffffffu && rq < 0x7fffffffu && rkv < 0x7fffffffu) {
+    if (mode_ok && tiles > ncu && (p.K >= 2048 || p.persist_any_k) && p.M < (1 << 20) && cb < 0x7fffffffu && rb < 0x7fffffffu && rq < 0x7fffffffu && rkv < 0x7fffffffu) {
       p.c_bytes = (unsigned)cb; p.r_bytes = (unsigned)rb; p.rq_bytes = (unsigned)rq; p.rkv_bytes = (unsigned)rkv;
       if (AMODE != 0) {
         // The convolution over all pyramid levels has a persistent form too (LEAN addressing, see the kernel: every level starts on a
@@ -3305,7 +3306,7 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
   // grouped tile order for dense launches with many row tiles (ring ping-pong kernel): tools modes 31 / 32 / 33 force a group of
   // 8 / 4 / 16 row tiles, 30 forces the plain order
   p.group_m = 0;
-  if (AMODE == 0 && (tile_cfg == 24 || tile_cfg == 28 || tile_cfg == 34 || tile_cfg == 35)) {
+  if (AMODE == 0 && (tile_cfg == 24 || tile_cfg == 28 || tile_cfg == 34 || tile_cfg == 35 || tile_cfg == 36)) {
     const int tm = g4r_ceil_div(p.M, tile_cfg == 28 ? 192 : 256);
     if (tm >= 12) p.group_m = 8;
     if (g_gemm_dbg == 30) p.group_m = 0;
@@ -3325,6 +3326,7 @@ int launch_gemm(GemmArgs& p, int tile_cfg, hipStream_t stream) {
     case 13: return launch_tile<64, 128, 1, 4, AMODE, true, 3, 64, 3>(p, stream);   // 72 KB ring of 3: 2 wg/CU; counted-wait fragment pipeline
     case 14: return launch_tile<64, 64, 2, 2, AMODE, true, 4, 64, 3>(p, stream);    // 64 KB ring of 4: 2 wg/CU; counted-wait fragment pipeline
     case 34: return launch_w4k64<AMODE>(p, stream);                              // 256x256, 4 waves x (128x128), K 64 x 2 buffers refilled as consumed (round 5)
+    case 36: p.persist_any_k = 1; return launch_w4k64<AMODE>(p, stream);         // tile 34 with its persistent form offered at every K (round 6; tests)
     case 24:                                                                     // 256x256 ping-pong, K 32 ring of 4 (G4R_BIG_TILE=24; operands >= 2 GiB)
       // the implicit-GEMM convs take the rotated single-barrier schedule (192^2 conv 693 -> 668 us, tools/gemm_bench.cpp
       // tile 31); the dense GEMMs lose 8-12 % on it (4096^3 1172 -> 1076 TF/s) and keep the two-barrier form
@@ -3426,7 +3428,7 @@ int g4r_gemm_qkv_rope_bf16(const void* A, const void* W, int B, int T, int K, in
   G4R_REQUIRE(A && W && q_out && k_cache && v_cache && cos_tab && sin_tab, "gemm_qkv_rope: null pointer");
   G4R_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (cache_row % 8) == 0 && (cache_batch % 8) == 0, "gemm_qkv_rope: 16-byte rows");
   if (tile_cfg == 0) tile_cfg = 28;
-  G4R_REQUIRE(tile_cfg == 24 || tile_cfg == 28 || tile_cfg == 34, "gemm_qkv_rope: 256-wide tiles only (24 / 28 / 34)");
+  G4R_REQUIRE(tile_cfg == 24 || tile_cfg == 28 || tile_cfg == 34 || tile_cfg == 36, "gemm_qkv_rope: 256-wide tiles only (24 / 28 / 34 / 36)");
   GemmArgs p = {};
   p.A = (const h16_t*)A; p.W = (const h16_t*)W; p.C = q_out;
   p.M = B * T; p.N = 3 * heads * head_dim; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = heads * head_dim;

@@ -141,7 +141,7 @@ PROFILER = _Profiler()
 TILE_NAMES = {0: "128x128", 1: "256x128", 2: "128x128reg", 4: "64x128", 5: "128x128s3", 6: "128x128s4",
               7: "128x128w8s4", 8: "256x128s3", 9: "256x256", 10: "128x128w8", 11: "128x64", 12: "64x128s4", 13: "64x128s3", 14: "64x64s4",
               15: "128x64s4", 22: "256x256pp", 24: "256x256pp32", 26: "256x256w4", 27: "128x384pp32", 28: "192x256pp32",
-              34: "256x256w4k64"}
+              34: "256x256w4k64", 36: "256x256w4k64"}
 # the production 256 x 256 tile: 34 = one wave per SIMD, K tiles of 64, straight-line epilogues (round 5: 1.38-1.41 PF/s on the
 # merged LLaMA shapes, +14 % over the ring ping-pong tile, profiles/r05_w4k64_epilogue.txt); G4R_BIG_TILE=24 = the ring
 # ping-pong tile of rounds 2-4 (A/B runs)
@@ -410,7 +410,7 @@ def gemm_qkv_rope(h, wqkv, B, T, heads, head_dim, q_out, k_cache, v_cache, cos, 
     HD = heads * head_dim
     if tile_cfg is None:
         tile_cfg = pick_tile(M, 3 * HD, Kd)
-    if head_dim != 128 or HD % 256 != 0 or tile_cfg not in (24, 28, 34) or M != B * T:
+    if head_dim != 128 or HD % 256 != 0 or tile_cfg not in (24, 28, 34, 36) or M != B * T:
         return None
     assert wqkv.shape == (3 * HD, Kd) and q_out.is_contiguous() and cos.size(1) == 64 and cos.is_contiguous() and sin.is_contiguous()
     assert k_cache.stride(2) == 1 and v_cache.stride() == k_cache.stride() and pos0 + T <= k_cache.size(1)

@@ -32,6 +32,7 @@ extern "C" {
  * 4, 24 = 256x256 ring ping-pong (also the route for operands of 2 GiB and more), 28 = 192x256 ring ping-pong, 34 = 256x256
  * one wave per SIMD, K tiles of 64 -- the production tile; launches of more than one wave of its tiles with N % 256 == 0,
  * K >= 2048, 16-bit output and no K slices run its PERSISTENT form (one workgroup per CU walks the tiles; bit-identical).
+ * 36 = tile 34 with the persistent form offered at every K (tests of its short-K paths).
  * Any other number returns G4R_ERR_INVALID_ARG (superseded forms exist in the tools build only, -DG4R_TOOLS_BUILD).
  */
 int g4r_gemm_bf16_nt(const void* A, const void* W, void* C, const float* bias, const void* residual,
