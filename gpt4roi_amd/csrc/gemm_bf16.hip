@@ -848,6 +848,11 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const h16_t* __restri
 // pieces (one coalesced 1 KiB load per row per step, 4 rows in flight), fp32 accumulate, shuffle
 // reduction.  Same epilogues as the GEMM (bias, residual, SwiGLU over interleaved row pairs, fp32 out).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack8_h16(const uint4v& r, float* f) {
+  f[0] = h16lo(r.x); f[1] = h16hi(r.x); f[2] = h16lo(r.y); f[3] = h16hi(r.y);
+  f[4] = h16lo(r.z); f[5] = h16hi(r.z); f[6] = h16lo(r.w); f[7] = h16hi(r.w);
+}
+
 __device__ __forceinline__ float dot8_bf16(const uint4v& a, const uint4v& b, float acc) {
   acc += h16lo(a.x) * h16lo(b.x); acc += h16hi(a.x) * h16hi(b.x);
   acc += h16lo(a.y) * h16lo(b.y); acc += h16hi(a.y) * h16hi(b.y);
@@ -868,13 +873,13 @@ __device__ __forceinline__ float dot8_bf16(const uint4v& a, const uint4v& b, flo
 // read-back: ~6 us of serial memory round trips per layer) by a kernel boundary that is there anyway.
 // x is staged in dynamic LDS (2 K bytes) next to a 16-byte static array: both must fit the default 64 KB limit
 #define G4R_GEMV_MAX_K 32736
-template <int R, int U, int XMODE, int NWV>
+template <int R, int U, int XMODE, int NWV, int MAXV = 4>
 __global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const h16_t* __restrict__ x, const float* __restrict__ gamma,
                                                         float eps, int mS, int mD, const h16_t* __restrict__ W,
                                                         void* __restrict__ C,
                                                         const float* __restrict__ bias,
                                                         const h16_t* __restrict__ residual, int N, int K, int ldw,
-                                                        int act, int out_f32) {
+                                                        int act, int out_f32, int early_on) {
   extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
   uint4v* xs = reinterpret_cast<uint4v*>(gemv_smem);
   __shared__ float red[4];
@@ -894,24 +899,57 @@ __global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const h16_t* __rest
         wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(wrow[r] + (size_t)idx * 8));
     }
   };
-  // (Issuing the first weight loads before x is staged does not help: vector memory returns in order, so the small x
-  // loads then queue behind R*U HBM loads -- measured 5-8 % slower.)
+  // Round 6: every wave issues its first block of weight loads right AFTER the loads of its share of the staging and BEFORE it
+  // waits for them: vector memory returns in order, so the x loads (older) are not delayed and the weight stream runs from the
+  // first cycles of the workgroup instead of after the 2-3 memory round trips + 2 barriers of the staging.  Same loads, same
+  // arithmetic, same bits.  (The other order -- weights first, then x -- queues x behind R*U HBM loads: 5-8 % slower, round 2.)
+  const bool early = early_on && n0 < N;   // (early_on = 0: debug mode 62, the A/B of tools/decode_bench.py)
+  bool pre = false;                        // the first block of W is already in flight when the main loop starts
   if (XMODE == 1) {
     // the first 4 waves stage and normalise x exactly as rmsnorm_bf16_kernel's 256 threads do (same element -> thread
     // map and summation order: bit-identical rstd); further waves of a wide workgroup only wait at the barriers
-    constexpr int MAXV = 4;  // K <= 8192 (checked by the launcher)
-    float f[MAXV][8];
+    // MAXV vectors of 8 per staging thread: K <= 2048 * MAXV (the launcher picks 2 for K <= 4096, else 4; K <= 8192 checked there).
+    // x stays PACKED in registers and is unpacked twice: with the first weight block (R*U*4 registers) in flight next to x and
+    // gamma the kernel must stay under 80 registers, or a CU no longer holds three workgroups (the wide projections launch 3-8 per CU)
+    uint4v xr[MAXV];
+    // gamma: the waves that do not stage x (4..NWV-1) fetch it next to the x loads of the stagers and park it in LDS behind x, so
+    // its round trip no longer follows the two barriers of the reduction and costs the stagers no registers
+    constexpr bool GLDS = NWV > 4;
+    constexpr int GW = GLDS ? (NWV - 4) * 64 : 1;
+    float* gs = reinterpret_cast<float*>(gemv_smem + (size_t)K * 2);
+    float4v gq[GLDS ? 2 * MAXV : 1];
     float s2 = 0.f;
     const bool stager = tid < 256;
+    if (stager) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int v = tid + i * 256;
-      if (stager && v < nvec) {
-        const uint4v r = *reinterpret_cast<const uint4v*>(x + v * 8);
-        f[i][0] = h16lo(r.x); f[i][1] = h16hi(r.x); f[i][2] = h16lo(r.y); f[i][3] = h16hi(r.y);
-        f[i][4] = h16lo(r.z); f[i][5] = h16hi(r.z); f[i][6] = h16lo(r.w); f[i][7] = h16hi(r.w);
+      for (int i = 0; i < MAXV; ++i) {
+        const int v = tid + i * 256;
+        if (v < nvec) xr[i] = *reinterpret_cast<const uint4v*>(x + v * 8);
+      }
+    } else if (GLDS) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s2 += f[i][k] * f[i][k];
+      for (int i = 0; i < 2 * MAXV; ++i) {
+        const int v4 = tid - 256 + i * GW;
+        if (v4 < (K >> 2)) gq[i] = *reinterpret_cast<const float4v*>(gamma + v4 * 4);
+      }
+    }
+    if (early) { load_w(lane); pre = true; }
+    if (stager) {
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int v = tid + i * 256;
+        if (v < nvec) {
+          float fx[8];
+          unpack8_h16(xr[i], fx);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s2 += fx[k] * fx[k];
+        }
+      }
+    } else if (GLDS) {
+#pragma unroll
+      for (int i = 0; i < 2 * MAXV; ++i) {
+        const int v4 = tid - 256 + i * GW;
+        if (v4 < (K >> 2)) *reinterpret_cast<float4v*>(gs + v4 * 4) = gq[i];
       }
     }
 #pragma unroll
@@ -924,12 +962,14 @@ __global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const h16_t* __rest
     for (int i = 0; i < MAXV; ++i) {
       const int v = tid + i * 256;
       if (stager && v < nvec) {
-        const float4v g0 = *reinterpret_cast<const float4v*>(gamma + v * 8);
-        const float4v g1 = *reinterpret_cast<const float4v*>(gamma + v * 8 + 4);
+        const float* gp = GLDS ? gs + v * 8 : gamma + v * 8;
+        const float4v g0 = *reinterpret_cast<const float4v*>(gp);
+        const float4v g1 = *reinterpret_cast<const float4v*>(gp + 4);
         const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        float o[8];
+        float o[8], fx[8];
+        unpack8_h16(xr[i], fx);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = h16_to_f32(f32_to_h16(f[i][k] * rstd)) * g[k];
+        for (int k = 0; k < 8; ++k) o[k] = h16_to_f32(f32_to_h16(fx[k] * rstd)) * g[k];
         uint4v w;
         w.x = pack_h16x2(o[0], o[1]); w.y = pack_h16x2(o[2], o[3]);
         w.z = pack_h16x2(o[4], o[5]); w.w = pack_h16x2(o[6], o[7]);
@@ -938,28 +978,93 @@ __global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const h16_t* __rest
     }
   } else if (XMODE == 2) {
     const int SLD = mD + 2;
-    for (int v = tid; v < nvec; v += NWV * 64) {
-      const int h = (v * 8) / mD, d0 = (v * 8) - h * mD;
-      const float* part = gamma + (size_t)h * mS * SLD;
+    constexpr int MS = 8;            // splits whose partials one thread holds in registers (the decode step uses 8)
+    float pm[MS], pl[MS];
+    float4v po0[MS], po1[MS];
+    auto part_of = [&](int v, int& d0) {
+      const int h = (v * 8) / mD;
+      d0 = (v * 8) - h * mD;
+      return gamma + (size_t)h * mS * SLD;
+    };
+    auto mload = [&](int v) {        // every load of the merge of one 8-element vector, issued together
+      int d0;
+      const float* part = part_of(v, d0);
+#pragma unroll
+      for (int i = 0; i < MS; ++i) {
+        if (i < mS) {
+          pm[i] = part[i * SLD + mD];
+          pl[i] = part[i * SLD + mD + 1];
+          po0[i] = *reinterpret_cast<const float4v*>(part + i * SLD + d0);
+          po1[i] = *reinterpret_cast<const float4v*>(part + i * SLD + d0 + 4);
+        }
+      }
+    };
+    auto mfinish = [&](int v) {      // the arithmetic of the loop form below, term for term
       float mm = -INFINITY;
-      for (int i = 0; i < mS; ++i) mm = fmaxf(mm, part[i * SLD + mD]);
+#pragma unroll
+      for (int i = 0; i < MS; ++i)
+        if (i < mS) mm = fmaxf(mm, pm[i]);
       float Lt = 0.f, a2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int i = 0; i < mS; ++i) {
-        const float mi = part[i * SLD + mD];
-        const float w = mi == -INFINITY ? 0.f : exp2f(mi - mm);
-        Lt += w * part[i * SLD + mD + 1];
-        const float4v o0 = *reinterpret_cast<const float4v*>(part + i * SLD + d0);
-        const float4v o1 = *reinterpret_cast<const float4v*>(part + i * SLD + d0 + 4);
-        a2[0] += w * o0.x; a2[1] += w * o0.y; a2[2] += w * o0.z; a2[3] += w * o0.w;
-        a2[4] += w * o1.x; a2[5] += w * o1.y; a2[6] += w * o1.z; a2[7] += w * o1.w;
+#pragma unroll
+      for (int i = 0; i < MS; ++i) {
+        if (i < mS) {
+          const float w = pm[i] == -INFINITY ? 0.f : exp2f(pm[i] - mm);
+          Lt += w * pl[i];
+          a2[0] += w * po0[i].x; a2[1] += w * po0[i].y; a2[2] += w * po0[i].z; a2[3] += w * po0[i].w;
+          a2[4] += w * po1[i].x; a2[5] += w * po1[i].y; a2[6] += w * po1[i].z; a2[7] += w * po1[i].w;
+        }
       }
       uint4v w8;
       w8.x = pack_h16x2(a2[0] / Lt, a2[1] / Lt); w8.y = pack_h16x2(a2[2] / Lt, a2[3] / Lt);
       w8.z = pack_h16x2(a2[4] / Lt, a2[5] / Lt); w8.w = pack_h16x2(a2[6] / Lt, a2[7] / Lt);
       xs[v] = w8;
+    };
+    if (mS <= MS) {
+      int v = tid;
+      if (v < nvec) mload(v);
+      if (early) { load_w(lane); pre = true; }
+      if (v < nvec) mfinish(v);
+      for (v += NWV * 64; v < nvec; v += NWV * 64) {
+        mload(v);
+        mfinish(v);
+      }
+    } else {
+      for (int v = tid; v < nvec; v += NWV * 64) {
+        int d0;
+        const float* part = part_of(v, d0);
+        float mm = -INFINITY;
+        for (int i = 0; i < mS; ++i) mm = fmaxf(mm, part[i * SLD + mD]);
+        float Lt = 0.f, a2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < mS; ++i) {
+          const float mi = part[i * SLD + mD];
+          const float w = mi == -INFINITY ? 0.f : exp2f(mi - mm);
+          Lt += w * part[i * SLD + mD + 1];
+          const float4v o0 = *reinterpret_cast<const float4v*>(part + i * SLD + d0);
+          const float4v o1 = *reinterpret_cast<const float4v*>(part + i * SLD + d0 + 4);
+          a2[0] += w * o0.x; a2[1] += w * o0.y; a2[2] += w * o0.z; a2[3] += w * o0.w;
+          a2[4] += w * o1.x; a2[5] += w * o1.y; a2[6] += w * o1.z; a2[7] += w * o1.w;
+        }
+        uint4v w8;
+        w8.x = pack_h16x2(a2[0] / Lt, a2[1] / Lt); w8.y = pack_h16x2(a2[2] / Lt, a2[3] / Lt);
+        w8.z = pack_h16x2(a2[4] / Lt, a2[5] / Lt); w8.w = pack_h16x2(a2[6] / Lt, a2[7] / Lt);
+        xs[v] = w8;
+      }
     }
   } else {
-    for (int v = tid; v < nvec; v += NWV * 64) xs[v] = *reinterpret_cast<const uint4v*>(x + v * 8);
+    constexpr int XPRE = 3;          // x vectors per thread held in registers across the early weight loads (K <= 12288 at 8 waves)
+    uint4v xr[XPRE];
+#pragma unroll
+    for (int i = 0; i < XPRE; ++i) {
+      const int v = tid + i * NWV * 64;
+      if (v < nvec) xr[i] = *reinterpret_cast<const uint4v*>(x + v * 8);
+    }
+    if (early) { load_w(lane); pre = true; }
+#pragma unroll
+    for (int i = 0; i < XPRE; ++i) {
+      const int v = tid + i * NWV * 64;
+      if (v < nvec) xs[v] = xr[i];
+    }
+    for (int v = tid + XPRE * NWV * 64; v < nvec; v += NWV * 64) xs[v] = *reinterpret_cast<const uint4v*>(x + v * 8);
   }
   __syncthreads();
   if (n0 >= N) return;
@@ -967,7 +1072,7 @@ __global__ __launch_bounds__(NWV * 64) void gemv_bf16_kernel(const h16_t* __rest
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = 0.f;
   for (int vb = lane; vb < nvec; vb += 64 * U) {
-    load_w(vb);
+    if (!(pre && vb == lane)) load_w(vb);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (vb + 64 * u < nvec) {
@@ -1014,16 +1119,19 @@ static void launch_gemv(int xmode, const h16_t* x, const float* gamma, float eps
                         hipStream_t stream) {
   const int waves = g4r_ceil_div(N, R);
   const dim3 grid(g4r_ceil_div(waves, NWV)), block(NWV * 64);
-  const size_t lds = (size_t)K * 2;
-  if (xmode == 1)
+  const size_t lds = (size_t)K * 2 + (xmode == 1 && NWV > 4 ? (size_t)K * 4 : 0);   // x, and gamma behind it (fused norm, wide workgroups)
+  if (xmode == 1 && K <= 4096)
+    hipLaunchKernelGGL((gemv_bf16_kernel<R, U, 1, NWV, 2>), grid, block, lds, stream, x, gamma, eps, mS, mD, W, C, bias,
+                       residual, N, K, ldw, act, out_f32, g_gemm_dbg == 62 ? 0 : 1);
+  else if (xmode == 1)
     hipLaunchKernelGGL((gemv_bf16_kernel<R, U, 1, NWV>), grid, block, lds, stream, x, gamma, eps, mS, mD, W, C, bias,
-                       residual, N, K, ldw, act, out_f32);
+                       residual, N, K, ldw, act, out_f32, g_gemm_dbg == 62 ? 0 : 1);
   else if (xmode == 2)
     hipLaunchKernelGGL((gemv_bf16_kernel<R, U, 2, NWV>), grid, block, lds, stream, x, gamma, eps, mS, mD, W, C, bias,
-                       residual, N, K, ldw, act, out_f32);
+                       residual, N, K, ldw, act, out_f32, g_gemm_dbg == 62 ? 0 : 1);
   else
     hipLaunchKernelGGL((gemv_bf16_kernel<R, U, 0, NWV>), grid, block, lds, stream, x, gamma, eps, mS, mD, W, C, bias,
-                       residual, N, K, ldw, act, out_f32);
+                       residual, N, K, ldw, act, out_f32, g_gemm_dbg == 62 ? 0 : 1);
 }
 
 // (R rows per wave, U K-steps in flight, waves per workgroup); variant >= 0: A/B probe (tools/gemm_bench.cpp v: cases)

@@ -33,6 +33,7 @@ struct GemvMfmaArgs {
   const h16_t* residual; long ldr;
   int B, N, K, act, out_f32;
   int KC;                       // K elements staged per pass (multiple of 64); one pass when the rows fit the LDS budget
+  int early;                    // the first weight block issued before the staging is waited for: 0 never, 1 without a fused norm, 2 always
 };
 
 __device__ __forceinline__ float gm_act(float v, int act) {
@@ -42,7 +43,7 @@ __device__ __forceinline__ float gm_act(float v, int act) {
   return v;
 }
 
-template <int NWV, int U, bool NORM, int RB>
+template <int NWV, int U, bool NORM, int RB, bool EARLY, int RPH>
 __global__ __launch_bounds__(NWV * 64) void gemv_mfma_kernel(GemvMfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) char gm_smem[];
   __shared__ float red[4];
@@ -64,9 +65,104 @@ __global__ __launch_bounds__(NWV * 64) void gemv_mfma_kernel(GemvMfmaArgs a) {
   const bool col_live = fr < B;
   const char* xrow = gm_smem + (col_live ? fr : 0) * rowb + fq * 16;
 
-  if (NORM) {
+  // the first block of this wave's weight stream (steps wave, wave + NWV, ... of the first pass): issued right AFTER the loads of
+  // the wave's share of the staging and BEFORE it waits for them -- vector memory returns in order, so the (older) x loads are not
+  // delayed, and the stream runs from the first cycles of the workgroup instead of after the staging's round trips and barriers
+  // (round 6; the single-row GEMV does the same).  early = 0: debug, tools/decode_bench.py --ab
+  uint4v w0[U][RB], w1[U][RB];
+  auto load_w = [&](int c0, int s0, int nsteps) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int s = s0 + u * NWV;
+      if (s > nsteps - 1) s = nsteps - 1;             // (clamped: the duplicate is not accumulated)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const h16_t* p = wrow[rb] + c0 + s * 64;
+        w0[u][rb] = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(p));
+        w1[u][rb] = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(p + 32));
+      }
+    }
+  };
+  const int nsteps0 = (K < a.KC ? K : a.KC) >> 6;
+  bool pre = false;
+  const int nvec = K >> 3;
+  // one-pass fused norm with at most 4 rows per 256 threads (B <= 8 at eight waves, K <= 4096): the 256 threads of "half" h take
+  // rows h, h + NH, h + 2 NH, ... -- each with rmsnorm_bf16_kernel's own element -> thread map (v = t + 256 i) and summation
+  // order, so rstd has the bits of the separate launch -- ALL rows in ONE memory round trip (the general form below walks the rows
+  // one round trip + two barriers each), and a thread normalises and stages exactly the vectors it summed: x is read once.
+  constexpr int NH = NWV / 4;
+  const bool fast = NORM && NH >= 1 && a.KC >= K && nvec <= 512 && B <= RPH * NH;   // RPH rows per 256 threads (2 or 4: registers)
+  bool staged = false;
+  if (NORM && fast) {
+    __shared__ float red2[16][4];
+    const int half = tid >> 8, t = tid & 255;
+    uint4v xr[RPH][2];
+    float4v gq[2][2];
+#pragma unroll
+    for (int j = 0; j < RPH; ++j) {
+      const int b = half + NH * j;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int v = t + 256 * i;
+        if (b < B && v < nvec) xr[j][i] = *reinterpret_cast<const uint4v*>(a.x + (size_t)b * a.ldx + (size_t)v * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = t + 256 * i;
+      if (v < nvec) {
+        gq[i][0] = *reinterpret_cast<const float4v*>(a.gamma + v * 8);
+        gq[i][1] = *reinterpret_cast<const float4v*>(a.gamma + v * 8 + 4);
+      }
+    }
+    if (EARLY) { load_w(0, wave, nsteps0); pre = true; }
+    float s2[RPH];
+#pragma unroll
+    for (int j = 0; j < RPH; ++j) s2[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < RPH; ++j) {
+      const int b = half + NH * j;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int v = t + 256 * i;
+        if (b < B && v < nvec) {
+          const uint4v r4 = xr[j][i];
+          const float f[8] = {h16lo(r4.x), h16hi(r4.x), h16lo(r4.y), h16hi(r4.y), h16lo(r4.z), h16hi(r4.z), h16lo(r4.w), h16hi(r4.w)};
+#pragma unroll
+          for (int k = 0; k < 8; ++k) s2[j] += f[k] * f[k];
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s2[j] += __shfl_xor(s2[j], o);
+      if (lane == 0 && b < B) red2[b][wave & 3] = s2[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RPH; ++j) {
+      const int b = half + NH * j;
+      if (b < B) {
+        const float rs = rsqrtf((red2[b][0] + red2[b][1] + red2[b][2] + red2[b][3]) / (float)K + a.eps);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int v = t + 256 * i;
+          if (v < nvec) {
+            uint4v r4 = xr[j][i];
+            const float4v g0 = gq[i][0], g1 = gq[i][1];
+            const float f[8] = {h16lo(r4.x), h16hi(r4.x), h16lo(r4.y), h16hi(r4.y), h16lo(r4.z), h16hi(r4.z), h16lo(r4.w), h16hi(r4.w)};
+            const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = h16_to_f32(f32_to_h16(f[k] * rs)) * g[k];
+            r4.x = pack_h16x2(o[0], o[1]); r4.y = pack_h16x2(o[2], o[3]);
+            r4.z = pack_h16x2(o[4], o[5]); r4.w = pack_h16x2(o[6], o[7]);
+            *reinterpret_cast<uint4v*>(gm_smem + b * rowb + v * 16) = r4;
+          }
+        }
+      }
+    }
+    staged = true;
+  } else if (NORM) {
     // rstd of every row, exactly as rmsnorm_bf16_kernel's 256 threads sum it (norm.hip): v = tid + 256 i, xor-shuffle, red[0..3]
-    const int nvec = K >> 3;
     for (int b = 0; b < B; ++b) {
       float s2 = 0.f;
       if (tid < 256) {
@@ -95,6 +191,22 @@ __global__ __launch_bounds__(NWV * 64) void gemv_mfma_kernel(GemvMfmaArgs a) {
     const int cn = K - c0 < a.KC ? K - c0 : a.KC;      // elements of this pass
     // ---- stage the B rows of this pass ----
     const int cvec = cn >> 3;
+    if (!NORM && EARLY && c0 == 0) {
+      // first pass without a norm: the thread's vector of the first four rows waits in registers while the first weight block is issued
+      constexpr int XP = 4, NT = NWV * 64;
+      uint4v xr[XP];
+#pragma unroll
+      for (int j = 0; j < XP; ++j)
+        if (j < B && tid < cvec) xr[j] = *reinterpret_cast<const uint4v*>(a.x + (size_t)j * a.ldx + (size_t)tid * 8);
+      load_w(0, wave, nsteps0);
+      pre = true;
+#pragma unroll
+      for (int j = 0; j < XP; ++j)
+        if (j < B && tid < cvec) *reinterpret_cast<uint4v*>(gm_smem + j * rowb + tid * 16) = xr[j];
+      for (int b = 0; b < B; ++b)
+        for (int v = tid + (b < XP ? NT : 0); v < cvec; v += NT)
+          *reinterpret_cast<uint4v*>(gm_smem + b * rowb + v * 16) = *reinterpret_cast<const uint4v*>(a.x + (size_t)b * a.ldx + (size_t)v * 8);
+    } else if (!staged) {
     for (int i = tid; i < B * cvec; i += NWV * 64) {
       const int b = i / cvec, v = i - b * cvec;
       uint4v r4 = *reinterpret_cast<const uint4v*>(a.x + (size_t)b * a.ldx + (size_t)(c0 + v * 8));
@@ -112,22 +224,11 @@ __global__ __launch_bounds__(NWV * 64) void gemv_mfma_kernel(GemvMfmaArgs a) {
       }
       *reinterpret_cast<uint4v*>(gm_smem + b * rowb + v * 16) = r4;
     }
+    }
     __syncthreads();
     // ---- stream this wave's steps of the pass: step s covers K [c0 + 64 s, + 64), wave w takes s = w, w + NWV, ... ----
     const int nsteps = cn >> 6;
-    for (int s0 = wave; s0 < nsteps; s0 += NWV * U) {
-      uint4v w0[U][RB], w1[U][RB];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        int s = s0 + u * NWV;
-        if (s > nsteps - 1) s = nsteps - 1;             // (clamped: the duplicate is not accumulated)
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-          const h16_t* p = wrow[rb] + c0 + s * 64;
-          w0[u][rb] = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(p));
-          w1[u][rb] = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(p + 32));
-        }
-      }
+    auto consume = [&](int s0) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int s = s0 + u * NWV;
@@ -145,6 +246,15 @@ __global__ __launch_bounds__(NWV * 64) void gemv_mfma_kernel(GemvMfmaArgs a) {
           }
         }
       }
+    };
+    int s0 = wave;
+    if (EARLY && pre && c0 == 0) {                      // the block that has been in flight since before the staging
+      consume(s0);
+      s0 += NWV * U;
+    }
+    for (; s0 < nsteps; s0 += NWV * U) {
+      load_w(c0, s0, nsteps);
+      consume(s0);
     }
     if (c0 + a.KC < K) __syncthreads();                 // the next pass overwrites the staged rows
   }
@@ -190,9 +300,9 @@ __global__ __launch_bounds__(NWV * 64) void gemv_mfma_kernel(GemvMfmaArgs a) {
   }
 }
 
-template <int NWV, int U, bool NORM, int RB = 1>
-int gm_launch(GemvMfmaArgs& a, hipStream_t stream) {
-  auto kern = gemv_mfma_kernel<NWV, U, NORM, RB>;
+template <int NWV, int U, bool NORM, int RB, bool EARLY, int RPH>
+int gm_launch_k(GemvMfmaArgs& a, hipStream_t stream) {
+  auto kern = gemv_mfma_kernel<NWV, U, NORM, RB, EARLY, RPH>;
   const size_t lds = (size_t)a.B * (a.KC * 2 + 16);
   static G4rPerDeviceOnce attr_set;
   if (attr_set.first()) {
@@ -204,13 +314,24 @@ int gm_launch(GemvMfmaArgs& a, hipStream_t stream) {
   return G4R_OK;
 }
 
+// the fused norm's one-round-trip form holds RPH rows per 256 threads in registers: 2 up to B = NWV / 2 rows, else 4
+template <int NWV, int U, bool NORM, int RB = 1>
+int gm_launch(GemvMfmaArgs& a, hipStream_t stream) {
+  const bool few = !NORM || a.B <= 2 * (NWV / 4);
+  // measured inside the batched decode step (profiles/r06_decode_batch_ab.txt): the early block pays on the launches WITHOUT a
+  // norm (o_proj); with the norm fused its registers (88-106 against 52-70) cost a resident workgroup per CU and it loses
+  const bool early = a.early == 2 || (a.early == 1 && !NORM);
+  if (early) return few ? gm_launch_k<NWV, U, NORM, RB, true, 2>(a, stream) : gm_launch_k<NWV, U, NORM, RB, true, 4>(a, stream);
+  return few ? gm_launch_k<NWV, U, NORM, RB, false, 2>(a, stream) : gm_launch_k<NWV, U, NORM, RB, false, 4>(a, stream);
+}
+
 }  // namespace
 
 extern "C" {
 
 // See include/g4r_kernels.h.  variant (tools only; 0 = production = 8 waves x 4 steps in flight; profiles/r05_gemv_batch.txt):
-// 2 = 4 waves x 8 steps, 3 = two 16-row blocks per workgroup (fewer, fatter workgroups: slower), 5 = 4 waves x 4 steps, >= 16 = the
-// LDS budget of the staged rows in KB
+// 2 = 4 waves x 8 steps, 3 = two 16-row blocks per workgroup (fewer, fatter workgroups: slower), 5 = 4 waves x 4 steps, 6 / 7 = production
+// without / with the early weight loads on every launch (the A/B of round 6; production: only without a fused norm), >= 16 = the LDS budget of the staged rows in KB
 int g4r_gemv_batch_bf16(const void* x, int B, long ldx, const float* gamma, float eps, const void* W, void* C, long ldc,
                         const float* bias, const void* residual, long ldr, int N, int K, int ldw, int act, int out_f32,
                         int variant, void* stream) {
@@ -226,6 +347,8 @@ int g4r_gemv_batch_bf16(const void* x, int B, long ldx, const float* gamma, floa
   // staged rows: B x (KC x 2 + 16) bytes within an LDS budget that leaves several workgroups per CU (the kernel lives on loads
   // in flight: at 82 KB -- 16 rows x 2560 -- one workgroup per CU ran at half the rate of four); equal passes, KC a multiple of
   // 64 x 8 (whole rounds of the eight-wave form).  variant >= 16: the budget in KB (tools)
+  a.early = variant == 6 ? 0 : variant == 7 ? 2 : 1;
+  if (variant == 6 || variant == 7) variant = 0;
   const int budget = variant >= 16 ? variant * 1024 : 98304;     // (measured: fewer passes beat more workgroups per CU)
   if (variant >= 16) variant = 1;
   int kc = ((budget / B - 16) / 2) / 512 * 512;

@@ -442,7 +442,7 @@ def gemm(a, w, bias=None, residual=None, act=None, out=None, out_dtype=None, spl
             and a.stride(0) >= K and w.stride(0) % 8 == 0 and (residual is None or residual.data_ptr() != out.data_ptr()) \
             and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0:        # (the kernel reads both operands in 16-byte pieces)
         # a handful of rows (the decode step of a batch of sequences): weight streaming with the products on the matrix pipe
-        return gemv_batch(a, w, bias=bias, residual=residual, act=act, out=out)
+        return gemv_batch(a, w, bias=bias, residual=residual, act=act, out=out, variant=GEMV_BATCH_VARIANT)
     thin_tail = False
     if tile_cfg is None and splits == 1 and M >= 1024 and pick_tile(M, N, K) == BIG_TILE and out.dtype != torch.float32:
         # several whole waves of 256 x 256 tiles plus a THIN last one (batch-4 gate|up 3068 x 22016: 1032 tiles = 4 waves + 8
@@ -553,10 +553,13 @@ def gemv_batch_wins(M, N, K):
     step (hipGraph replay, LLaMA-7B, 767-token prompts) it wins at 2-4 sequences (3.66 / 3.74 / 3.83 vs 3.91 / 4.00 / 4.02 ms per
     step) and loses at 8 (4.51 vs 4.36) -- each of its N / 16 workgroups stages all the rows, which the tiles amortise over 64
     output columns.  So: 2..4 rows, one staging pass, K <= 8192."""
-    return _GEMV_BATCH_ON and 2 <= M <= 4 and 512 <= K <= 8192 and K % 64 == 0 and M * (2 * K + 16) <= 98304
+    return _GEMV_BATCH_ON and 2 <= M <= GEMV_BATCH_ROWS and 512 <= K <= 8192 and K % 64 == 0 and M * (2 * K + 16) <= 98304
 
 
 _GEMV_BATCH_ON = os.environ.get("G4R_GEMV_BATCH", "1") != "0"      # (read once: gemm() sits in the eager decode loop)
+GEMV_BATCH_ROWS = 4          # rows up to which gemm() routes to the kernel
+GEMV_BATCH_VARIANT = 0       # tools (decode_batch_ab.py): 6 / 7 = never / always issue the first weight block before the staging
+GEMV_BATCH_FUSED_NORM = True    # the batched decode step: RMSNorm inside the q|k|v / gate|up / lm_head launches (LlamaDecoder._decode_step_batch)
 
 
 def conv3x3(x, w, bias=None, act=None, groups=1, out=None, out_dtype=None, splits=1, tile_cfg=None,

@@ -592,9 +592,14 @@ class LlamaDecoder:
         scale = 1.0 / math.sqrt(D)
         work = self._attn_work(B)
         x = K.gather_rows(self.embed, st["tok32"])
+        fused = K.GEMV_BATCH_FUSED_NORM and K.gemv_batch_wins(B, 3 * C, C) and x.stride(0) % 8 == 0
+
+        def norm_proj(x, gamma, w, **kw):       # RMSNorm + projection: one launch on the weight-streaming kernel, else two
+            if fused and K.gemv_batch_wins(B, w.size(0), C):
+                return K.gemv_batch(x, w, norm_weight=gamma, eps=self.eps, variant=K.GEMV_BATCH_VARIANT, **kw)
+            return K.gemm(K.rmsnorm(x, gamma, self.eps), w, **kw)
         for li, L in enumerate(self.layers):
-            h = K.rmsnorm(x, L['n1'], self.eps)
-            qkv = K.gemm(h, L['wqkv'])
+            qkv = norm_proj(x, L['n1'], L['wqkv'])
             if st.get("ragged"):            # pos = [B cache lengths | RoPE position], all advanced by batch_advance
                 a = K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, work, qkv=qkv, cos=self.cos,
                                   sin=self.sin, kv_lens_dev=st["pos"][:B], rope_pos_dev=st["pos"][B:])
@@ -602,10 +607,9 @@ class LlamaDecoder:
                 a = K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, work, kv_len_dev=st["pos"], qkv=qkv,
                                   cos=self.cos, sin=self.sin)
             x = K.gemm(a, L['wo'], residual=x)
-            h = K.rmsnorm(x, L['n2'], self.eps)
-            f = K.gemm(h, L['wgu'], act="swiglu")
+            f = norm_proj(x, L['n2'], L['wgu'], act="swiglu")
             x = K.gemm(f, L['wd'], residual=x)
-        logits = K.gemm(K.rmsnorm(x, self.norm, self.eps), self.lm_head, out_dtype=torch.float32)
+        logits = norm_proj(x, self.norm, self.lm_head, out_dtype=torch.float32)
         K.batch_advance(K.argmax_rows(logits), st["tok"], st["tok32"], st["out"], st["step"], st["pos"])
 
     @torch.no_grad()

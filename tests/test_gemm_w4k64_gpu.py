@@ -272,13 +272,14 @@ def test_gemv_batch_rows_share_one_weight_stream(B, N, Kd, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B", [2, 7, 16])
-def test_gemv_batch_fused_rmsnorm_is_the_separate_launch(B, dtype):
+@pytest.mark.parametrize("B,Kd", [(2, 4096), (4, 4096), (5, 4096), (7, 4096), (8, 2048), (8, 4096), (16, 4096), (3, 8192), (2, 576)])
+def test_gemv_batch_fused_rmsnorm_is_the_separate_launch(B, Kd, dtype):
     """the RMSNorm in front of q|k|v / gate|up / lm_head fused into the staging: bit-identical to rmsnorm() followed by the
-    un-normed call (same element -> thread map, summation order and roundings as rmsnorm_bf16_kernel), one pass and two"""
-    x = rnd(B, 4096, seed=40, dtype=dtype)
-    gamma = 1 + 0.1 * rnd(4096, seed=41, dtype=torch.float32)
-    w = rnd(1536, 4096, seed=42, scale=0.05, dtype=dtype)
+    un-normed call (same element -> thread map, summation order and roundings as rmsnorm_bf16_kernel), one pass and two; up to 8 rows
+    of K <= 4096 take the one-round-trip form (round 6: all rows summed at once, 2 or 4 per 256 threads), the others the row loop"""
+    x = rnd(B, Kd, seed=40, dtype=dtype)
+    gamma = 1 + 0.1 * rnd(Kd, seed=41, dtype=torch.float32)
+    w = rnd(1536, Kd, seed=42, scale=0.05, dtype=dtype)
     fused = K.gemv_batch(x, w, norm_weight=gamma, eps=1e-6)
     assert torch.equal(fused, K.gemv_batch(K.rmsnorm(x, gamma, 1e-6), w))
     h = x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6)

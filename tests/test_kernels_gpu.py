@@ -612,7 +612,8 @@ def test_splice_embed():
 @pytest.mark.parametrize("N,Kd,act,res,f32", [(12288, 4096, None, False, False), (4096, 4096, None, True, False),
                                              (22016, 4096, "swiglu", False, False), (4096, 11008, None, True, False),
                                              (32006, 4096, None, False, True), (1000, 512, None, False, False),
-                                             (36, 1088, "swiglu", False, False)])
+                                             (36, 1088, "swiglu", False, False), (2048, 8192, None, True, False),
+                                             (76, 5184, "swiglu", False, False)])
 def test_gemv_with_fused_rmsnorm_is_bit_identical_to_the_two_launches(N, Kd, act, res, f32):
     """g4r_gemv_rmsnorm_bf16 (the decode-step projections): the fused RMSNorm reproduces g4r_rmsnorm_bf16 bit for bit, so
     fused == rmsnorm() -> gemm(M = 1); both within bf16 tolerance of an fp32 statement.  LLaMA-7B shapes + ragged ones."""
