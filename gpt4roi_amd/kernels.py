@@ -552,7 +552,8 @@ def gemv_batch_wins(M, N, K):
     gate|up and lm_head (o_proj 12 vs 18 us) and loses on down_proj (K = 11008: two staging passes); INSIDE the batched decode
     step (hipGraph replay, LLaMA-7B, 767-token prompts) it wins at 2-4 sequences (3.66 / 3.74 / 3.83 vs 3.91 / 4.00 / 4.02 ms per
     step) and loses at 8 (4.51 vs 4.36) -- each of its N / 16 workgroups stages all the rows, which the tiles amortise over 64
-    output columns.  So: 2..4 rows, one staging pass, K <= 8192."""
+    output columns.  So: 2..4 rows, one staging pass, K <= 8192.  Round 6 (profiles/r06_decode_batch_ab.txt): with the fused
+    RMSNorm in its one-round-trip form 3.51 / 3.65 / 3.76 ms at 2 / 3 / 4 sequences; 8 sequences still lose (4.47 vs 4.30)."""
     return _GEMV_BATCH_ON and 2 <= M <= GEMV_BATCH_ROWS and 512 <= K <= 8192 and K % 64 == 0 and M * (2 * K + 16) <= 98304
 
 
