@@ -2293,7 +2293,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmArgs& p, float16v (&acc)[4
 // into the per-lane offset, an out-of-image tap is an offset beyond the descriptor's extent (zeros), K tile = 64 channels
 // of one tap.
 // ---------------------------------------------------------------------------------------------
-template <int AMODE, bool PROBE, int EPI>
+template <int AMODE, bool PROBE, int EPI, bool MI16P = false>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, NW = 4, BKT = 64, ROWB = 128, NP = 8;
   constexpr int TM = 4, TN = 4;
@@ -2432,12 +2432,32 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) fw[ks][j] = *reinterpret_cast<const h16x8*>(sb + b_row_off + j * 32 * ROWB + slot);
   };
+  // MI16P (tools build, debug mode 65; results are WRONG by construction): the same loads, fragment reads and barriers, but every
+  // 32 x 32 x 16 product is replaced by TWO v_mfma_f32_16x16x32 on four-register accumulators -- the same FLOPs per K tile through
+  // the other MFMA shape, to measure what that shape buys under the power cap with the real kernel's traffic around it
+  float4v acc4[MI16P ? TM : 1][MI16P ? TN : 1][4];
+  if (MI16P) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc4[MI16P ? i : 0][MI16P ? j : 0][r] = float4v{0.f, 0.f, 0.f, 0.f};
+  }
   auto mma_rows = [&](auto ks_tag, auto i0_tag, auto i1_tag) {    // rows [i0, i1) of k-step ks
     constexpr int ks = decltype(ks_tag)::value, i0 = decltype(i0_tag)::value, i1 = decltype(i1_tag)::value;
 #pragma unroll
     for (int i = i0; i < i1; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = G4R_MFMA_32X32X16(fw[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (MI16P) {
+          constexpr int r0 = 2 * (ks & 1);
+          acc4[i][j][r0] = G4R_MFMA_16X16X32(fw[ks][j], fa[ks][i], acc4[i][j][r0], 0, 0, 0);
+          acc4[i][j][r0 + 1] = G4R_MFMA_16X16X32(fa[ks][i], fw[ks][j], acc4[i][j][r0 + 1], 0, 0, 0);
+        } else {
+          acc[i][j] = G4R_MFMA_32X32X16(fw[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+        }
+      }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -2541,17 +2561,28 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4k64_kernel(GemmArgs p) {
     for (; i < nt; ++i) body(i, std::false_type{});
     if (PROBE) { if (wg_probe) wg_stamps[2] = __builtin_amdgcn_s_memtime(); }
   }
+  if (MI16P) {       // no epilogue: the accumulators only have to stay alive (C is left untouched)
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc4[MI16P ? i : 0][MI16P ? j : 0][r >> 2][r & 3];
+    if (sum == 12345.678f) reinterpret_cast<float*>(p.C)[lane] = sum;
+    return;
+  }
   __syncthreads();   // the operand buffers are idle: stage the epilogue through them
   long long park_t = 0;
   w4_epilogue<EPI, PROBE>(p, acc, smem + wave * W4Epi::WAVE_BYTES, m0 + wm * 128, n0 + wn * 128, lane, split, park_t);
   if (PROBE) { if (wg_probe) { wg_stamps[3] = __builtin_amdgcn_s_memtime(); wg_stamps[6] = wall_clock64(); wg_stamps[7] = park_t; } }
 }
 
-template <int AMODE, bool PROBE, int EPI>
+template <int AMODE, bool PROBE, int EPI, bool MI16P = false>
 int launch_w4k64_epi(GemmArgs& p, hipStream_t stream) {
   const size_t ring = 2 * (256 + 256) * 64 * 2, epi = 4 * (size_t)W4Epi::WAVE_BYTES;
   const size_t lds = ring > epi ? ring : epi;
-  auto kern = gemm_bf16_w4k64_kernel<AMODE, PROBE, EPI>;
+  auto kern = gemm_bf16_w4k64_kernel<AMODE, PROBE, EPI, MI16P>;
   static G4rPerDeviceOnce attr_set;
   if (attr_set.first()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -3275,6 +3306,9 @@ int launch_w4k64(GemmArgs& p, hipStream_t stream) {
       }
     }
   }
+#ifdef G4R_TOOLS_BUILD
+  if (AMODE == 0 && !PROBE && g_gemm_dbg == 65 && mode == W4_P16) return launch_w4k64_epi<0, false, W4_P16, true>(p, stream);   // MFMA-shape probe
+#endif
   int rc = G4R_OK;
   if (AMODE != 0) {                       // the convolutions: bias / ReLU only
     rc = (mode == W4_P16) ? launch_w4k64_epi<AMODE, false, W4_P16>(p, stream)

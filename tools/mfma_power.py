@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """tools/mfma_power.py -- round 6: matrix-pipe throughput under the socket power cap by MFMA SHAPE, nothing but MFMAs in the loop
 (tools/probe/mfma_power_probe.hip: one wave per SIMD, 256 accumulator registers, random bf16 operands in registers):
-v_mfma_f32_32x32x16_bf16 (the hand kernels) against v_mfma_f32_16x16x32_bf16 (the vendor library's kernels), same FLOPs per pass.
+v_mfma_f32_32x32x16_bf16 (the hand kernels, 16 products per pass) against v_mfma_f32_16x16x32_bf16 (the vendor library's kernels, 64
+products per pass = twice the FLOPs of the other arm's pass; the first version of this script counted them as equal).
 Each arm runs alone for --seconds; socket power and shader clock are sampled from sysfs (tools/power_ab.py).
 
     hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/probe/mfma_power_probe.so tools/probe/mfma_power_probe.hip
@@ -21,7 +22,8 @@ so.mfma_probe_launch.restype = ctypes.c_int
 out = torch.zeros(4096, device="cuda")
 src = _sysfs()
 blocks, iters = 256, 20000
-flops = blocks * 4 * iters * 16 * 32 * 32 * 16 * 2.0
+flops0 = blocks * 4 * iters * 16 * 32 * 32 * 16 * 2.0        # mode 0: 16 products of 32 x 32 x 16 per pass
+flops1 = blocks * 4 * iters * 64 * 16 * 16 * 32 * 2.0        # mode 1: 64 products of 16 x 16 x 32 per pass = TWICE mode 0's
 st = torch.cuda.current_stream().cuda_stream
 for name, mode in (("v_mfma_f32_32x32x16_bf16 x 16 accumulators", 0), ("v_mfma_f32_16x16x32_bf16 x 64 accumulators", 1),
                    ("v_mfma_f32_32x32x16_bf16 x 16 accumulators (again)", 0)):
@@ -51,7 +53,7 @@ for name, mode in (("v_mfma_f32_32x32x16_bf16 x 16 accumulators", 0), ("v_mfma_f
     half = samples[len(samples) // 2:]
     pw = [s["power_W"] for s in half if "power_W" in s]
     ck = [s["sclk_MHz"] for s in half if "sclk_MHz" in s]
-    tf = flops / us / 1e6
+    tf = (flops1 if mode == 1 else flops0) / us / 1e6
     clk = sum(ck) / len(ck) if ck else None
     print(json.dumps({"arm": name, "us_per_launch": round(us, 1), "TFs": round(tf, 1), "power_W": round(sum(pw) / len(pw), 1) if pw else None,
                       "sclk_MHz": round(clk, 1) if clk else None,

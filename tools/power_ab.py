@@ -73,6 +73,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--probe16", action="store_true", help="tools build only: add the per-tile kernel with every 32x32x16 product replaced by two "
+                    "16x16x32 ones (debug mode 65, wrong results, same traffic and FLOPs): what the other MFMA shape buys under the power cap")
     a = ap.parse_args()
     src = _sysfs()
     print(json.dumps({"n_cards": len(src), "first_sysfs": sample(src) if src else None, "first_smi": smi_sample()}), flush=True)
@@ -93,6 +95,9 @@ def main():
         arms = {"hand_persistent": hand(0), "vendor": lambda: torch.mm(x, w.t(), out=out)}
         if dt is torch.bfloat16:
             arms["hand_per_tile"] = hand(61)
+        if a.probe16:
+            arms = {"hand_per_tile": hand(61), "hand_per_tile_16x16x32_PROBE_wrong_results": hand(65), "hand_per_tile_again": hand(61),
+                    "vendor": arms["vendor"]}
         for name, fn in arms.items():
             for _ in range(3):
                 fn()

@@ -2,7 +2,7 @@
 // One wave per SIMD (256 threads per workgroup, one workgroup per CU), all 256 accumulator registers in use, operands held in
 // registers (random bf16, different registers for every product so the operand buses toggle), no memory traffic in the loop:
 //   mode 0: 16 accumulators of v_mfma_f32_32x32x16_bf16 (the hand kernels' shape): 16 products per pass
-//   mode 1: 64 accumulators of v_mfma_f32_16x16x32_bf16 (the vendor library's shape): 64 products per pass, same FLOPs
+//   mode 1: 64 accumulators of v_mfma_f32_16x16x32_bf16 (the vendor library's shape): 64 products per pass = TWICE mode 0's FLOPs
 // Host: tools/mfma_power.py launches each for a few seconds and samples socket power / shader clock.
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o mfma_power_probe.so mfma_power_probe.hip
 #include <hip/hip_runtime.h>
