@@ -384,6 +384,16 @@ def small_m_split_plan(M, N, K):
     return None
 
 
+def decode_split_plan(M, N, K):
+    """(tile_cfg, K slices) when gemm() runs a batched-decode projection (a handful of rows) as K slices on the 64x64 ring tile
+    followed by a reduce launch -- o_proj / down_proj of LlamaDecoder._decode_step_batch: 8 x 4096 x {4096, 11008} -- or None.
+    The step then hands the partials to rmsnorm_splitk (reduce + residual + the next RMSNorm in one launch, same bits)."""
+    if 1 < M <= 64 and not gemv_batch_wins(M, N, K) and pick_tile(M, N, K) == 14 and K >= 4096 and K % 64 == 0 \
+            and -(-M // 64) * -(-N // 64) <= 64:
+        return 14, 4                                     # (the branch of gemm() with the same conditions)
+    return None
+
+
 def layernorm_splitk(partials, n_slices, bias, residual, gamma, beta, eps=1e-5):
     """x = bf16(sum of the first n_slices partials + bias + residual); y = layernorm(x) -> (x, y) in one pass (bit-identical
     to gemm(..., bias=, residual=) with K slices + layernorm())."""
@@ -560,6 +570,7 @@ def gemv_batch_wins(M, N, K):
 _GEMV_BATCH_ON = os.environ.get("G4R_GEMV_BATCH", "1") != "0"      # (read once: gemm() sits in the eager decode loop)
 GEMV_BATCH_ROWS = 4          # rows up to which gemm() routes to the kernel
 GEMV_BATCH_VARIANT = 0       # tools (decode_batch_ab.py): 6 / 7 = never / always issue the first weight block before the staging
+DECODE_SPLITK_NORM = True       # the batched decode step: K-slice reduce + residual + next RMSNorm as one launch (rmsnorm_splitk)
 GEMV_BATCH_FUSED_NORM = True    # the batched decode step: RMSNorm inside the q|k|v / gate|up / lm_head launches (LlamaDecoder._decode_step_batch)
 
 

@@ -594,22 +594,37 @@ class LlamaDecoder:
         x = K.gather_rows(self.embed, st["tok32"])
         fused = K.GEMV_BATCH_FUSED_NORM and K.gemv_batch_wins(B, 3 * C, C) and x.stride(0) % 8 == 0
 
-        def norm_proj(x, gamma, w, **kw):       # RMSNorm + projection: one launch on the weight-streaming kernel, else two
+        def norm_proj(x, gamma, w, h=None, **kw):
+            """RMSNorm + projection: the normalised rows h when the previous launch already made them, else one launch on the
+            weight-streaming kernel (few rows), else two"""
+            if h is not None:
+                return K.gemm(h, w, **kw)
             if fused and K.gemv_batch_wins(B, w.size(0), C):
                 return K.gemv_batch(x, w, norm_weight=gamma, eps=self.eps, variant=K.GEMV_BATCH_VARIANT, **kw)
             return K.gemm(K.rmsnorm(x, gamma, self.eps), w, **kw)
+
+        def proj_res_norm(a, w, x, gamma_next):
+            """x + a . w^T and, where that projection runs as K slices (more rows than the weight-streaming kernel takes), the NEXT
+            RMSNorm in the slices' reduce launch (round 6: -64 launches per step; same bits as reduce, then norm)"""
+            plan = K.decode_split_plan(B, w.size(0), a.size(1)) if K.DECODE_SPLITK_NORM else None
+            if plan is None:
+                return K.gemm(a, w, residual=x), None
+            part, ns = K.gemm_partials(a, w, plan[1], plan[0])
+            return K.rmsnorm_splitk(part, ns, x, gamma_next, self.eps)
+        h = None
+        nl = len(self.layers)
         for li, L in enumerate(self.layers):
-            qkv = norm_proj(x, L['n1'], L['wqkv'])
+            qkv = norm_proj(x, L['n1'], L['wqkv'], h=h)
             if st.get("ragged"):            # pos = [B cache lengths | RoPE position], all advanced by batch_advance
                 a = K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, work, qkv=qkv, cos=self.cos,
                                   sin=self.sin, kv_lens_dev=st["pos"][:B], rope_pos_dev=st["pos"][B:])
             else:
                 a = K.attn_decode(None, self.kc[li, :B], self.vc[li, :B], H, scale, work, kv_len_dev=st["pos"], qkv=qkv,
                                   cos=self.cos, sin=self.sin)
-            x = K.gemm(a, L['wo'], residual=x)
-            f = norm_proj(x, L['n2'], L['wgu'], act="swiglu")
-            x = K.gemm(f, L['wd'], residual=x)
-        logits = norm_proj(x, self.norm, self.lm_head, out_dtype=torch.float32)
+            x, h2 = proj_res_norm(a, L['wo'], x, L['n2'])
+            f = norm_proj(x, L['n2'], L['wgu'], h=h2, act="swiglu")
+            x, h = proj_res_norm(f, L['wd'], x, self.layers[li + 1]['n1'] if li + 1 < nl else self.norm)
+        logits = norm_proj(x, self.norm, self.lm_head, h=h, out_dtype=torch.float32)
         K.batch_advance(K.argmax_rows(logits), st["tok"], st["tok32"], st["out"], st["step"], st["pos"])
 
     @torch.no_grad()

@@ -29,14 +29,16 @@ def main():
     dec = LlamaDecoder(lsd, heads=l["heads"], max_positions=2048, device=dev)
     del lsd
     # name: (rows routed to the kernel, fused norm, variant (6 / 7 = never / always early loads; 0: only without a fused norm))
-    configs = {"tiles": (0, False, 0), "kernel_noearly_sepnorm": (16, False, 6), "kernel_early_sepnorm": (16, False, 7),
+    configs = {"tiles_separate_reduce_and_norm": (0, False, 0, False), "tiles": (0, False, 0), "kernel_noearly_sepnorm": (16, False, 6), "kernel_early_sepnorm": (16, False, 7),
                "kernel_noearly_fused": (16, True, 6), "kernel_early_fused": (16, True, 7), "kernel_production_fused": (16, True, 0)}
     for B in [int(x) for x in a.batches.split(",")]:
         emb = (torch.randn(B, a.prompt, l["hidden"], device=dev) * 0.02).to(torch.bfloat16)
         ids, ms = {}, {k: [] for k in configs}
         for r in range(a.rounds):
-            for name, (rows, fused, variant) in configs.items():
+            for name, cfg in configs.items():
+                rows, fused, variant = cfg[:3]
                 K.GEMV_BATCH_ROWS, K.GEMV_BATCH_FUSED_NORM, K.GEMV_BATCH_VARIANT = rows, fused, variant
+                K.DECODE_SPLITK_NORM = cfg[3] if len(cfg) > 3 else True
                 dec._bstate = {}
                 out = dec.decode_graph_batch(emb, a.tokens + 2)
                 torch.cuda.synchronize()
