@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgpt4roi_hip.so")
+LIB_PATH = os.environ.get("G4R_LIB") or os.path.join(HERE, "lib", "libgpt4roi_hip.so")     # (G4R_LIB: tools, a library built with G4R_BUILD_TAG)
 ABI_VERSION = 5
 _lib = None
 

@@ -15,8 +15,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "lib", "obj")
-LIB = os.path.join(HERE, "lib", "libgpt4roi_hip.so")
+_TAG = os.environ.get("G4R_BUILD_TAG", "")        # tools: a second library next to the shipped one (A/B of compile-time switches), see _lib.py G4R_LIB
+OBJ = os.path.join(HERE, "lib", "obj" + ("_" + _TAG if _TAG else ""))
+LIB = os.path.join(HERE, "lib", "libgpt4roi_hip" + ("_" + _TAG if _TAG else "") + ".so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(os.path.dirname(HERE), "include"),
