@@ -286,3 +286,25 @@ def test_gemv_batch_fused_rmsnorm_is_the_separate_launch(B, Kd, dtype):
     assert rel(fused, (h.to(dtype).float() * gamma).to(dtype).float() @ w.float().t()) < TOL[dtype]
     sw = K.gemv_batch(x, w, norm_weight=gamma, eps=1e-6, act="swiglu")
     assert torch.equal(sw, K.gemv_batch(K.rmsnorm(x, gamma, 1e-6), w, act="swiglu"))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Kd", [(8, 4096), (16, 4096), (8, 11008), (5, 11008)])
+def test_batched_decode_reduce_fused_with_the_next_rmsnorm_is_bit_identical(M, Kd, dtype):
+    """LlamaDecoder._decode_step_batch on the tiles path (round 6): o_proj / down_proj as K slices whose reduce launch also adds the
+    residual and applies the next RMSNorm (gemm_partials + rmsnorm_splitk) against gemm(residual=) + rmsnorm(): every element of
+    the residual stream and of the normalised rows, six draws each (7.9 M elements compared on the GPU box: no mismatch)"""
+    plan = K.decode_split_plan(M, 4096, Kd)
+    assert plan == (14, 4)
+    for seed in range(6):
+        a = rnd(M, Kd, seed=100 + seed, dtype=dtype)
+        w = rnd(4096, Kd, seed=200 + seed, scale=0.03, dtype=dtype)
+        x = rnd(M, 4096, seed=300 + seed, scale=1.0, dtype=dtype)
+        gam = 1 + 0.1 * rnd(4096, seed=400 + seed, dtype=torch.float32)
+        x1 = K.gemm(a, w, residual=x)
+        h1 = K.rmsnorm(x1, gam, 1e-6)
+        part, ns = K.gemm_partials(a, w, plan[1], plan[0])
+        x2, h2 = K.rmsnorm_splitk(part, ns, x, gam, 1e-6)
+        assert torch.equal(x1, x2) and torch.equal(h1, h2)
+    assert K.decode_split_plan(3, 4096, 4096) is None              # few rows of K <= 8192: the weight-streaming kernel, no K slices
+
