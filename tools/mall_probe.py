@@ -36,4 +36,4 @@ for name, N in (("o_proj 4096x4096 (33.5 MB)", 4096), ("q|k|v 12288x4096 (100 MB
         torch.cuda.synchronize()
         res[mode] = e0.elapsed_time(e1) * 1e3 / (20 * 24)
     mb = N * 4096 * 2 / 1e6
-    print(f"{name}: hot {res['hot']:.2f} us ({mb / res["hot"]:.2f} TB/s)  cold {res['cold']:.2f} us ({mb / res["cold"]:.2f} TB/s)  copies {ncopies}")
+    print(f"{name}: hot {res['hot']:.2f} us ({mb / res['hot']:.2f} TB/s)  cold {res['cold']:.2f} us ({mb / res['cold']:.2f} TB/s)  copies {ncopies}")
